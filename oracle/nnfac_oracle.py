@@ -1,0 +1,419 @@
+"""CPU oracle for the nn_fac HALS-NNLS / beta-MU hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy restatement of the reference algorithms (ax-le/nn-fac 0.3.4).
+It is the checker for the HIP engine, never the thing shipped: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+Nothing under ``nn_fac_amd/`` imports it.
+
+Parity status: PINNED.  ``oracle/gen_golden.py`` runs the real reference (imported
+from /root/reference in the build container) on seeded inputs, first re-asserting
+the reference's own known answers (tests/NMF_tests.py:35-41,68-135), and stores
+inputs + outputs in ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks this
+restatement against those fixtures to ~1e-12 (fp64).
+
+Each function cites the reference lines it follows.  The statement sequence (same
+``np.dot`` shapes, same Python row loop, same temporaries) is kept so that timing the
+oracle is a fair stand-in for timing the reference (``cpu_baseline.kind = "port"``).
+
+The tensor helpers restate the documented semantics of tensorly 0.6.0 (pinned in the
+reference's setup.py:30, not vendored in /root/reference and not installable offline).
+"""
+import math
+import time
+
+import numpy as np
+
+EPS_MU = 1e-12  # reference: nn_fac/update_rules/mu.py:18
+
+
+# --------------------------------------------------------------------------------------
+# exceptions (nn_fac/utils/errors.py:8-18).  They derive from BaseException there too.
+# --------------------------------------------------------------------------------------
+class ArgumentException(BaseException):
+    pass
+
+
+class InvalidArgumentValue(ArgumentException):
+    pass
+
+
+class CustomNotValidFactors(ArgumentException):
+    pass
+
+
+class CustomNotEngouhFactors(ArgumentException):
+    pass
+
+
+class InvalidInitializationType(ArgumentException):
+    pass
+
+
+class OptimException(BaseException):
+    pass
+
+
+class ZeroColumnWhenUnautorized(OptimException):
+    pass
+
+
+# --------------------------------------------------------------------------------------
+# a1: accelerated HALS NNLS  (nn_fac/update_rules/nnls.py:24-198)
+# --------------------------------------------------------------------------------------
+def hals_nnls_acc(UtM, UtU, in_V, maxiter=500, atime=None, alpha=0.5, delta=0.01,
+                  sparsity_coefficient=None, normalize=False, nonzero=False,
+                  sweep_log=None):
+    """Gauss-Seidel sweep over the rows of V with projection on the nonnegative orthant.
+
+    nnls.py:130-135 argument checks; :147 works on a copy; :149-152 initial state;
+    :156 loop condition; :158-185 row update; :187-196 bookkeeping; :198 return.
+    ``sweep_log`` (oracle-only) receives nodelta of every sweep.
+    """
+    for name, a in (("UtM", UtM), ("UtU", UtU), ("in_V", in_V)):
+        if len(np.shape(a)) != 2:
+            raise ArgumentException(f"Argument {name} should be a matrix, got shape {np.shape(a)}.")
+    r, n = np.shape(UtM)
+    if not in_V.size:
+        # nnls.py:138-145 -- effectively dead in the reference (np.linalg.linalg); kept for shape.
+        V = np.linalg.solve(UtU, UtM)
+        V[V < 0] = 0
+        V = (np.sum(UtM * V) / np.sum(UtU * np.dot(V, V.T))) * V
+    else:
+        V = in_V.copy()
+
+    rho, eps0, cnt, eps = 100000, 0, 1, 1
+    t0 = time.time()
+    while eps >= delta * eps0 and cnt <= 1 + alpha * rho and cnt <= maxiter:
+        nodelta = 0
+        for k in range(r):
+            if UtU[k, k] != 0:
+                if sparsity_coefficient != None:  # noqa: E711  (reference compares with !=)
+                    step = np.maximum((UtM[k, :] - UtU[k, :] @ V - sparsity_coefficient * np.ones(n)) / UtU[k, k],
+                                      -V[k, :])
+                else:
+                    step = np.maximum((UtM[k, :] - UtU[k, :] @ V) / UtU[k, k], -V[k, :])
+                V[k, :] = V[k, :] + step
+                nodelta = nodelta + np.dot(step, np.transpose(step))
+                if nonzero and (V[k, :] == 0).all():
+                    V[k, :] = 1e-16 * np.max(V)
+            elif nonzero:
+                raise ZeroColumnWhenUnautorized("Column " + str(k) + " of U is zero with nonzero condition")
+            if normalize:
+                nrm = np.linalg.norm(V[k, :])
+                if nrm != 0:
+                    V[k, :] /= nrm
+                else:
+                    V[k, :] = 1 / n ** (1 / 2)
+        if cnt == 1:
+            eps0 = nodelta
+            btime = max(time.time() - t0, 10e-7)
+            if atime:
+                rho = atime / btime
+        eps = nodelta
+        if sweep_log is not None:
+            sweep_log.append(float(nodelta))
+        cnt += 1
+    return V, eps, cnt, rho
+
+
+# --------------------------------------------------------------------------------------
+# a6: beta-divergence and the MU exponent  (nn_fac/utils/beta_divergence.py:17-80)
+# --------------------------------------------------------------------------------------
+def gamma_beta(beta):
+    """beta_divergence.py:75-80."""
+    if beta < 1:
+        return 1 / (2 - beta)
+    if beta > 2:
+        return 1 / (beta - 1)
+    return 1
+
+
+def beta_divergence(a, b, beta):
+    """beta_divergence.py:42-52 (inputs must be strictly positive for beta in {0,1})."""
+    if beta < 0:
+        raise InvalidArgumentValue("Invalid value for beta: negative one.")
+    if beta == 1:
+        q = np.divide(a, b, where=(b != 0))
+        return np.sum(a * np.log(q, where=(q != 0)) - a + b)
+    if beta == 0:
+        return np.sum(a / b - np.log(a / b, where=(a != 0)) - 1)
+    return np.sum(1 / (beta * (beta - 1)) * (a ** beta + (beta - 1) * b ** beta - beta * a * (b ** (beta - 1))))
+
+
+# --------------------------------------------------------------------------------------
+# a5: multiplicative update  (nn_fac/update_rules/mu.py:20-97)
+# --------------------------------------------------------------------------------------
+def mu_betadivmin(U, V, M, beta):
+    """mu.py:79-97.  No epsilon in any denominator; result clipped at 1e-12."""
+    if beta < 0:
+        raise InvalidArgumentValue("Invalid value for beta: negative one.")
+    K = np.dot(U, V)
+    if beta == 1:
+        Kinv = K ** (-1)
+        line = np.sum(V.T, axis=0)
+        denom = np.array([line for _ in range(np.shape(K)[0])])
+        return np.maximum(U * (np.dot((Kinv * M), V.T) / denom), EPS_MU)
+    if beta == 2:
+        denom = np.dot(K, V.T)
+        return np.maximum(U * (np.dot(M, V.T) / denom), EPS_MU)
+    if beta == 3:
+        denom = np.dot(K ** 2, V.T)
+        return np.maximum(U * (np.dot((K * M), V.T) / denom) ** gamma_beta(beta), EPS_MU)
+    denom = np.dot(K ** (beta - 1), V.T)
+    return np.maximum(U * (np.dot((K ** (beta - 2) * M), V.T) / denom) ** gamma_beta(beta), EPS_MU)
+
+
+def switch_alternate_mu(data, U, V, beta, matrix):
+    """mu.py:24-29."""
+    if matrix in ("U", "W"):
+        return mu_betadivmin(U, V, data, beta)
+    if matrix in ("V", "H"):
+        return np.transpose(mu_betadivmin(V.T, U.T, data.T, beta))
+    raise InvalidArgumentValue(f"Invalid value for matrix: got {matrix}.")
+
+
+# --------------------------------------------------------------------------------------
+# a2/a3/a4: NMF driver  (nn_fac/nmf.py:19-458)
+# --------------------------------------------------------------------------------------
+def one_nmf_step(data, rank, U_in, V_in, norm_data, update_rule, beta,
+                 sparsity_coefficients, fixed_modes, normalize, deterministic, sweeps=None):
+    """nmf.py:387-458.  ``sweeps`` (oracle-only) collects cnt-1 of each hals call."""
+    if update_rule not in ("hals", "mu"):
+        raise InvalidArgumentValue(f"Invalid update rule: {update_rule}")
+    if update_rule == "hals" and beta != 2:
+        raise InvalidArgumentValue("hals is only valid for beta = 2.")
+    if len(sparsity_coefficients) != 2:
+        raise ValueError("NMF needs 2 sparsity coefficients to be performed")
+    U, V = U_in.copy(), V_in.copy()
+    a = math.inf if deterministic else 0.5
+
+    if 0 not in fixed_modes:
+        if update_rule == "hals":
+            t = time.time()
+            VVt = np.dot(V, np.transpose(V))
+            VMt = np.dot(V, np.transpose(data))
+            t = time.time() - t
+            out = hals_nnls_acc(VMt, VVt, np.transpose(U_in), maxiter=100, atime=t, alpha=a, delta=0.01,
+                                sparsity_coefficient=sparsity_coefficients[0], normalize=normalize[0],
+                                nonzero=False)
+            U = np.transpose(out[0])
+            if sweeps is not None:
+                sweeps.append(out[2] - 1)
+        else:
+            U = switch_alternate_mu(data, U, V, beta, "U")
+
+    if 1 not in fixed_modes:
+        if update_rule == "hals":
+            t = time.time()
+            UtU = np.dot(np.transpose(U), U)
+            UtM = np.dot(np.transpose(U), data)
+            t = time.time() - t
+            out = hals_nnls_acc(UtM, UtU, V_in, maxiter=100, atime=t, alpha=a, delta=0.01,
+                                sparsity_coefficient=sparsity_coefficients[1], normalize=normalize[1],
+                                nonzero=False)
+            V = out[0]
+            if sweeps is not None:
+                sweeps.append(out[2] - 1)
+        else:
+            V = switch_alternate_mu(data, U, V, beta, "V")
+
+    sp = np.where(np.array(sparsity_coefficients) == None, 0, sparsity_coefficients)  # noqa: E711
+    if update_rule == "hals":
+        # matrix 1-norm (max column abs-sum), NOT entry-wise l1: nmf.py:452
+        cost = np.linalg.norm(data - np.dot(U, V), ord='fro') ** 2 \
+            + 2 * (sp[0] * np.linalg.norm(U, ord=1) + sp[1] * np.linalg.norm(V, ord=1))
+    else:
+        cost = beta_divergence(data, np.dot(U, V), beta)
+    return U, V, cost
+
+
+def compute_nmf(data, rank, U_in, V_in, n_iter_max=100, tol=1e-8, update_rule="hals", beta=2,
+                sparsity_coefficients=[None, None], fixed_modes=[], normalize=[False, False],
+                verbose=False, return_costs=False, deterministic=False, sweeps=None):
+    """nmf.py:284-329."""
+    U, V = U_in.copy(), V_in.copy()
+    costs, toc = [], []
+    norm_data = np.linalg.norm(data)
+    tic = time.time()
+    if sparsity_coefficients is None:
+        sparsity_coefficients = [None, None]
+    if fixed_modes is None:
+        fixed_modes = []
+    if normalize is None or normalize is False:
+        normalize = [False, False]
+    for it in range(n_iter_max):
+        U, V, c = one_nmf_step(data, rank, U, V, norm_data, update_rule, beta, sparsity_coefficients,
+                               fixed_modes, normalize, deterministic, sweeps=sweeps)
+        toc.append(time.time() - tic)
+        costs.append(c)
+        if it > 0 and abs(costs[-2] - costs[-1]) < tol:
+            break
+    if return_costs:
+        return np.array(U), np.array(V), costs, toc
+    return np.array(U), np.array(V)
+
+
+def nmf_random_init(shape, rank, seed):
+    """initialize_factors.py:40-46 with deterministic=True: legacy global RandomState stream."""
+    import random
+    np.random.seed(seed)
+    random.seed(seed)
+    m, n = shape
+    return np.random.rand(m, rank), np.random.rand(rank, n)
+
+
+def nmf(data, rank, init="random", U_0=None, V_0=None, n_iter_max=100, tol=1e-8, update_rule="hals", beta=2,
+        sparsity_coefficients=[None, None], fixed_modes=[], normalize=[False, False], verbose=False,
+        return_costs=False, deterministic=False, seed=0, sweeps=None):
+    """nmf.py:175-193 (random and custom init only; nndsvd is an initialiser, out of scope)."""
+    if min(data.shape) < rank:
+        rank = min(data.shape)
+    if deterministic:
+        np.random.seed(seed)
+    if init.lower() == "custom":
+        if U_0 is None or V_0 is None:
+            raise CustomNotValidFactors("Custom initialization, but (at least) one factor is set to 'None'")
+    elif init.lower() == "random":
+        if deterministic:
+            U_0, V_0 = nmf_random_init(data.shape, rank, seed)
+        else:
+            U_0, V_0 = np.random.rand(data.shape[0], rank), np.random.rand(rank, data.shape[1])
+    else:
+        raise InvalidInitializationType("Initialization type not understood (oracle: random|custom).")
+    return compute_nmf(data, rank, U_0, V_0, n_iter_max=n_iter_max, tol=tol, update_rule=update_rule, beta=beta,
+                       sparsity_coefficients=sparsity_coefficients, fixed_modes=fixed_modes, normalize=normalize,
+                       verbose=verbose, return_costs=return_costs, deterministic=deterministic, sweeps=sweeps)
+
+
+# --------------------------------------------------------------------------------------
+# tensorly 0.6.0 semantics used by ntf.py (published behaviour)
+# --------------------------------------------------------------------------------------
+def unfold(t, mode):
+    return np.moveaxis(t, mode, 0).reshape(t.shape[mode], -1)
+
+
+def fold(u, mode, shape):
+    full = [shape[mode]] + [s for i, s in enumerate(shape) if i != mode]
+    return np.moveaxis(u.reshape(full), 0, mode)
+
+
+def khatri_rao(mats, skip_matrix=None):
+    ms = [m for i, m in enumerate(mats) if i != skip_matrix]
+    res = ms[0]
+    R = res.shape[1]
+    for M in ms[1:]:
+        res = (res[:, None, :] * M[None, :, :]).reshape(-1, R)
+    return res
+
+
+def mode_dot(t, M, mode, transpose=False):
+    if transpose:
+        M = np.conj(M.T)
+    shape = list(t.shape)
+    shape[mode] = M.shape[0]
+    return fold(M @ unfold(t, mode), mode, shape)
+
+
+def multi_mode_dot(t, mats, skip=None, transpose=False):
+    out = t
+    for i, M in enumerate(mats):
+        if i == skip:
+            continue
+        out = mode_dot(out, M, i, transpose=transpose)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# a7: NTF driver  (nn_fac/ntf.py:201-477)
+# --------------------------------------------------------------------------------------
+def one_ntf_step(unfolded_tensors, rank, in_factors, norm_tensor, update_rule, beta,
+                 sparsity_coefficients, fixed_modes, normalize, alpha=0.5, delta=0.01, sweeps=None):
+    """ntf.py:422-477.  Cost reuses the loop-leaked mode/rhs/krao of the last updated mode."""
+    if update_rule not in ("hals", "mu"):
+        raise InvalidArgumentValue(f"Invalid update rule: {update_rule}")
+    if update_rule == "hals" and beta != 2:
+        raise InvalidArgumentValue("hals is only valid for beta = 2.")
+    for f in fixed_modes:
+        sparsity_coefficients[f] = None
+    factors = in_factors.copy()
+    modes = [m for m in range(len(unfolded_tensors)) if m not in fixed_modes]
+    for mode in modes:
+        if update_rule == "hals":
+            t = time.time()
+            cross = np.ones((rank, rank))
+            for i, f in enumerate(factors):
+                if i != mode:
+                    cross *= np.dot(np.transpose(f), f)
+            krao = khatri_rao(factors, skip_matrix=mode)
+            rhs = np.dot(unfolded_tensors[mode], krao)
+            t = time.time() - t
+            out = hals_nnls_acc(np.transpose(rhs), cross, np.transpose(factors[mode]), maxiter=100, atime=t,
+                                alpha=alpha, delta=delta, sparsity_coefficient=sparsity_coefficients[mode],
+                                normalize=normalize[mode])
+            factors[mode] = np.transpose(out[0])
+            if sweeps is not None:
+                sweeps.append(out[2] - 1)
+        else:
+            krao = khatri_rao(factors, skip_matrix=mode)
+            factors[mode] = mu_betadivmin(factors[mode], krao.T, unfolded_tensors[mode], beta)
+    sparsity_error = 0
+    for idx, s in enumerate(sparsity_coefficients):
+        if s:
+            sparsity_error += 2 * (s * np.linalg.norm(factors[idx], ord=1))
+    if update_rule == "hals":
+        rec = norm_tensor ** 2 - 2 * np.dot(factors[mode].reshape(-1), rhs.reshape(-1)) \
+            + np.sqrt(np.sum(np.abs(np.dot(factors[mode], np.transpose(krao))) ** 2)) ** 2
+    else:
+        rec = beta_divergence(unfolded_tensors[mode], factors[mode] @ krao.T, beta)
+    return factors, (rec + sparsity_error) / (norm_tensor ** 2)
+
+
+def compute_ntf(tensor_in, rank, factors_in, n_iter_max=100, tol=1e-8, update_rule="hals", beta=2,
+                sparsity_coefficients=[], fixed_modes=[], normalize=[], verbose=False, return_costs=False,
+                alpha=0.5, delta=0.01, sweeps=None):
+    """ntf.py:288-344.  ``alpha``/``delta`` are oracle-only pass-throughs to one_ntf_step
+    (the reference never overrides them: ntf.py:316-317, so its HALS path is wall-clock dependent)."""
+    factors = list(factors_in).copy()
+    tensor = tensor_in.copy()
+    norm_tensor = np.sqrt(np.sum(np.abs(tensor) ** 2))
+    nb = tensor.ndim
+    if sparsity_coefficients is None or len(sparsity_coefficients) != nb:
+        sparsity_coefficients = [None] * nb
+    if fixed_modes is None:
+        fixed_modes = []
+    if normalize is None or len(normalize) != nb:
+        normalize = [False] * nb
+    costs, toc = [], []
+    tic = time.time()
+    unf = [unfold(tensor, m) for m in range(nb)]
+    for it in range(n_iter_max):
+        factors, c = one_ntf_step(unf, rank, factors, norm_tensor, update_rule, beta, sparsity_coefficients,
+                                  fixed_modes, normalize, alpha=alpha, delta=delta, sweeps=sweeps)
+        toc.append(time.time() - tic)
+        costs.append(c)
+        if it > 0 and abs(costs[-2] - costs[-1]) < tol:
+            break
+    if return_costs:
+        return factors, costs, toc
+    return factors
+
+
+# --------------------------------------------------------------------------------------
+# synthetic inputs shared by tests and bench
+# --------------------------------------------------------------------------------------
+def synth_nmf(m, n, r, seed=0, dtype=np.float32):
+    """X = W*H* + 1e-2*rand, plus inits U0, V0, all from one legacy RandomState(seed) stream."""
+    rng = np.random.RandomState(seed)
+    W, H = rng.rand(m, r), rng.rand(r, n)
+    X = (W @ H + 1e-2 * rng.rand(m, n)).astype(dtype)
+    U0 = rng.rand(m, r).astype(dtype)
+    V0 = rng.rand(r, n).astype(dtype)
+    return X, U0, V0
+
+
+def synth_ntf(shape, R, seed=0, dtype=np.float32):
+    rng = np.random.RandomState(seed)
+    gen = [rng.rand(s, R) for s in shape]
+    T = np.einsum('ir,jr,kr->ijk', *gen) + 1e-2 * rng.rand(*shape)
+    F0 = [rng.rand(s, R).astype(dtype) for s in shape]
+    return T.astype(dtype), F0

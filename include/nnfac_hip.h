@@ -1,0 +1,133 @@
+/*
+ * nnfac_hip.h -- C ABI of libnnfac_hip.so, the MI355X (gfx950) inner-update engine behind
+ * nn_fac's HALS-NNLS / beta-divergence MU hot path.
+ *
+ * The reference (ax-le/nn-fac) is pure Python: it has no FFI layer.  Each entry point below
+ * names the reference statement(s) it replaces (file:line under /root/reference); the Python
+ * host in nn_fac_amd/ keeps the reference's function signatures and calls these through ctypes
+ * (INTEGRATION.md shows the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every pointer except `ctx`, `out_ctx` is a DEVICE pointer owned by the caller (fp32 unless
+ *     the name says f64); the library never frees or keeps them;
+ *   - matrices are row-major with an explicit leading dimension in ELEMENTS;
+ *   - factors are passed "transposed": an m-by-r factor U is handed over as Ut (r-by-m, ld >= m), which is the
+ *     layout hals_nnls_acc itself works on (nnls.py:147 takes U_in^T, V_in as r-by-n_cols);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ *     allocates nothing: scratch comes from the context workspace (sized at nnf_ctx_create);
+ *   - return value: 0 = NNF_OK, negative = error (nnf_status_string); no exception crosses the ABI;
+ *   - a context is bound to one device and must not be used from two threads at once; one context
+ *     per stream if calls on different streams may overlap (they share the workspace otherwise).
+ *   - rank limit: 1 <= r <= 128 (NNF_ERR_UNSUPPORTED above).
+ */
+#ifndef NNFAC_HIP_H
+#define NNFAC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNF_OK 0
+#define NNF_ERR_ARG (-1)         /* bad size / null pointer / bad flag combination            */
+#define NNF_ERR_LAUNCH (-2)      /* HIP runtime error on launch (hipGetLastError)              */
+#define NNF_ERR_UNSUPPORTED (-3) /* shape outside the built kernels (r > 128, ...)             */
+#define NNF_ERR_WORKSPACE (-4)   /* context workspace too small for this call                  */
+#define NNF_ERR_DEVICE (-5)      /* wrong / unavailable device                                 */
+
+#define NNF_MAX_RANK 128
+
+/* hals flags */
+#define NNF_HALS_SPARSITY 1u  /* subtract `sparsity` in the row update (nnls.py:162-164)       */
+#define NNF_HALS_NORMALIZE 2u /* l2-normalise each row after its update (nnls.py:179-185)      */
+#define NNF_HALS_NONZERO 4u   /* all-zero row -> 1e-16*max(V) (nnls.py:173-174)                */
+
+typedef struct nnf_ctx nnf_ctx;
+
+/* status block written by nnf_hals_solve_f32 (device memory, 8 doubles) */
+#define NNF_HALS_ST_EPS 0     /* nodelta of the last executed sweep        (nnls.py:195)       */
+#define NNF_HALS_ST_CNT 1     /* cnt as returned by the reference = sweeps done + 1 (:196)     */
+#define NNF_HALS_ST_EPS0 2    /* nodelta of the first sweep                (nnls.py:188)       */
+#define NNF_HALS_ST_ERR 3     /* 0 ok; 1 = grid barrier timed out (result invalid);
+                                 2 = zero Gram diagonal met with NONZERO set (nnls.py:176-177) */
+#define NNF_HALS_ST_WORDS 8
+
+int nnf_version(void);
+const char* nnf_status_string(int status);
+
+/* Create a context on HIP device `device` with `workspace_bytes` of scratch (0 = default 256 MiB). */
+int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_bytes);
+int nnf_ctx_destroy(nnf_ctx* ctx);
+size_t nnf_ctx_workspace_bytes(const nnf_ctx* ctx);
+
+/* G[r x r] = A[r x K] * A^T.   Replaces VVt = np.dot(V, V.T) (nmf.py:407), UtU = np.dot(U.T, U) (nmf.py:432),
+ * and each factor Gram in ntf.py:442-445.  Split-K partials are summed in fp64 in a fixed order. */
+int nnf_gram_f32(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg, void* stream);
+
+/* out[r x m] = V[r x n] * X[m x n]^T.   Replaces VMt = np.dot(V, data.T) (nmf.py:408), the "X H^T" product. */
+int nnf_xht_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r, int64_t ldv,
+                float* out, int64_t ldo, void* stream);
+
+/* out[r x n] = Ut[r x m] * X[m x n].   Replaces UtM = np.dot(U.T, data) (nmf.py:433), the "W^T X" product.
+ * Split over m across workgroups; partial slabs summed in a fixed order (bitwise reproducible). */
+int nnf_xty_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int r, int64_t ldu,
+                float* out, int64_t ldo, void* stream);
+
+/* *out_f64 = sum_ij (X[i,j] - sum_k Ut[k,i] V[k,j])^2.   Replaces np.linalg.norm(data - U@V, 'fro')**2 (nmf.py:452)
+ * without materialising U@V.  Per-lane fp32, then fp64 from the wave level up, fixed order. */
+int nnf_frob_resid_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                       const float* V, int64_t ldv, int r, double* out_f64, void* stream);
+
+/* hals_nnls_acc (nnls.py:147-198) on device: V (r x ncols, in/out) is swept in place until
+ *   eps >= delta*eps0 fails, or sweeps == max_sweeps                         (nnls.py:156)
+ * max_sweeps is min(maxiter, floor(1+alpha*rho)) resolved by the host; the wall-clock rule of nnls.py:190-194 stays
+ * on the host side (nn_fac_amd/update_rules/nnls.py).  UtU is r x r (ldg), UtM r x ncols (ldm).
+ * status_f64: NNF_HALS_ST_WORDS doubles.  The sweep loop, the global sum of squared steps and the stopping decision
+ * all run inside one persistent launch (grid barrier per sweep); nothing is read back by the host. */
+int nnf_hals_solve_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V, int64_t ldv,
+                       int r, int64_t ncols, int max_sweeps, double delta, float sparsity, unsigned flags,
+                       double* status_f64, void* stream);
+
+/* Same sweeps, fixed count, no stopping rule: runs exactly `nsweeps` sweeps and writes the LOCAL sum of squared steps of
+ * each sweep to nodelta_f64[0..nsweeps).  Building block of the row-sharded solve (the stopping scalar is all-reduced by
+ * the host between chunks). */
+int nnf_hals_sweeps_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V, int64_t ldv,
+                        int r, int64_t ncols, int nsweeps, float sparsity, unsigned flags, double* nodelta_f64,
+                        void* stream);
+
+/* mu_betadivmin (mu.py:79-97) for the left factor, transposed storage:
+ *   Ut_out[k,i] = max(Ut[k,i] * (num[k,i]/den[k,i])^gamma(beta), 1e-12),
+ *   num = ((UV)^(beta-2) .* X) V^T, den = (UV)^(beta-1) V^T       (beta=1: den = rowsum(V); beta=2: Gram form)
+ * One pass over X; U@V is never materialised.  Ut_out may alias Ut only if it is the same pointer. */
+int nnf_mu_left_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                    const float* V, int64_t ldv, int r, double beta, float* Ut_out, int64_t lduo, void* stream);
+
+/* switch_alternate_mu(..., "V") (mu.py:26-27): V_out[k,j] = max(V[k,j] * (num/den)^gamma, 1e-12) with
+ *   num = U^T((UV)^(beta-2) .* X), den = U^T (UV)^(beta-1); split over m, fixed-order slab reduction. */
+int nnf_mu_right_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                     const float* V, int64_t ldv, int r, double beta, float* V_out, int64_t ldvo, void* stream);
+
+/* beta_divergence(X, U@V, beta) (beta_divergence.py:45-52) fused with the product; *out_f64 = the sum. */
+int nnf_betadiv_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                    const float* V, int64_t ldv, int r, double beta, double* out_f64, void* stream);
+
+/* MTTKRP of a dense 3-way tensor T[I x J x K] (C order) with the Khatri-Rao product of the two other factors
+ * generated on the fly: replaces khatri_rao + np.dot(unfolded[mode], krao) (ntf.py:448-449).
+ * Factors are passed transposed (Ft_a: R x dim_a, ld = ld_a).  out is R x dim_mode (the rhs^T hals_nnls_acc wants). */
+int nnf_mttkrp3_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t K, const float* Ft0, int64_t ld0,
+                    const float* Ft1, int64_t ld1, const float* Ft2, int64_t ld2, int R, int mode, float* out,
+                    int64_t ldo, void* stream);
+
+/* small helpers used by the drivers (all deterministic, fixed-order) */
+/* *out_f64 = sum_ij A[i,j]*B[i,j]   (fp64 accumulate)  -- inner products of ntf.py:470 */
+int nnf_dot_f32(nnf_ctx* ctx, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int64_t cols,
+                double* out_f64, void* stream);
+/* C = A .* B elementwise, r x r  (Hadamard of Grams, ntf.py:442-445) */
+int nnf_hadamard_f32(nnf_ctx* ctx, const float* A, const float* B, float* C, int64_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNFAC_HIP_H */

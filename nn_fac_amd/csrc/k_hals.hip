@@ -1,0 +1,243 @@
+// Accelerated HALS NNLS sweeps (nn_fac/update_rules/nnls.py:147-198) as ONE persistent launch.
+//
+// Data: V (r x ncols, row-major) is updated in place; UtM (r x ncols) and UtU (r x r) are read-only.
+// Every column of V is an independent Gauss-Seidel problem; the only cross-column coupling is the
+// stopping scalar sum(step^2) (and, with NORMALIZE / NONZERO, a row norm / row-all-zero / max(V)).
+//
+// Fast path (flags subset of {SPARSITY}):
+//   one lane = one column; the column of V (and of UtM when RP <= 64) lives in VGPRs for the whole solve;
+//   the padded Gram (RP x RP) and 1/diag are read through the scalar cache (wave-uniform operands -> s_load + v_fmac with
+//   an SGPR source), so a sweep costs RP^2 VALU FMAs per column and no LDS or HBM traffic at all.
+//   Per sweep the workgroups exchange ONE double each through a grid barrier (write-through store of the partial,
+//   vmcnt drain, agent-scope counter add, relaxed poll, every workgroup re-sums all partials in index order so all
+//   reach the same decision bit for bit; cdna_hip_programming.md Guideline 16, R1 form).  Spins are bounded.
+//   If ncols exceeds the resident thread count the same kernel strides over column sets, re-reading its own
+//   stores (no cross-workgroup hand-off of V is ever needed).
+// Generic path (NORMALIZE / NONZERO, any r): columns in LDS, run-time rank loop, one grid reduction per row.
+#include "k_hals_common.h"
+
+// prep: padded Gram, 1/diag, zeroed barrier words and status
+__global__ void nnf_hals_prep_kernel(const float* __restrict__ UtU, int64_t ldg, int r, int RP, float* __restrict__ Gp,
+                                     float* __restrict__ dinv, unsigned* counter, double* status) {
+    for (int e = threadIdx.x; e < RP * RP; e += blockDim.x) {
+        const int a = e / RP, b = e - a * RP;
+        Gp[e] = (a < r && b < r) ? UtU[(int64_t)a * ldg + b] : 0.f;
+    }
+    for (int k = threadIdx.x; k < RP; k += blockDim.x) {
+        const float d = (k < r) ? UtU[(int64_t)k * ldg + k] : 0.f;
+        dinv[k] = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;
+    }
+    if (threadIdx.x == 0) {
+        *counter = 0u;
+        if (status) {
+            status[NNF_HALS_ST_EPS] = 1.0;
+            status[NNF_HALS_ST_CNT] = 1.0;
+            status[NNF_HALS_ST_EPS0] = 0.0;
+            status[NNF_HALS_ST_ERR] = 0.0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Generic path: any r, all flags.  128 threads per workgroup, one column per thread, column in LDS
+// (vl[k*128 + tid]); each row update may need a grid reduction (row sum of squares, row non-zero count, max V).
+// Requires all workgroups resident (grid sized by the host) -- columns beyond the resident set are strided.
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __restrict__ UtM, int64_t ldm,
+                                                               const float* __restrict__ Gp, const float* __restrict__ dinv,
+                                                               int RP, float* __restrict__ V, int64_t ldv, int r,
+                                                               int64_t ncols, int max_sweeps, double delta, float sp,
+                                                               unsigned flags, hals_sync sy, double* __restrict__ status,
+                                                               double* __restrict__ sweep_partials) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* vl = reinterpret_cast<float*>(smem);                       // [r][128]
+    double* red = reinterpret_cast<double*>(smem + (size_t)r * 128 * 4 + 16);
+    __shared__ unsigned lds_flag;
+    const int nblocks = gridDim.x;
+    const int64_t gthreads = (int64_t)nblocks * 128;
+    const int64_t gtid = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    const bool rowsync = (flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) != 0;
+    // with row-level grid reductions every thread must take part in every exchange: one column per thread only
+    const bool active = gtid < ncols;
+    unsigned epoch = 0;
+    double eps0 = 0.0, eps = 1.0;
+    int done = 0, err = 0;
+    bool ok = true;
+    float* mycol = vl + threadIdx.x;
+    const int64_t col0 = active ? gtid : 0;
+    for (int k = 0; k < r; ++k) mycol[k * 128] = active ? V[(int64_t)k * ldv + col0] : 0.f;
+    for (int s = 1; s <= max_sweeps && ok; ++s) {
+        double nd = 0.0;
+        for (int k = 0; k < r; ++k) {
+            const float di = dinv[k];
+            if (di != 0.f) {
+                float dot = 0.f;
+                for (int i = 0; i < r; ++i) dot = fmaf(Gp[k * RP + i], mycol[i * 128], dot);
+                const float vk = mycol[k * 128];
+                float step = fmaxf((UtM[(int64_t)k * ldm + col0] - dot - sp) * di, -vk);
+                if (!active) step = 0.f;
+                mycol[k * 128] = vk + step;
+                nd += (double)step * (double)step;
+            } else if (flags & NNF_HALS_NONZERO) {
+                err = 2;   // nnls.py:176-177
+            }
+            if (rowsync) {
+                const float vk = mycol[k * 128];
+                double vmax = 0.0;
+                if (flags & NNF_HALS_NONZERO)
+                    for (int i = 0; i < r; ++i) vmax = fmax(vmax, (double)mycol[i * 128]);
+                double mine[3] = {active ? (double)vk * (double)vk : 0.0, (active && vk != 0.f) ? 1.0 : 0.0,
+                                  active ? vmax : -1.0e300};
+                double tot[3];
+                const double b0 = nnf_block_sum_f64(mine[0], red);
+                const double b1 = nnf_block_sum_f64(mine[1], red);
+                // block max of mine[2]
+                double bm = mine[2];
+                for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(bm, o, 64); bm = y > bm ? y : bm; }
+                if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bm;
+                __syncthreads();
+                bm = red[0] > red[1] ? red[0] : red[1];
+                __syncthreads();
+                double pub[3] = {b0, b1, bm};
+                if (threadIdx.x != 0) { pub[0] = 0; pub[1] = 0; }
+                ok = grid_exchange<3>(sy, ++epoch, nblocks, pub, tot, red, &lds_flag);
+                if (!ok) break;
+                if ((flags & NNF_HALS_NONZERO) && di != 0.f && tot[1] == 0.0 && active)
+                    mycol[k * 128] = (float)(1e-16 * tot[2]);            // nnls.py:173-174
+                if (flags & NNF_HALS_NORMALIZE) {
+                    // the norm is taken after the NONZERO refill (nnls.py:179-185)
+                    double nsq = tot[0];
+                    if ((flags & NNF_HALS_NONZERO) && di != 0.f && tot[1] == 0.0) {
+                        const double f = 1e-16 * tot[2];
+                        nsq = f * f * (double)ncols;
+                    }
+                    if (active) {
+                        if (nsq != 0.0) mycol[k * 128] = (float)((double)mycol[k * 128] / sqrt(nsq));
+                        else mycol[k * 128] = (float)(1.0 / sqrt((double)ncols));
+                    }
+                }
+            }
+        }
+        if (!ok) break;
+        done = s;
+        const double bs = nnf_block_sum_f64(nd, red);
+        if (MODE == 1) {
+            if (threadIdx.x == 0) sweep_partials[(size_t)(s - 1) * nblocks + blockIdx.x] = bs;
+        } else {
+            double mine[1] = {bs}, tot[1];
+            ok = grid_exchange<1>(sy, ++epoch, nblocks, mine, tot, red, &lds_flag);
+            if (!ok) break;
+            if (s == 1) eps0 = tot[0];
+            eps = tot[0];
+            if (!(eps >= delta * eps0)) break;
+        }
+    }
+    if (active)
+        for (int k = 0; k < r; ++k) V[(int64_t)k * ldv + col0] = mycol[k * 128];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && status) {
+        if (MODE == 0 && max_sweeps >= 1) {
+            status[NNF_HALS_ST_EPS] = eps;
+            status[NNF_HALS_ST_CNT] = (double)(done + 1);
+            status[NNF_HALS_ST_EPS0] = eps0;
+        }
+        if (!ok) status[NNF_HALS_ST_ERR] = 1.0;
+        else if (err) status[NNF_HALS_ST_ERR] = (double)err;
+    }
+}
+
+// out[s] = sum_b partials[s][b]  (index order)
+__global__ __launch_bounds__(256) void nnf_hals_sum_sweeps_kernel(const double* __restrict__ partials, int nblocks,
+                                                                  double* __restrict__ out) {
+    __shared__ double red[4];
+    const double* p = partials + (size_t)blockIdx.x * nblocks;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += p[b];
+    const double t = nnf_block_sum_f64(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static int pick_rp(int r) {
+    static const int opts[] = {8, 16, 24, 32, 40, 48, 52, 56, 64, 80, 96, 104, 112, 128};
+    for (int o : opts)
+        if (r <= o) return o;
+    return -1;
+}
+
+template <int MODE>
+static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V, int64_t ldv,
+                      int r, int64_t ncols, int nsweeps, double delta, float sparsity, unsigned flags, double* status,
+                      double* nodelta_out, hipStream_t st) {
+    if (!ctx || !UtM || !UtU || !V || r < 1 || ncols < 1 || ldm < ncols || ldv < ncols || ldg < r || nsweeps < 0)
+        return NNF_ERR_ARG;
+    if (MODE == 0 && !status) return NNF_ERR_ARG;
+    if (MODE == 1 && !nodelta_out && nsweeps > 0) return NNF_ERR_ARG;
+    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    if (flags & ~(NNF_HALS_SPARSITY | NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) return NNF_ERR_ARG;
+    const int RP = pick_rp(r);
+    const float sp = (flags & NNF_HALS_SPARSITY) ? sparsity : 0.f;
+    const int max_blocks = 3 * ctx->num_cus > 2048 ? 3 * ctx->num_cus : 2048;
+    nnf_ws_cursor cur(ctx);
+    float* Gp = (float*)cur.take((size_t)RP * RP * 4);
+    float* dinv = (float*)cur.take((size_t)RP * 4);
+    unsigned* counter = (unsigned*)cur.take(256);
+    double* slots = (double*)cur.take((size_t)2 * max_blocks * 4 * 8);
+    double* sweep_partials = nullptr;
+    if (MODE == 1) sweep_partials = (double*)cur.take((size_t)(nsweeps > 0 ? nsweeps : 1) * max_blocks * 8);
+    if (!Gp || !dinv || !counter || !slots || (MODE == 1 && !sweep_partials)) return NNF_ERR_WORKSPACE;
+    hipLaunchKernelGGL(nnf_hals_prep_kernel, dim3(1), dim3(256), 0, st, UtU, ldg, r, RP, Gp, dinv, counter,
+                       MODE == 0 ? status : (double*)nullptr);
+    NNF_CHECK_LAUNCH();
+    if (nsweeps == 0) return NNF_OK;
+    hals_sync sy{counter, slots};
+    int nblocks = 0, rc = NNF_OK;
+    const bool generic = (flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) != 0;
+    if (generic) {
+        // one column per thread, all workgroups resident (row-level grid reductions)
+        const size_t shm = (size_t)r * 128 * 4 + 16 + 3 * 2 * 8 + 64;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_generic_kernel<MODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_generic_kernel<MODE>, 128, shm) != hipSuccess ||
+            nb < 1)
+            return NNF_ERR_LAUNCH;
+        int bpc = nb >= 3 ? nb - 1 : nb;
+        if (bpc > 4) bpc = 4;
+        const int64_t grid = nnf_cdiv(ncols, 128);
+        if (grid > (int64_t)bpc * ctx->num_cus || grid > max_blocks) return NNF_ERR_UNSUPPORTED;
+        nblocks = (int)grid;
+        hipLaunchKernelGGL((nnf_hals_generic_kernel<MODE>), dim3(nblocks), dim3(128), shm, st, UtM, ldm, Gp, dinv, RP, V,
+                           ldv, r, ncols, nsweeps, delta, sp, flags, sy, status, sweep_partials);
+        NNF_CHECK_LAUNCH();
+    } else {
+        if ((((int64_t)(r - 1) * ldv + ncols) * 4) >= (int64_t)0x7fff0000 || (((int64_t)(r - 1) * ldm + ncols) * 4) >= (int64_t)0x7fff0000)
+            return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+        hals_args a{UtM, ldm, Gp, dinv, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status, sweep_partials};
+        if (RP <= 48) rc = nnf_hals_fast_part0(ctx, RP, a, max_blocks, &nblocks, st);
+        else if (RP <= 64) rc = nnf_hals_fast_part1(ctx, RP, a, max_blocks, &nblocks, st);
+        else if (RP <= 104) rc = nnf_hals_fast_part2(ctx, RP, a, max_blocks, &nblocks, st);
+        else rc = nnf_hals_fast_part3(ctx, RP, a, max_blocks, &nblocks, st);
+        if (rc != NNF_OK) return rc;
+    }
+    if (MODE == 1) {
+        hipLaunchKernelGGL(nnf_hals_sum_sweeps_kernel, dim3(nsweeps), dim3(256), 0, st, sweep_partials, nblocks,
+                           nodelta_out);
+        NNF_CHECK_LAUNCH();
+    }
+    return NNF_OK;
+}
+
+extern "C" int nnf_hals_solve_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V,
+                                  int64_t ldv, int r, int64_t ncols, int max_sweeps, double delta, float sparsity,
+                                  unsigned flags, double* status_f64, void* stream) {
+    return hals_entry<0>(ctx, UtM, ldm, UtU, ldg, V, ldv, r, ncols, max_sweeps, delta, sparsity, flags, status_f64,
+                         nullptr, (hipStream_t)stream);
+}
+
+extern "C" int nnf_hals_sweeps_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V,
+                                   int64_t ldv, int r, int64_t ncols, int nsweeps, float sparsity, unsigned flags,
+                                   double* nodelta_f64, void* stream) {
+    return hals_entry<1>(ctx, UtM, ldm, UtU, ldg, V, ldv, r, ncols, nsweeps, 0.0, sparsity, flags, nullptr, nodelta_f64,
+                         (hipStream_t)stream);
+}

@@ -1,0 +1,95 @@
+// Shared by k_hals.hip (entry points, generic path) and k_hals_fast.hip (register-resident fast path).
+#pragma once
+#include "nnf_internal.h"
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define HALS_SPIN_LIMIT (1u << 22)
+
+struct hals_sync {
+    unsigned* counter;   // monotonic arrival counter (zeroed by the prep kernel)
+    double* slots;       // [2][nblocks][4] partials, parity-double-buffered
+};
+
+// Exchange up to 3 doubles between all workgroups; returns sums of v0, v1 and the max of v2 in out[0..2].
+// `epoch` counts barrier episodes from 1.  Returns false on timeout (wave-uniform after the barrier).
+template <int NV>
+__device__ __forceinline__ bool grid_exchange(const hals_sync& sy, unsigned epoch, int nblocks, const double (&mine)[NV],
+                                              double (&out)[NV], double* red, unsigned* lds_flag) {
+    double* slot = sy.slots + ((size_t)(epoch & 1) * nblocks + blockIdx.x) * 4;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + i), __builtin_bit_cast(unsigned long long, mine[i]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(sy.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = epoch * (unsigned)nblocks;
+        unsigned spins = 0, ok = 1;
+        while (__hip_atomic_load(sy.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > HALS_SPIN_LIMIT) { ok = 0; break; }
+        }
+        *lds_flag = ok;
+    }
+    __syncthreads();
+    const bool ok = (*lds_flag != 0);
+    // every workgroup sums every partial in the same order
+    double s[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s[i] = (i == 2) ? -1.0e300 : 0.0;
+    const double* base = sy.slots + (size_t)(epoch & 1) * nblocks * 4;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const double x = __builtin_bit_cast(
+                double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(base + (size_t)b * 4 + i),
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (i == 2) s[i] = x > s[i] ? x : s[i]; else s[i] += x;
+        }
+    }
+    // block reduce (fixed order) and broadcast through LDS
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double v = s[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double y = __shfl_down(v, o, 64);
+            if (i == 2) v = y > v ? y : v; else v += y;
+        }
+        if ((threadIdx.x & 63) == 0) red[w * NV + i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double v = red[i];
+        for (int k = 1; k < nw; ++k) {
+            const double y = red[k * NV + i];
+            if (i == 2) v = y > v ? y : v; else v += y;
+        }
+        out[i] = v;
+    }
+    __syncthreads();
+    return ok;
+}
+
+
+struct hals_args {
+    const float* UtM; int64_t ldm;
+    const float* Gp;      // padded Gram  RP x RP (zeros outside r x r), workspace
+    const float* dinv;    // 1/diag (0 where the diagonal is 0 or padded), workspace
+    float* V; int64_t ldv;
+    int r; int64_t ncols;
+    int max_sweeps; double delta; float sp;
+    int mode;             // 0: solve (stopping rule on device)  1: fixed sweep count, per-sweep local partials
+    hals_sync sy;
+    double* status;
+    double* sweep_partials;
+};
+
+int nnf_hals_fast_part0(nnf_ctx*, int RP, const hals_args&, int max_blocks_cap, int* nblocks_out, hipStream_t);
+int nnf_hals_fast_part1(nnf_ctx*, int RP, const hals_args&, int max_blocks_cap, int* nblocks_out, hipStream_t);
+int nnf_hals_fast_part2(nnf_ctx*, int RP, const hals_args&, int max_blocks_cap, int* nblocks_out, hipStream_t);
+int nnf_hals_fast_part3(nnf_ctx*, int RP, const hals_args&, int max_blocks_cap, int* nblocks_out, hipStream_t);

@@ -1,0 +1,541 @@
+// Streaming fp32-MFMA contractions over the data matrix X (gfx950 / CDNA4, wave64).
+//
+//   xty : out[r x n] = Ut[r x m] * X[m x n]          ("W^T X",  nmf.py:433)   split over m, slab reduce
+//   xht : out[r x m] = V [r x n] * X[m x n]^T        ("X H^T",  nmf.py:408)
+//   gram: G  [r x r] = A [r x K] * A^T               (nmf.py:407,432; ntf.py:442-445)
+//   frob: sum (X - Ut^T V)^2                         (nmf.py:452) product never materialised
+//
+// Common design
+//   * v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles/issue/SIMD; MI355X_MICROARCH "Matrix cores").  The 16-granular M tile
+//     keeps rank padding small (r=50 -> 64).  Operand lane maps (cdna_hip_programming.md s.3):
+//       A[row = l&15][k = l>>4],  B[k = l>>4][col = l&15],  D[row = 4*(l>>4)+reg][col = l&15].
+//   * X is read ONCE per kernel, straight from HBM into VGPRs with 16-byte buffer loads whose four components feed
+//     four different MFMAs, so no LDS round trip for the streamed operand: for xty/frob a wave instruction covers
+//     4 rows x 256 contiguous bytes; the column a lane holds in component c is 4*(l&15)+c, i.e. the four N tiles of a
+//     wave are column-interleaved (a pure relabelling, undone in the epilogue's float4 stores).
+//   * The small operand (Ut / V tile) is staged once per workgroup into LDS in *fragment order*
+//     ([tile][k-group][lane] float4) so every fragment read is one conflict-free linear ds_read_b128.
+//   * Hardware bounds checking of the buffer descriptor (num_records) zero-fills rows past the end of a workgroup's
+//     row range; ragged k tails are masked with selects (never 0*garbage).
+//   * Register double buffering: the loads of the next 64-deep chunk are issued right after the MFMAs that free the
+//     registers, so ~16 KB per wave stay in flight (hipcc's in-order vmcnt bookkeeping keeps them counted).
+#include "k_stream_common.h"
+
+// =========================================================================================================
+// xty: slab[ks][rk][j] = sum_{i in split ks} Ut[rk][i] * X[i][j]
+//   grid: 8*ceil(nsplit/8)*ncb workgroups of 256 threads; workgroup = (row split ks, 256-column block cb);
+//   wave w owns columns cb*256 + 64w .. +63 (lane: 4*(l&15)+c), all MT row tiles; k runs over the split's rows.
+// =========================================================================================================
+template <int MT, bool VEC>
+__global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_xty_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+                                                         const float* __restrict__ Ut, int64_t ldu, int r,
+                                                         float* __restrict__ slabs, int64_t ldp, int ncb, int nsplit,
+                                                         int64_t rows_per_split, int a_vec_ok) {
+    __shared__ f32x4 ldsA[2][MT * 256];
+    int ks, cb;
+    nnf_xcd_map(blockIdx.x, ncb, ks, cb);
+    if (ks >= nsplit) return;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jj = lane & 15, g = lane >> 4;
+    const int64_t i_begin = (int64_t)ks * rows_per_split;
+    const int64_t i_end = (i_begin + rows_per_split < m) ? (i_begin + rows_per_split) : m;
+    const int nchunk = (int)((i_end - i_begin + 63) >> 6);
+    const int64_t jl = (int64_t)cb * 256 + w * 64 + 4 * jj;  // lane's first column
+
+    const rsrc_t rs = nnf_make_rsrc(X + i_begin * ldx, (uint32_t)(((i_end - i_begin - 1) * ldx + n) * 4));
+    // lanes whose columns lie outside the matrix read nothing (offset beyond num_records -> 0)
+    const int voff = (jl < n) ? (int)(((int64_t)4 * g * ldx + jl) * 4) : (int)0x7ffffff0;
+    const int ldx4 = (int)(ldx * 4);
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) acc[mt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 xb[4][4];  // [k-group t][k-step c]: row i_begin + 64q + 16t + 4g + c, columns jl..jl+3
+    f32x4 areg[MT];
+
+    stageA_load<MT>(Ut, ldu, r, i_end, i_begin, a_vec_ok, areg);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, (16 * t + c) * ldx4);
+    stageA_store<MT>(ldsA[0], areg);
+    __syncthreads();
+
+    for (int q = 0; q < nchunk; ++q) {
+        const f32x4* img = ldsA[q & 1];
+        // next chunk's A tile: global loads now, LDS write after the MFMAs (rows past i_end come back as zeros)
+        stageA_load<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), a_vec_ok, areg);
+        const int soff_next = (q + 1) * 64 * ldx4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 af[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = img[(mt * 4 + t) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) acc[mt][cc] = MFMA16(af[mt][c], xb[t][c][cc], acc[mt][cc]);
+            // refill the registers just consumed with the same rows of the next chunk (past the end: zeros)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, soff_next + (16 * t + c) * ldx4);
+        }
+        stageA_store<MT>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
+        __syncthreads();
+    }
+
+    // epilogue: D[row = 4g+reg][col = jj] of tile (mt, cc) is out[16mt+4g+reg][jl+cc] -> one float4 per (mt, reg)
+    if (jl < ldp) {
+        float* sl = slabs + (int64_t)ks * r * ldp;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rk = 16 * mt + 4 * g + reg;
+                if (rk < r) {
+                    f32x4 o = {acc[mt][0][reg], acc[mt][1][reg], acc[mt][2][reg], acc[mt][3][reg]};
+                    *reinterpret_cast<f32x4*>(sl + (int64_t)rk * ldp + jl) = o;
+                }
+            }
+    }
+}
+
+// out[row][col] = sum_s slabs[s][row][col]  (fp64 accumulate, slab order fixed -> bitwise reproducible)
+__global__ __launch_bounds__(256) void nnf_reduce_slabs_kernel(const float* __restrict__ slabs, int nslab,
+                                                               int64_t slab_stride, int rows, int64_t cols, int64_t lds,
+                                                               float* __restrict__ out, int64_t ldo) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / cols, col = e - row * cols;
+        const float* p = slabs + row * lds + col;
+        double s = 0.0;
+        for (int k = 0; k < nslab; ++k) s += (double)p[(int64_t)k * slab_stride];
+        out[row * ldo + col] = (float)s;
+    }
+}
+
+int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, int rows, int64_t cols, int64_t lds,
+                            float* out, int64_t ldo, hipStream_t st) {
+    const int64_t total = (int64_t)rows * cols;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(nnf_reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, slabs, nslab, slab_stride, rows, cols, lds,
+                       out, ldo);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+
+template <int MT, bool VEC>
+static int launch_xty(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int r,
+                      int64_t ldu, float* out, int64_t ldo, hipStream_t st) {
+    const int ncb = (int)nnf_cdiv(n, 256);
+    const int64_t ldp = nnf_rup(n, 4);
+    int64_t target = 2 * (int64_t)ctx->num_cus / ncb;
+    if (target < 1) target = 1;
+    int64_t nsplit = target;
+    const int64_t max_split = nnf_cdiv(m, 64);
+    if (nsplit > max_split) nsplit = max_split;
+    // workspace bound
+    const int64_t slab_elems = (int64_t)r * ldp;
+    const int64_t ws_max = (int64_t)(ctx->ws_bytes / 4) / slab_elems;
+    if (ws_max < 1) return NNF_ERR_WORKSPACE;
+    if (nsplit > ws_max) nsplit = ws_max;
+    int64_t rows_per_split = nnf_rup(nnf_cdiv(m, nsplit), 64);
+    // 32-bit buffer offsets inside one split
+    while ((rows_per_split + 128) * ldx * 4 >= (int64_t)0x7fff0000) {
+        if (rows_per_split <= 64) return NNF_ERR_UNSUPPORTED;
+        rows_per_split = nnf_rup(rows_per_split / 2, 64);
+    }
+    nsplit = nnf_cdiv(m, rows_per_split);
+    if (nsplit > ws_max) return NNF_ERR_WORKSPACE;
+    nnf_ws_cursor cur(ctx);
+    float* slabs = (float*)cur.take((size_t)nsplit * slab_elems * 4);
+    if (!slabs) return NNF_ERR_WORKSPACE;
+    const int a_vec_ok = ((((uintptr_t)Ut) & 15) == 0 && (ldu & 3) == 0) ? 1 : 0;
+    const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * ncb;
+    hipLaunchKernelGGL((nnf_xty_kernel<MT, VEC>), dim3(grid), dim3(256), 0, st, X, m, n, ldx, Ut, ldu, r, slabs, ldp, ncb,
+                       (int)nsplit, rows_per_split, a_vec_ok);
+    NNF_CHECK_LAUNCH();
+    return nnf_launch_reduce_slabs(slabs, (int)nsplit, slab_elems, r, n, ldp, out, ldo, st);
+}
+
+// =========================================================================================================
+// xht: out[rk][i] = sum_j V[rk][j] * X[i][j]
+//   workgroup = 256 rows of X (wave w: rows 64w..64w+63 as four 16-row N tiles), k runs over the n columns.
+//   B operand lane (ii = l&15, g = l>>4) of tile nt, k-group t: float4 X[i0w+16nt+ii][64q+16t+4g .. +3].
+// =========================================================================================================
+template <int MT, bool VEC>
+__global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_xht_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+                                                         const float* __restrict__ V, int64_t ldv, int r,
+                                                         float* __restrict__ out, int64_t ldo, int a_vec_ok) {
+    __shared__ f32x4 ldsA[2][MT * 256];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ii = lane & 15, g = lane >> 4;
+    const int64_t i0w = (int64_t)blockIdx.x * 256 + 64 * w;
+    int64_t rows = m - i0w;
+    if (rows > 64) rows = 64;
+    const uint32_t bytes = rows > 0 ? (uint32_t)(((rows - 1) * ldx + n) * 4) : 0u;
+    const rsrc_t rs = nnf_make_rsrc(X + (rows > 0 ? i0w : 0) * ldx, bytes);
+    const int voff = (int)(((int64_t)ii * ldx + 4 * g) * 4);
+    const int ldx4 = (int)(ldx * 4);
+    const int nchunk = (int)((n + 63) >> 6);
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 xb[4][4];  // [k-group t][row tile nt]
+    f32x4 areg[MT];
+
+    stageA_load<MT>(V, ldv, r, n, 0, a_vec_ok, areg);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 64 * t);
+    stageA_store<MT>(ldsA[0], areg);
+    __syncthreads();
+
+    for (int q = 0; q < nchunk; ++q) {
+        const f32x4* img = ldsA[q & 1];
+        stageA_load<MT>(V, ldv, r, n, 64 * (int64_t)(q + 1), a_vec_ok, areg);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 af[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = img[(mt * 4 + t) * 64 + lane];
+            // ragged k tail: never multiply a staged zero by out-of-row data
+            const int64_t nrem = n - (64 * (int64_t)q + 16 * t + 4 * g);
+            if (nrem < 4) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c >= nrem) xb[t][nt][c] = 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(af[mt][c], xb[t][nt][c], acc[mt][nt]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * (q + 1) + 64 * t);
+        }
+        stageA_store<MT>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
+        __syncthreads();
+    }
+
+    // epilogue: tile (mt, nt): out[16mt + 4g + reg][i0w + 16nt + ii]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int64_t i = i0w + 16 * nt + ii;
+        if (i < m) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int rk = 16 * mt + 4 * g + reg;
+                    if (rk < r) out[(int64_t)rk * ldo + i] = acc[mt][nt][reg];
+                }
+        }
+    }
+}
+
+template <int MT, bool VEC>
+static int launch_xht(nnf_ctx*, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r, int64_t ldv,
+                      float* out, int64_t ldo, hipStream_t st) {
+    if (64 * ldx * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
+    const int a_vec_ok = ((((uintptr_t)V) & 15) == 0 && (ldv & 3) == 0) ? 1 : 0;
+    const int grid = (int)nnf_cdiv(m, 256);
+    hipLaunchKernelGGL((nnf_xht_kernel<MT, VEC>), dim3(grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
+                       a_vec_ok);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+
+// =========================================================================================================
+// gram: slab[ks] = A[:, split ks] * A[:, split ks]^T.  Both MFMA operands are the same LDS fragment image
+// (B[k][col] = A[col][k] is the A-fragment of tile `col/16`).  Wave w owns tile rows {w, w+4}.
+// =========================================================================================================
+template <int MT>
+__global__ __launch_bounds__(256) void nnf_gram_kernel(const float* __restrict__ A, int r, int64_t K, int64_t lda,
+                                                       float* __restrict__ slabs, int64_t k_per_split, int a_vec_ok) {
+    __shared__ f32x4 ldsA[2][MT * 256];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jj = lane & 15, g = lane >> 4;
+    const int64_t k_begin = (int64_t)blockIdx.x * k_per_split;
+    const int64_t k_end = (k_begin + k_per_split < K) ? (k_begin + k_per_split) : K;
+    const int nchunk = (int)((k_end - k_begin + 63) >> 6);
+    constexpr int NR = (MT + 3) / 4;  // tile rows per wave
+    f32x4 acc[NR][MT];
+#pragma unroll
+    for (int a = 0; a < NR; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 areg[MT];
+    stageA_load<MT>(A, lda, r, k_end, k_begin, a_vec_ok, areg);
+    stageA_store<MT>(ldsA[0], areg);
+    __syncthreads();
+    for (int q = 0; q < nchunk; ++q) {
+        const f32x4* img = ldsA[q & 1];
+        stageA_load<MT>(A, lda, r, k_end, k_begin + 64 * (int64_t)(q + 1), a_vec_ok, areg);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 bf[MT];
+#pragma unroll
+            for (int b = 0; b < MT; ++b) bf[b] = img[(b * 4 + t) * 64 + lane];
+#pragma unroll
+            for (int a = 0; a < NR; ++a) {
+                const int mt = w + 4 * a;
+                if (mt < MT) {
+                    const f32x4 af = img[(mt * 4 + t) * 64 + lane];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int b = 0; b < MT; ++b) acc[a][b] = MFMA16(af[c], bf[b][c], acc[a][b]);
+                }
+            }
+        }
+        stageA_store<MT>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
+        __syncthreads();
+    }
+    float* sl = slabs + (int64_t)blockIdx.x * r * r;
+#pragma unroll
+    for (int a = 0; a < NR; ++a) {
+        const int mt = w + 4 * a;
+        if (mt < MT) {
+#pragma unroll
+            for (int b = 0; b < MT; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = 16 * mt + 4 * g + reg, col = 16 * b + jj;
+                    if (row < r && col < r) sl[row * r + col] = acc[a][b][reg];
+                }
+        }
+    }
+}
+
+template <int MT>
+static int launch_gram(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
+                       hipStream_t st) {
+    int64_t nsplit = 2 * (int64_t)ctx->num_cus;
+    const int64_t max_split = nnf_cdiv(K, 64);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    const int64_t kps = nnf_rup(nnf_cdiv(K, nsplit), 64);
+    nsplit = nnf_cdiv(K, kps);
+    nnf_ws_cursor cur(ctx);
+    float* slabs = (float*)cur.take((size_t)nsplit * r * r * 4);
+    if (!slabs) return NNF_ERR_WORKSPACE;
+    const int a_vec_ok = ((((uintptr_t)A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL((nnf_gram_kernel<MT>), dim3((int)nsplit), dim3(256), 0, st, A, r, K, lda, slabs, kps, a_vec_ok);
+    NNF_CHECK_LAUNCH();
+    return nnf_launch_reduce_slabs(slabs, (int)nsplit, (int64_t)r * r, r, r, r, G, ldg, st);
+}
+
+// =========================================================================================================
+// frob: sum_ij (X[i][j] - sum_k Ut[k][i] V[k][j])^2
+//   workgroup = 128 rows (wave w: rows 32w..32w+31 as two 16-row M tiles), sweeping all columns in 64-wide blocks.
+//   P tile: A[i = l&15][k] = Ut[k][i] fragments (whole rank, staged once), B[k][col] = V[k][j0+4jj+c] fragments
+//   (restaged per column block, fragment order), D[row = 4g+reg][col = jj] of N tile cc <-> column j0+4jj+cc,
+//   which is exactly what a lane's float4 load of X[row][j0+4jj..+3] holds.
+//   The rank loop is a run-time loop (both operands come from LDS), so one kernel serves every r <= 128.
+// =========================================================================================================
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void nnf_frob_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+                                                          const float* __restrict__ Ut, int64_t ldu,
+                                                          const float* __restrict__ V, int64_t ldv, int r,
+                                                          double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KS = (r + 3) >> 2;                               // k-steps of 4
+    float* ldsU = reinterpret_cast<float*>(smem);              // [wave 4][rt 2][KS][64]
+    f32x4* ldsV = reinterpret_cast<f32x4*>(smem + (size_t)4 * 2 * KS * 64 * 4);  // [2][KS][64] float4
+    double* red = reinterpret_cast<double*>(smem + (size_t)4 * 2 * KS * 64 * 4 + (size_t)2 * KS * 64 * 16);
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jj = lane & 15, g = lane >> 4;
+    const int64_t i0w = (int64_t)blockIdx.x * 128 + 32 * w;
+    int64_t rows = m - i0w;
+    if (rows > 32) rows = 32;
+    const uint32_t bytes = rows > 0 ? (uint32_t)(((rows - 1) * ldx + n) * 4) : 0u;
+    const rsrc_t rs = nnf_make_rsrc(X + (rows > 0 ? i0w : 0) * ldx, bytes);
+    const int ldx4 = (int)(ldx * 4);
+    const int voff = (int)(((int64_t)4 * g * ldx + 4 * jj) * 4);
+    const int nblk = (int)((n + 63) >> 6);
+
+    // U fragments of this wave's 32 rows: ldsU[w][rt][s][lane] = Ut[4s + (lane>>4)][i0w + 16rt + (lane&15)]
+    for (int e = lane; e < 2 * KS * 64; e += 64) {
+        const int rt = e / (KS * 64), rem = e - rt * KS * 64, s = rem >> 6, L = rem & 63;
+        const int k = 4 * s + (L >> 4);
+        const int64_t i = i0w + 16 * rt + (L & 15);
+        ldsU[(w * 2 + rt) * KS * 64 + s * 64 + L] = (k < r && i < m) ? Ut[(int64_t)k * ldu + i] : 0.f;
+    }
+    // V fragments of one 64-column block: img[s][lane] = float4 V[4s + (lane>>4)][j0 + 4(lane&15) .. +3]
+    auto stageV = [&](int blk, f32x4* img) {
+        const int64_t j0 = 64 * (int64_t)blk;
+        for (int e = threadIdx.x; e < KS * 64; e += 256) {
+            const int s = e >> 6, L = e & 63;
+            const int k = 4 * s + (L >> 4);
+            const int64_t j = j0 + 4 * (L & 15);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < r && j < n) {
+                const float* p = V + (int64_t)k * ldv + j;
+                v[0] = p[0];
+                if (j + 1 < n) v[1] = p[1];
+                if (j + 2 < n) v[2] = p[2];
+                if (j + 3 < n) v[3] = p[3];
+            }
+            img[e] = v;
+        }
+    };
+    stageV(0, ldsV);
+    f32x4 xb[2][4];  // [rt][reg]: row i0w + 16rt + 4g + reg, columns j0+4jj..+3
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) xb[rt][reg] = nnf_bload4<VEC>(rs, voff, (16 * rt + reg) * ldx4);
+    __syncthreads();
+
+    double dsum = 0.0;
+    const float* uf = ldsU + (size_t)(w * 2) * KS * 64 + lane;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const f32x4* img = ldsV + (size_t)(blk & 1) * KS * 64;
+        if (blk + 1 < nblk) stageV(blk + 1, ldsV + (size_t)((blk + 1) & 1) * KS * 64);
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) acc[rt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 bv = img[s * 64 + lane];
+            const float a0 = uf[s * 64], a1 = uf[KS * 64 + s * 64];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                acc[0][cc] = MFMA16(a0, bv[cc], acc[0][cc]);
+                acc[1][cc] = MFMA16(a1, bv[cc], acc[1][cc]);
+            }
+        }
+        // residual of this 32 x 64 block; columns past n hold the next row's data -> masked out
+        const int64_t jrem = n - (64 * (int64_t)blk + 4 * jj);
+        float loc = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float d = (cc < jrem) ? (xb[rt][reg][cc] - acc[rt][cc][reg]) : 0.f;
+                    loc = fmaf(d, d, loc);
+                }
+        dsum += (double)loc;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                xb[rt][reg] = nnf_bload4<VEC>(rs, voff, (16 * rt + reg) * ldx4 + 256 * (blk + 1));
+        __syncthreads();
+    }
+    const double bs = nnf_block_sum_f64(dsum, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = bs;
+}
+
+// sum of `count` doubles in index order by one workgroup -> out[0]
+__global__ __launch_bounds__(256) void nnf_sum_partials_kernel(const double* __restrict__ partial, int64_t count,
+                                                               double* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t e = threadIdx.x; e < count; e += 256) s += partial[e];
+    const double t = nnf_block_sum_f64(s, red);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+
+#define DISPATCH_MT(FN, VEC, ...)                         \
+    switch (MT) {                                         \
+        case 1: return FN<1, VEC>(__VA_ARGS__);           \
+        case 2: return FN<2, VEC>(__VA_ARGS__);           \
+        case 3: return FN<3, VEC>(__VA_ARGS__);           \
+        case 4: return FN<4, VEC>(__VA_ARGS__);           \
+        case 5: return FN<5, VEC>(__VA_ARGS__);           \
+        case 6: return FN<6, VEC>(__VA_ARGS__);           \
+        case 7: return FN<7, VEC>(__VA_ARGS__);           \
+        default: return FN<8, VEC>(__VA_ARGS__);          \
+    }
+
+extern "C" int nnf_xty_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int r,
+                           int64_t ldu, float* out, int64_t ldo, void* stream) {
+    if (!ctx || !X || !Ut || !out || m < 1 || n < 1 || r < 1 || ldx < n || ldu < m || ldo < n) return NNF_ERR_ARG;
+    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int MT = (r + 15) / 16;
+    if (x_vec_ok(X, ldx)) {
+        DISPATCH_MT(launch_xty, true, ctx, X, m, n, ldx, Ut, r, ldu, out, ldo, st)
+    } else {
+        DISPATCH_MT(launch_xty, false, ctx, X, m, n, ldx, Ut, r, ldu, out, ldo, st)
+    }
+}
+
+extern "C" int nnf_xht_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r,
+                           int64_t ldv, float* out, int64_t ldo, void* stream) {
+    if (!ctx || !X || !V || !out || m < 1 || n < 1 || r < 1 || ldx < n || ldv < n || ldo < m) return NNF_ERR_ARG;
+    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int MT = (r + 15) / 16;
+    if (x_vec_ok(X, ldx)) {
+        DISPATCH_MT(launch_xht, true, ctx, X, m, n, ldx, V, r, ldv, out, ldo, st)
+    } else {
+        DISPATCH_MT(launch_xht, false, ctx, X, m, n, ldx, V, r, ldv, out, ldo, st)
+    }
+}
+
+extern "C" int nnf_gram_f32(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
+                            void* stream) {
+    if (!ctx || !A || !G || r < 1 || K < 1 || lda < K || ldg < r) return NNF_ERR_ARG;
+    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    switch ((r + 15) / 16) {
+        case 1: return launch_gram<1>(ctx, A, r, K, lda, G, ldg, st);
+        case 2: return launch_gram<2>(ctx, A, r, K, lda, G, ldg, st);
+        case 3: return launch_gram<3>(ctx, A, r, K, lda, G, ldg, st);
+        case 4: return launch_gram<4>(ctx, A, r, K, lda, G, ldg, st);
+        case 5: return launch_gram<5>(ctx, A, r, K, lda, G, ldg, st);
+        case 6: return launch_gram<6>(ctx, A, r, K, lda, G, ldg, st);
+        case 7: return launch_gram<7>(ctx, A, r, K, lda, G, ldg, st);
+        default: return launch_gram<8>(ctx, A, r, K, lda, G, ldg, st);
+    }
+}
+
+extern "C" int nnf_frob_resid_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
+                                  int64_t ldu, const float* V, int64_t ldv, int r, double* out_f64, void* stream) {
+    if (!ctx || !X || !Ut || !V || !out_f64 || m < 1 || n < 1 || r < 1 || ldx < n || ldu < m || ldv < n)
+        return NNF_ERR_ARG;
+    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    if (32 * ldx * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)nnf_cdiv(m, 128);
+    nnf_ws_cursor cur(ctx);
+    double* partial = (double*)cur.take((size_t)grid * 8);
+    if (!partial) return NNF_ERR_WORKSPACE;
+    const int KS = (r + 3) / 4;
+    const size_t shm = (size_t)4 * 2 * KS * 64 * 4 + (size_t)2 * KS * 64 * 16 + 64;
+    if (shm > 48 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_frob_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_frob_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    }
+    if (x_vec_ok(X, ldx))
+        hipLaunchKernelGGL((nnf_frob_kernel<true>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
+                           partial);
+    else
+        hipLaunchKernelGGL((nnf_frob_kernel<false>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
+                           partial);
+    NNF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nnf_sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)grid, out_f64);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}

@@ -1,0 +1,63 @@
+// Device helpers shared by the streaming MFMA kernels (k_stream.hip, k_mu.hip, k_mttkrp.hip).
+#pragma once
+#include "nnf_internal.h"
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t nnf_make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 nnf_bload4(rsrc_t rs, int voff, int soff) {
+    if constexpr (VEC) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    } else {  // rows not 16-byte aligned: four dword loads (small / odd shapes only)
+        f32x4 v;
+        v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+        v[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4, soff, 0));
+        v[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 8, soff, 0));
+        v[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 12, soff, 0));
+        return v;
+    }
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ---------------------------------------------------------------------------------------------------------
+// A-operand staging.  LDS image of one 64-deep chunk of a row-major r x K matrix A:
+//   img[(mt*4 + t)*64 + lane].c = A[16*mt + (lane&15)][k0 + 16*t + 4*(lane>>4) + c]      (zero outside r x K)
+// 256 threads: thread -> (t = tid>>6, lane = tid&63), MT float4 each.
+// ---------------------------------------------------------------------------------------------------------
+template <int MT>
+__device__ __forceinline__ void stageA_load(const float* __restrict__ A, int64_t lda, int r, int64_t K, int64_t k0,
+                                            bool vec_ok, f32x4 (&regs)[MT]) {
+    const int t = threadIdx.x >> 6, L = threadIdx.x & 63;
+    const int64_t kk = k0 + 16 * t + 4 * (L >> 4);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = 16 * mt + (L & 15);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < r && kk < K) {
+            const float* p = A + (int64_t)row * lda + kk;
+            if (vec_ok && kk + 3 < K) {
+                v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+                v[0] = p[0];
+                if (kk + 1 < K) v[1] = p[1];
+                if (kk + 2 < K) v[2] = p[2];
+                if (kk + 3 < K) v[3] = p[3];
+            }
+        }
+        regs[mt] = v;
+    }
+}
+template <int MT>
+__device__ __forceinline__ void stageA_store(f32x4* __restrict__ img, const f32x4 (&regs)[MT]) {
+    const int t = threadIdx.x >> 6, L = threadIdx.x & 63;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) img[(mt * 4 + t) * 64 + L] = regs[mt];
+}
+
+
+static inline bool x_vec_ok(const float* X, int64_t ldx) { return (((uintptr_t)X) & 15) == 0 && (ldx & 3) == 0; }

@@ -1,0 +1,105 @@
+// Context management and small deterministic helpers of libnnfac_hip.so.
+#include "nnf_internal.h"
+#include <new>
+
+extern "C" int nnf_version(void) { return 100; }  // 0.1.0
+
+extern "C" const char* nnf_status_string(int status) {
+    switch (status) {
+        case NNF_OK: return "ok";
+        case NNF_ERR_ARG: return "invalid argument";
+        case NNF_ERR_LAUNCH: return "HIP launch/runtime error";
+        case NNF_ERR_UNSUPPORTED: return "shape not supported by the built kernels";
+        case NNF_ERR_WORKSPACE: return "context workspace too small";
+        case NNF_ERR_DEVICE: return "device unavailable";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_bytes) {
+    if (!out_ctx) return NNF_ERR_ARG;
+    *out_ctx = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return NNF_ERR_DEVICE;
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess) return NNF_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return NNF_ERR_DEVICE;
+    nnf_ctx* c = new (std::nothrow) nnf_ctx();
+    if (!c) return NNF_ERR_DEVICE;
+    c->device = device;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    c->num_cus = cus;
+    c->ws_bytes = workspace_bytes ? workspace_bytes : (size_t)256 << 20;
+    c->ws = nullptr;
+    hipError_t e = hipMalloc((void**)&c->ws, c->ws_bytes);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) {
+        delete c;
+        return NNF_ERR_WORKSPACE;
+    }
+    *out_ctx = c;
+    return NNF_OK;
+}
+
+extern "C" int nnf_ctx_destroy(nnf_ctx* ctx) {
+    if (!ctx) return NNF_ERR_ARG;
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    delete ctx;
+    return NNF_OK;
+}
+
+extern "C" size_t nnf_ctx_workspace_bytes(const nnf_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
+
+// ---- dot: sum_ij A[i,j]*B[i,j] in fp64, fixed order ------------------------------------------------------
+__global__ __launch_bounds__(256) void nnf_dot_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                      int64_t ldb, int64_t rows, int64_t cols, double* __restrict__ partial) {
+    __shared__ double red[4];
+    const int64_t total = rows * cols;
+    double s = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e / cols, j = e - i * cols;
+        s += (double)A[i * lda + j] * (double)B[i * ldb + j];
+    }
+    const double t = nnf_block_sum_f64(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void nnf_sum_f64_kernel(const double* __restrict__ partial, int64_t count,
+                                                          double* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t e = threadIdx.x; e < count; e += 256) s += partial[e];
+    const double t = nnf_block_sum_f64(s, red);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+extern "C" int nnf_dot_f32(nnf_ctx* ctx, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows,
+                           int64_t cols, double* out_f64, void* stream) {
+    if (!ctx || !A || !B || !out_f64 || rows < 1 || cols < 1 || lda < cols || ldb < cols) return NNF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t grid = nnf_cdiv(rows * cols, 256 * 8);
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    nnf_ws_cursor cur(ctx);
+    double* partial = (double*)cur.take((size_t)grid * 8);
+    if (!partial) return NNF_ERR_WORKSPACE;
+    hipLaunchKernelGGL(nnf_dot_kernel, dim3((int)grid), dim3(256), 0, st, A, lda, B, ldb, rows, cols, partial);
+    NNF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nnf_sum_f64_kernel, dim3(1), dim3(256), 0, st, partial, grid, out_f64);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+
+__global__ void nnf_hadamard_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                    int64_t count) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x)
+        C[e] = A[e] * B[e];
+}
+extern "C" int nnf_hadamard_f32(nnf_ctx* ctx, const float* A, const float* B, float* C, int64_t count, void* stream) {
+    if (!ctx || !A || !B || !C || count < 1) return NNF_ERR_ARG;
+    int64_t grid = nnf_cdiv(count, 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(nnf_hadamard_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, A, B, C, count);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}

@@ -1,0 +1,209 @@
+"""Thin tensor-level wrapper over the C ABI: torch tensors in, raw device pointers out.
+
+PyTorch is plumbing here (device memory, streams); every arithmetic statement of the hot path runs in
+libnnfac_hip.so.  Factors are kept "transposed" on the device (Ut: r x m, V: r x n), the layout hals_nnls_acc works on.
+"""
+import ctypes as C
+import threading
+
+import torch
+
+from . import _lib
+from .utils.errors import EngineError
+
+HALS_SPARSITY, HALS_NORMALIZE, HALS_NONZERO = 1, 2, 4
+ST_EPS, ST_CNT, ST_EPS0, ST_ERR, ST_WORDS = 0, 1, 2, 3, 8
+
+_engines = {}
+_lock = threading.Lock()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk2d(t, name):
+    if t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
+        raise EngineError(f"{name}: expected a 2-D float32 device tensor with unit inner stride, got "
+                          f"{tuple(t.shape)} {t.dtype} {t.device} strides {t.stride()}")
+    return t
+
+
+class Engine:
+    """One context (workspace + device properties) per device."""
+
+    def __init__(self, device, workspace_bytes=0):
+        if not torch.cuda.is_available():
+            raise EngineError("no ROCm device available: the nn_fac_amd engine is GPU-only (no CPU fallback)")
+        self.device = torch.device(device)
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.nnf_ctx_create(C.byref(h), self.device.index or 0, workspace_bytes), "nnf_ctx_create")
+        self.ctx = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.nnf_ctx_destroy(self.ctx)
+        except Exception:  # interpreter shutdown
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- contractions -------------------------------------------------------------------------------
+    def gram(self, A, out=None):
+        """A (r x K) -> A A^T (r x r)."""
+        _chk2d(A, "gram A")
+        r, K = A.shape
+        G = out if out is not None else torch.empty((r, r), dtype=torch.float32, device=A.device)
+        _lib.check(self.lib.nnf_gram_f32(self.ctx, _ptr(A), r, K, A.stride(0), _ptr(G), G.stride(0), self._stream()),
+                   "nnf_gram_f32")
+        return G
+
+    def xht(self, X, V, out=None):
+        """V (r x n), X (m x n) -> V X^T (r x m)."""
+        _chk2d(X, "xht X"), _chk2d(V, "xht V")
+        m, n = X.shape
+        r = V.shape[0]
+        if V.shape[1] != n:
+            raise EngineError("xht: shape mismatch")
+        O = out if out is not None else torch.empty((r, m), dtype=torch.float32, device=X.device)
+        _lib.check(self.lib.nnf_xht_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(V), r, V.stride(0), _ptr(O),
+                                        O.stride(0), self._stream()), "nnf_xht_f32")
+        return O
+
+    def xty(self, X, Ut, out=None):
+        """Ut (r x m), X (m x n) -> Ut X (r x n)."""
+        _chk2d(X, "xty X"), _chk2d(Ut, "xty Ut")
+        m, n = X.shape
+        r = Ut.shape[0]
+        if Ut.shape[1] != m:
+            raise EngineError("xty: shape mismatch")
+        O = out if out is not None else torch.empty((r, n), dtype=torch.float32, device=X.device)
+        _lib.check(self.lib.nnf_xty_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), r, Ut.stride(0), _ptr(O),
+                                        O.stride(0), self._stream()), "nnf_xty_f32")
+        return O
+
+    def frob_resid(self, X, Ut, V, out=None):
+        """sum (X - Ut^T V)^2 as a 1-element float64 device tensor."""
+        _chk2d(X, "frob X"), _chk2d(Ut, "frob Ut"), _chk2d(V, "frob V")
+        m, n = X.shape
+        r = Ut.shape[0]
+        if Ut.shape[1] != m or V.shape != (r, n):
+            raise EngineError("frob_resid: shape mismatch")
+        o = out if out is not None else torch.empty(1, dtype=torch.float64, device=X.device)
+        _lib.check(self.lib.nnf_frob_resid_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
+                                               V.stride(0), r, _ptr(o), self._stream()), "nnf_frob_resid_f32")
+        return o
+
+    def dot(self, A, B):
+        _chk2d(A, "dot A"), _chk2d(B, "dot B")
+        o = torch.empty(1, dtype=torch.float64, device=A.device)
+        _lib.check(self.lib.nnf_dot_f32(self.ctx, _ptr(A), A.stride(0), _ptr(B), B.stride(0), A.shape[0], A.shape[1],
+                                        _ptr(o), self._stream()), "nnf_dot_f32")
+        return o
+
+    def hadamard(self, A, B, out=None):
+        A, B = A.contiguous(), B.contiguous()
+        Cc = out if out is not None else torch.empty_like(A)
+        _lib.check(self.lib.nnf_hadamard_f32(self.ctx, _ptr(A), _ptr(B), _ptr(Cc), A.numel(), self._stream()),
+                   "nnf_hadamard_f32")
+        return Cc
+
+    # ---- HALS ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _hals_flags(sparsity, normalize, nonzero):
+        f = 0
+        if sparsity is not None:
+            f |= HALS_SPARSITY
+        if normalize:
+            f |= HALS_NORMALIZE
+        if nonzero:
+            f |= HALS_NONZERO
+        return f
+
+    def hals_solve(self, UtM, UtU, V, max_sweeps, delta=0.01, sparsity=None, normalize=False, nonzero=False,
+                   status=None):
+        """In-place accelerated HALS on V (r x ncols); returns the 8-double status tensor (device, not synced)."""
+        _chk2d(UtM, "hals UtM"), _chk2d(UtU, "hals UtU"), _chk2d(V, "hals V")
+        r, ncols = V.shape
+        if UtM.shape != (r, ncols) or UtU.shape[0] < r or UtU.shape[1] < r:
+            raise EngineError("hals_solve: shape mismatch")
+        st = status if status is not None else torch.empty(ST_WORDS, dtype=torch.float64, device=V.device)
+        _lib.check(self.lib.nnf_hals_solve_f32(self.ctx, _ptr(UtM), UtM.stride(0), _ptr(UtU), UtU.stride(0), _ptr(V),
+                                               V.stride(0), r, ncols, int(max_sweeps), float(delta),
+                                               float(sparsity or 0.0),
+                                               self._hals_flags(sparsity, normalize, nonzero), _ptr(st),
+                                               self._stream()), "nnf_hals_solve_f32")
+        return st
+
+    def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False):
+        """Exactly `nsweeps` in-place sweeps; returns the per-sweep LOCAL sum of squared steps (float64, device)."""
+        _chk2d(UtM, "hals UtM"), _chk2d(UtU, "hals UtU"), _chk2d(V, "hals V")
+        r, ncols = V.shape
+        nd = torch.zeros(max(int(nsweeps), 1), dtype=torch.float64, device=V.device)
+        _lib.check(self.lib.nnf_hals_sweeps_f32(self.ctx, _ptr(UtM), UtM.stride(0), _ptr(UtU), UtU.stride(0), _ptr(V),
+                                                V.stride(0), r, ncols, int(nsweeps), float(sparsity or 0.0),
+                                                self._hals_flags(sparsity, normalize, nonzero), _ptr(nd),
+                                                self._stream()), "nnf_hals_sweeps_f32")
+        return nd[:int(nsweeps)]
+
+    # ---- MU / beta-divergence -----------------------------------------------------------------------
+    def mu_left(self, X, Ut, V, beta, out=None):
+        _chk2d(X, "mu X"), _chk2d(Ut, "mu Ut"), _chk2d(V, "mu V")
+        m, n = X.shape
+        r = Ut.shape[0]
+        O = out if out is not None else torch.empty_like(Ut)
+        _lib.check(self.lib.nnf_mu_left_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
+                                            V.stride(0), r, float(beta), _ptr(O), O.stride(0), self._stream()),
+                   "nnf_mu_left_f32")
+        return O
+
+    def mu_right(self, X, Ut, V, beta, out=None):
+        _chk2d(X, "mu X"), _chk2d(Ut, "mu Ut"), _chk2d(V, "mu V")
+        m, n = X.shape
+        r = Ut.shape[0]
+        O = out if out is not None else torch.empty_like(V)
+        _lib.check(self.lib.nnf_mu_right_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
+                                             V.stride(0), r, float(beta), _ptr(O), O.stride(0), self._stream()),
+                   "nnf_mu_right_f32")
+        return O
+
+    def betadiv(self, X, Ut, V, beta, out=None):
+        _chk2d(X, "betadiv X"), _chk2d(Ut, "betadiv Ut"), _chk2d(V, "betadiv V")
+        m, n = X.shape
+        r = Ut.shape[0]
+        o = out if out is not None else torch.empty(1, dtype=torch.float64, device=X.device)
+        _lib.check(self.lib.nnf_betadiv_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
+                                            V.stride(0), r, float(beta), _ptr(o), self._stream()), "nnf_betadiv_f32")
+        return o
+
+    def mttkrp3(self, T, Ft, mode, out=None):
+        """T (I x J x K, contiguous), Ft = [F0^T, F1^T, F2^T] (each R x dim) -> R x dim_mode."""
+        if T.dim() != 3 or T.dtype != torch.float32 or not T.is_contiguous():
+            raise EngineError("mttkrp3: T must be a contiguous 3-way float32 tensor")
+        for f in Ft:
+            _chk2d(f, "mttkrp factor")
+        I, J, K = T.shape
+        R = Ft[0].shape[0]
+        O = out if out is not None else torch.empty((R, T.shape[mode]), dtype=torch.float32, device=T.device)
+        _lib.check(self.lib.nnf_mttkrp3_f32(self.ctx, _ptr(T), I, J, K, _ptr(Ft[0]), Ft[0].stride(0), _ptr(Ft[1]),
+                                            Ft[1].stride(0), _ptr(Ft[2]), Ft[2].stride(0), R, int(mode), _ptr(O),
+                                            O.stride(0), self._stream()), "nnf_mttkrp3_f32")
+        return O
+
+
+def get_engine(device=None):
+    """Process-wide engine for `device` (default: current device)."""
+    if not torch.cuda.is_available():
+        raise EngineError("no ROCm device available: the nn_fac_amd engine is GPU-only (no CPU fallback)")
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    if dev.index is None:
+        dev = torch.device(f"cuda:{torch.cuda.current_device()}")
+    with _lock:
+        e = _engines.get(dev.index)
+        if e is None:
+            e = Engine(dev)
+            _engines[dev.index] = e
+        return e

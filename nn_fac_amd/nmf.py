@@ -1,0 +1,231 @@
+"""NMF driver on the MI355X engine -- drop-in for nn_fac/nmf.py (nmf :19-193, compute_nmf :196-329, one_nmf_step :332-458).
+
+The outer alternating loop, its stopping test and the call signatures are the reference's; what changes is where the
+arithmetic runs: data and factors live on the device for the whole run (factors transposed: Ut r x m, V r x n) and
+each statement of one_nmf_step maps to one call of libnnfac_hip.so:
+
+    VVt = V V^T, VMt = V X^T      (nmf.py:407-408)  -> nnf_gram_f32, nnf_xht_f32
+    hals_nnls_acc(VMt, VVt, U^T)  (nmf.py:415/418)  -> nnf_hals_solve_f32   (one persistent launch)
+    UtU = U^T U, UtM = U^T X      (nmf.py:432-433)  -> nnf_gram_f32, nnf_xty_f32
+    hals_nnls_acc(UtM, UtU, V)    (nmf.py:440/443)  -> nnf_hals_solve_f32
+    ||X - U V||_F^2               (nmf.py:452)      -> nnf_frob_resid_f32   (product never materialised)
+    mu / beta-divergence          (nmf.py:422,447,455) -> nnf_mu_left_f32, nnf_mu_right_f32, nnf_betadiv_f32
+
+Inputs may be NumPy arrays or torch tensors; results come back in kind.  Arithmetic is fp32 on the device
+(fp64 for every long reduction), whatever the input dtype.  Row-sharded multi-GPU runs go through
+``nn_fac_amd.dist`` (same step, RCCL all-reduce of the Gram / cross terms).
+"""
+import math
+import time
+import warnings
+
+import numpy as np
+import torch
+
+from .utils import errors as err
+from .utils import initialize_factors as init_factors
+from . import engine as _engine
+from ._convert import device_of, to_dev, to_dev_t, like_input
+
+
+def nmf(data, rank, init="random", U_0=None, V_0=None, n_iter_max=100, tol=1e-8,
+        update_rule="hals", beta=2,
+        sparsity_coefficients=[None, None], fixed_modes=[], normalize=[False, False],
+        verbose=False, return_costs=False, deterministic=False, seed=0):
+    """Nonnegative matrix factorisation  data ~= U V  (reference docstring: nmf.py:23-174)."""
+    if min(data.shape) < rank:
+        min_data = min(data.shape)
+        rank = min_data
+        warnings.warn(f"The rank is too high for the input matrix. It was set to {min_data} instead.")
+
+    if deterministic:
+        np.random.seed(seed)
+
+    if init.lower() == "custom":
+        if U_0 is None or V_0 is None:
+            raise err.CustomNotValidFactors("Custom initialization, but (at least) one factor is set to 'None'")
+    else:
+        U_0, V_0 = init_factors.nmf_initialization(data, rank, init, deterministic=deterministic, seed=seed)
+
+    return compute_nmf(data, rank, U_0, V_0, n_iter_max=n_iter_max, tol=tol,
+                       update_rule=update_rule, beta=beta,
+                       sparsity_coefficients=sparsity_coefficients, fixed_modes=fixed_modes, normalize=normalize,
+                       verbose=verbose, return_costs=return_costs, deterministic=deterministic)
+
+
+def compute_nmf(data, rank, U_in, V_in, n_iter_max=100, tol=1e-8,
+                update_rule="hals", beta=2,
+                sparsity_coefficients=[None, None], fixed_modes=[], normalize=[False, False],
+                verbose=False, return_costs=False, deterministic=False, sweep_log=None):
+    """Outer loop of nmf.py:284-329.  ``sweep_log`` (extension): list receiving the inner sweep counts."""
+    dev = device_of(data, U_in, V_in)
+    eng = _engine.get_engine(dev)
+    X = to_dev(data, dev)
+    Ut = to_dev_t(U_in, dev).clone()
+    V = to_dev(V_in, dev).clone()
+    cost_fct_vals = []
+    tic = time.time()
+    toc = []
+
+    if sparsity_coefficients is None:
+        sparsity_coefficients = [None, None]
+    if fixed_modes is None:
+        fixed_modes = []
+    if normalize is None or normalize is False:
+        normalize = [False, False]
+
+    ws = _StepBuffers(X, Ut.shape[0])
+    for iteration in range(n_iter_max):
+        Ut, V, nstat = _one_nmf_step_dev(eng, ws, X, rank, Ut, V, update_rule, beta, sparsity_coefficients,
+                                         fixed_modes, normalize, deterministic)
+        host = ws.block.cpu()   # the only host synchronisation of the iteration: cost + HALS status words
+        cost = float(host[16])
+        _raise_on_status(host, nstat)
+        if sweep_log is not None:
+            sweep_log.extend(int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(nstat))
+        toc.append(time.time() - tic)
+        cost_fct_vals.append(cost)
+
+        if verbose:
+            if iteration == 0:
+                print('Normalized cost function value={}'.format(cost))
+            else:
+                if cost_fct_vals[-2] - cost_fct_vals[-1] > 0:
+                    print('Normalized cost function value={}, variation={}.'.format(
+                        cost_fct_vals[-1], cost_fct_vals[-2] - cost_fct_vals[-1]))
+                else:
+                    print('\033[91m' + 'Normalized cost function value={}, variation={}.'.format(
+                        cost_fct_vals[-1], cost_fct_vals[-2] - cost_fct_vals[-1]) + '\033[0m')
+
+        if iteration > 0 and abs(cost_fct_vals[-2] - cost_fct_vals[-1]) < tol:
+            if verbose:
+                print('Converged in {} iterations.'.format(iteration))
+            break
+
+    U_out, V_out = like_input(Ut.t(), U_in), like_input(V, V_in)
+    if return_costs:
+        return U_out, V_out, cost_fct_vals, toc
+    return U_out, V_out
+
+
+def one_nmf_step(data, rank, U_in, V_in, norm_data, update_rule, beta,
+                 sparsity_coefficients, fixed_modes, normalize, deterministic):
+    """One pass of updates on U then V, then the cost (nmf.py:387-458).  Returns (U, V, cost)."""
+    dev = device_of(data, U_in, V_in)
+    eng = _engine.get_engine(dev)
+    X = to_dev(data, dev)
+    Ut, V = to_dev_t(U_in, dev), to_dev(V_in, dev)
+    ws = _StepBuffers(X, Ut.shape[0])
+    Ut2, V2, nstat = _one_nmf_step_dev(eng, ws, X, rank, Ut, V, update_rule, beta, sparsity_coefficients,
+                                       fixed_modes, normalize, deterministic)
+    host = ws.block.cpu()
+    cost = float(host[16])
+    _raise_on_status(host, nstat)
+    return like_input(Ut2.t(), U_in), like_input(V2, V_in), cost
+
+
+# ------------------------------------------------------------------------------------------------------------
+class _StepBuffers:
+    """Device scratch reused across iterations (cross terms, Grams, status words)."""
+
+    def __init__(self, X, r):
+        m, n = X.shape
+        f32 = dict(dtype=torch.float32, device=X.device)
+        self.VMt = torch.empty((r, m), **f32)
+        self.UtM = torch.empty((r, n), **f32)
+        self.G = torch.empty((r, r), **f32)
+        self.G2 = torch.empty((r, r), **f32)
+        # one block read back per iteration: HALS status of the first / second solve at [0:8] / [8:16], cost at [16]
+        self.block = torch.zeros(24, dtype=torch.float64, device=X.device)
+        self.cost = self.block[16:17]
+
+
+def _raise_on_status(host, nstat):
+    for i in range(nstat):
+        code = int(host[8 * i + _engine.ST_ERR])
+        if code == 2:
+            raise err.ZeroColumnWhenUnautorized("A column of U is zero with nonzero condition")
+        if code != 0:
+            raise err.EngineError("hals grid barrier timed out; result invalid")
+
+
+def _hals_call(eng, cross, gram, F, sparsity, normalize, deterministic, timer, status):
+    """hals_nnls_acc(..., maxiter=100, atime=timer, alpha=inf|0.5, delta=0.01) of nmf.py:415-419,440-444, in place."""
+    from .update_rules.nnls import sweep_budget
+    budget = 100
+    if not deterministic:
+        # wall-clock rule: rho = atime / btime with btime = time of one sweep (nnls.py:190-194)
+        probe = F.clone()
+        torch.cuda.synchronize(F.device)
+        t0 = time.time()
+        eng.hals_sweeps(cross, gram, probe, 1, sparsity=sparsity, normalize=normalize)
+        torch.cuda.synchronize(F.device)
+        btime = max(time.time() - t0, 10e-7)
+        rho = timer / btime if timer else 100000
+        budget = max(1, sweep_budget(100, 0.5, rho))
+    return eng.hals_solve(cross, gram, F, budget, delta=0.01, sparsity=sparsity, normalize=normalize, nonzero=False,
+                          status=status)
+
+
+def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
+                      deterministic):
+    """Device-resident step.  Ut_in (r x m) and V_in (r x n) are not modified.  Returns the new factors and the number
+    of HALS solves run; the cost and the solves' status words are left in ws.block (read back by the caller)."""
+    if update_rule not in ["hals", "mu"]:
+        raise err.InvalidArgumentValue(f"Invalid update rule: {update_rule}") from None
+    if update_rule == "hals" and beta != 2:
+        raise err.InvalidArgumentValue(f"The hals is only valid for the frobenius norm, corresponding to the beta divergence with beta = 2. Here, beta was set to {beta}. To compute NMF with this value of beta, please use the mu update_rule.") from None
+    if len(sparsity_coefficients) != 2:
+        raise ValueError("NMF needs 2 sparsity coefficients to be performed")
+
+    Ut, V = Ut_in, V_in
+    nstat = 0
+    dev = X.device
+
+    if 0 not in fixed_modes:
+        if update_rule == "hals":
+            timer = None
+            if not deterministic:
+                torch.cuda.synchronize(dev)
+                t0 = time.time()
+            eng.gram(V, out=ws.G)                       # VVt  (nmf.py:407)
+            eng.xht(X, V, out=ws.VMt)                   # VMt  (nmf.py:408)
+            if not deterministic:
+                torch.cuda.synchronize(dev)
+                timer = time.time() - t0
+            Ut = Ut_in.clone()                          # solve starts from U_in^T (nmf.py:415)
+            _hals_call(eng, ws.VMt, ws.G, Ut, sparsity_coefficients[0], normalize[0], deterministic, timer,
+                       ws.block[8 * nstat:8 * nstat + 8])
+            nstat += 1
+        else:
+            Ut = eng.mu_left(X, Ut_in, V, beta)         # nmf.py:422
+
+    if 1 not in fixed_modes:
+        if update_rule == "hals":
+            timer = None
+            if not deterministic:
+                torch.cuda.synchronize(dev)
+                t0 = time.time()
+            eng.gram(Ut, out=ws.G2)                     # UtU  (nmf.py:432)
+            eng.xty(X, Ut, out=ws.UtM)                  # UtM  (nmf.py:433)
+            if not deterministic:
+                torch.cuda.synchronize(dev)
+                timer = time.time() - t0
+            V = V_in.clone()                            # solve starts from V_in (nmf.py:440)
+            _hals_call(eng, ws.UtM, ws.G2, V, sparsity_coefficients[1], normalize[1], deterministic, timer,
+                       ws.block[8 * nstat:8 * nstat + 8])
+            nstat += 1
+        else:
+            V = eng.mu_right(X, Ut, V_in, beta)         # nmf.py:447
+
+    sp = [0 if s is None else s for s in sparsity_coefficients]
+    if update_rule == "hals":
+        eng.frob_resid(X, Ut, V, out=ws.cost)                     # nmf.py:452
+        if sp[0] or sp[1]:
+            # matrix 1-norm (max column abs-sum, np.linalg.norm(., ord=1)) -- NOT the entry-wise l1 (nmf.py:452)
+            nU = Ut.abs().sum(dim=1).max().double()   # columns of U are rows of Ut
+            nV = V.abs().sum(dim=0).max().double()
+            ws.cost.add_(2 * (sp[0] * nU + sp[1] * nV))
+    else:
+        eng.betadiv(X, Ut, V, beta, out=ws.cost)                  # nmf.py:455
+    return Ut, V, nstat

@@ -1,0 +1,127 @@
+"""The CPU oracle against the fixtures produced by the real reference (oracle/gen_golden.py).  No GPU needed."""
+import math
+
+import numpy as np
+import pytest
+
+import nnfac_oracle as orc
+
+
+def _kw(vec):
+    kw = dict(maxiter=int(vec[0]), delta=float(vec[1]), alpha=math.inf)
+    if vec[2] >= 0:
+        kw["sparsity_coefficient"] = float(vec[2])
+    kw["normalize"], kw["nonzero"] = bool(vec[3]), bool(vec[4])
+    return kw
+
+
+def test_g0_reference_known_answers(golden):
+    g = golden("g0_known_answers.npz")
+    data, rank = g["data"], int(g["rank"])
+    assert abs(data[0][0] - 2.143518599859098) < 1e-7            # reference tests/NMF_tests.py:68
+    for rule, beta, seed in (("hals", 2, 0), ("mu", 2, 82), ("mu", 1, 82), ("mu", 0, 82)):
+        tag = f"{rule}_b{beta}_s{seed}"
+        U, V, costs, _ = orc.nmf(data, rank, init="random", n_iter_max=10, tol=1e-8, update_rule=rule, beta=beta,
+                                 return_costs=True, deterministic=True, seed=seed)
+        u00, v00, c0, c1 = g[f"known_{tag}"]                    # literals of tests/NMF_tests.py:76-81,...,130-135
+        assert abs(U[0][0] - u00) < 1e-7 and abs(V[0][0] - v00) < 1e-7
+        assert abs(costs[0] - c0) < 1e-7 and abs(costs[-1] - c1) < 1e-7
+        np.testing.assert_allclose(U, g[f"U_{tag}"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(V, g[f"V_{tag}"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(costs, g[f"costs_{tag}"], rtol=1e-12)
+
+
+def test_g0_random_init_stream():
+    U, V = orc.nmf_random_init((73, 25), 9, 0)
+    assert abs(U[0][0] - 0.5488135) < 1e-7 and abs(V[0][0] - 1.15834001e-01) < 1e-7   # NMF_tests.py:40-41
+
+
+def test_g1_hals(golden):
+    g = golden("g1_hals.npz")
+    for c in range(int(g["ncases"])):
+        s = int(g[f"c{c}_shape"])
+        log = []
+        V, eps, cnt, _ = orc.hals_nnls_acc(g[f"s{s}_UtM"], g[f"s{s}_UtU"], g[f"s{s}_Vin"], sweep_log=log,
+                                           **_kw(g[f"c{c}_kw"]))
+        assert cnt == int(g[f"c{c}_cnt"]), c
+        np.testing.assert_allclose(V, g[f"c{c}_V"], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(eps, float(g[f"c{c}_eps"]), rtol=1e-12)
+        np.testing.assert_allclose(log, g[f"c{c}_nodelta"], rtol=1e-12)
+
+
+def test_hals_argument_errors():
+    r = np.random.RandomState(0)
+    with pytest.raises(orc.ArgumentException):
+        orc.hals_nnls_acc(r.rand(8, 8), r.rand(8, 8), np.array([]))
+    with pytest.raises(orc.ArgumentException):
+        orc.hals_nnls_acc(r.rand(8), r.rand(8, 8), r.rand(8, 8))
+    G = r.rand(8, 8)
+    G[2, 2] = 0
+    orc.hals_nnls_acc(r.rand(8, 8), G, r.rand(8, 8))
+    with pytest.raises(orc.ZeroColumnWhenUnautorized):
+        orc.hals_nnls_acc(r.rand(8, 8), G, r.rand(8, 8), nonzero=True)
+
+
+def test_g2_mu_and_divergence(golden):
+    g = golden("g2_mu.npz")
+    U, V, M = g["U"], g["V"], g["M"]
+    for b in (0, 0.5, 1, 1.5, 2, 3, 4):
+        b = int(b) if float(b).is_integer() else b
+        np.testing.assert_allclose(orc.switch_alternate_mu(M, U, V, b, "U"), g[f"muU_b{b}"], rtol=1e-13)
+        np.testing.assert_allclose(orc.switch_alternate_mu(M, U, V, b, "V"), g[f"muV_b{b}"], rtol=1e-13)
+        np.testing.assert_allclose(orc.beta_divergence(M, U @ V, b), float(g[f"div_b{b}"]), rtol=1e-13)
+        assert orc.gamma_beta(b) == float(g[f"gamma_b{b}"])
+    with pytest.raises(orc.InvalidArgumentValue):
+        orc.mu_betadivmin(U, V, M, -1)
+    with pytest.raises(orc.InvalidArgumentValue):
+        orc.switch_alternate_mu(M, U, V, 1, "X")
+
+
+def test_g4_config_a(golden):
+    g = golden("g4_nmf_configA.npz")
+    for dt, tag, tol in ((np.float64, "f64", 1e-12), (np.float32, "f32", 2e-5)):
+        X, U0, V0 = g["X"].astype(dt), g["U0"].astype(dt), g["V0"].astype(dt)
+        for rule, beta in (("hals", 2), ("mu", 2), ("mu", 1), ("mu", 0), ("mu", 1.5), ("mu", 3)):
+            sw = []
+            U, V, costs, _ = orc.nmf(X, 10, init="custom", U_0=U0, V_0=V0, n_iter_max=10, tol=0, update_rule=rule,
+                                     beta=beta, return_costs=True, deterministic=True, sweeps=sw)
+            k = f"{rule}_b{beta}_{tag}"
+            np.testing.assert_allclose(U, g[f"U_{k}"], rtol=tol, atol=tol)
+            np.testing.assert_allclose(V, g[f"V_{k}"], rtol=tol, atol=tol)
+            np.testing.assert_allclose(costs, g[f"costs_{k}"], rtol=max(tol, 1e-12))
+            assert list(sw) == list(g[f"sweeps_{k}"])
+    X, U0, V0 = g["X"], g["U0"], g["V0"]
+    U, V, costs, _ = orc.nmf(X, 10, init="custom", U_0=U0, V_0=V0, n_iter_max=6, tol=0, update_rule="hals",
+                             sparsity_coefficients=[0.05, 0.1], normalize=[False, True], return_costs=True,
+                             deterministic=True)
+    np.testing.assert_allclose(U, g["U_hals_sparse_norm"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(costs, g["costs_hals_sparse_norm"], rtol=1e-11)
+    U, V, costs, _ = orc.nmf(X, 10, init="custom", U_0=U0, V_0=V0, n_iter_max=4, tol=0, update_rule="hals",
+                             fixed_modes=[0], return_costs=True, deterministic=True)
+    np.testing.assert_allclose(U, U0)            # mode 0 fixed: U untouched
+    np.testing.assert_allclose(V, g["V_hals_fixed0"], rtol=1e-11, atol=1e-13)
+
+
+def test_g6_ntf(golden):
+    g = golden("g6_ntf.npz")
+    for name in ("small", "cube", "ragged"):
+        T = g[f"{name}_T"]
+        F0 = [g[f"{name}_F0_{i}"] for i in range(3)]
+        R = F0[0].shape[1]
+        unf = [orc.unfold(T, m) for m in range(3)]
+        nrm = np.sqrt(np.sum(T ** 2))
+        # unfold/khatri_rao convention: unfold(cp(F), mode) == F[mode] @ khatri_rao(F, skip=mode).T
+        cp = np.einsum('ir,jr,kr->ijk', *F0)
+        for mode in range(3):
+            np.testing.assert_allclose(orc.unfold(cp, mode), F0[mode] @ orc.khatri_rao(F0, skip_matrix=mode).T,
+                                       rtol=1e-12)
+        for rule, beta in (("hals", 2), ("mu", 2), ("mu", 1)):
+            f = [x.copy() for x in F0]
+            costs = []
+            for _ in range(5):
+                f, c = orc.one_ntf_step(unf, R, f, nrm, rule, beta, [None] * 3, [], [False] * 3, alpha=math.inf,
+                                        delta=0.01)
+                costs.append(c)
+            for i in range(3):
+                np.testing.assert_allclose(f[i], g[f"{name}_{rule}_b{beta}_F{i}"], rtol=1e-10, atol=1e-13)
+            np.testing.assert_allclose(costs, g[f"{name}_{rule}_b{beta}_costs"], rtol=1e-10)

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- HALS NMF outer iterations/s on the MI355X engine (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--rule hals|mu] [--no-cpu]
+
+One "step" = one outer NMF iteration (nn_fac.nmf.one_nmf_step semantics: U update, V update, cost) on synthetic dense
+data already resident in HBM.  N = 1: configs[1] of BASELINE.json, 100000 x 2000 rank 50, HALS, fp32, deterministic
+(alpha = inf, delta = 0.01, maxiter = 100).  N > 1 (torchrun, one rank per GPU, RCCL): the data matrix is row-sharded,
+every rank holds a 100000 x 2000 block of an (N*100000) x 2000 matrix (weak scaling); the r x r Gram and r x n cross term
+are all-reduced.  `value` counts 100000-row blocks processed per second = N * iterations/s, so it is
+the whole-job aggregate and equals iterations/s at N = 1.
+
+The JSON line also carries
+  roofline     -- the dominant kernel (xty, "W^T X"): algorithmic flops 2*r*m*n per launch / its mean launch time,
+                  measured live with HIP events on the launch stream, against the dense fp32 MFMA peak (157.3 TFLOP/s);
+  cpu_baseline -- the NumPy restatement of the reference (oracle/, kind "port") timed on this box's host cores on a
+                  bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M, N, R = 100000, 2000, 50
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_on_device(m, n, r, seed, device):
+    """X = W*H* + 1e-2*rand (strictly positive), U0, V0 -- same recipe as SURVEY.md 8d, generated in HBM."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    W = torch.rand(m, r, device=device, generator=g)
+    H = torch.rand(r, n, device=device, generator=g)
+    X = W @ H
+    X += 1e-2 * torch.rand(m, n, device=device, generator=g)
+    U0 = torch.rand(m, r, device=device, generator=g)
+    V0 = torch.rand(r, n, device=device, generator=g)
+    return X, U0, V0
+
+
+def time_kernel(fn, reps, stream):
+    """Mean duration (ms) of `fn` launches, HIP events recorded on the launch stream."""
+    for _ in range(2):
+        fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    stream.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def cpu_baseline(rule, beta):
+    """Bounded sample of the same workload through the CPU oracle (the reference's statement sequence)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nnfac_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    ms = 20000                                   # 1/5 of the rows, same n and r: ~10-30 s of CPU work
+    X, U0, V0 = orc.synth_nmf(ms, N, R, seed=0, dtype=np.float32)
+    U, V = U0, V0
+    U, V, _ = orc.one_nmf_step(X, R, U, V, None, rule, beta, [None, None], [], [False, False], True)   # warm-up
+    t0 = time.time()
+    its = 2
+    for _ in range(its):
+        U, V, _ = orc.one_nmf_step(X, R, U, V, None, rule, beta, [None, None], [], [False, False], True)
+    dt = (time.time() - t0) / its
+    # the outer iteration is linear in m (all m-sized statements) apart from the r x n solve, which is small
+    return {"value": (ms / M) / dt, "unit": "iterations/s", "cores": int(threads), "kind": "port",
+            "sample": f"{its} iterations of one_nmf_step on a {ms}x{N} rank-{R} fp32 slice (1/{M // ms} of the rows), "
+                      f"scaled by {ms}/{M}; NumPy/OpenBLAS threads={threads}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rule", default="hals", choices=["hals", "mu"])
+    ap.add_argument("--beta", type=float, default=None)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    beta = args.beta if args.beta is not None else (2 if args.rule == "hals" else 1)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device(f"cuda:{torch.cuda.current_device()}")
+
+    from nn_fac_amd.engine import get_engine
+    from nn_fac_amd import nmf as nmf_mod
+    eng = get_engine(device)
+    X, U0, V0 = synth_on_device(M, N, R, seed=rank, device=device)
+    if world > 1:
+        dist.broadcast(V0, src=0)               # V is replicated
+    Ut, V = U0.t().contiguous(), V0.clone()
+    group = dist.group.WORLD if world > 1 else None
+    ws = nmf_mod._StepBuffers(X, R)
+    sweeps = []
+
+    def step():
+        nonlocal Ut, V
+        Ut, V, nstat = nmf_mod._one_nmf_step_dev(eng, ws, X, R, Ut, V, args.rule, beta, [None, None], [],
+                                                 [False, False], True, group=group)
+        host = ws.block.cpu()                   # cost + status: the per-iteration host sync of compute_nmf
+        sweeps.append([int(host[8 * i + 1]) - 1 for i in range(nstat)])
+        return float(host[16])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sweeps.clear()
+    barrier()
+    t0 = time.perf_counter()
+    cost = None
+    for _ in range(args.steps):
+        cost = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    # dominant kernel, timed live on the launch stream
+    stream = torch.cuda.current_stream(device)
+    xty_ms = time_kernel(lambda: eng.xty(X, Ut, out=ws.UtM), 20, stream)
+    flops = 2.0 * R * M * N
+    achieved = flops / (xty_ms * 1e-3) / 1e12
+    xty_bytes = (M * N + R * M + R * N) * 4
+
+    if rank == 0:
+        out = {
+            "metric": "HALS NMF outer iterations/s (100000x2000 rank-50 row blocks per second)" if args.rule == "hals"
+                      else f"MU(beta={beta:g}) NMF outer iterations/s (100000x2000 rank-50 row blocks per second)",
+            "value": world * args.steps / dt,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"NMF {args.rule} beta={beta:g}, {M}x{N} rank {R} per GPU "
+                                   f"(configs[1] of BASELINE.json), deterministic (alpha=inf, delta=0.01, maxiter=100)",
+                       "rows_total": world * M, "cols": N, "rank": R,
+                       "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
+                       "inner_sweeps_per_step_last": sweeps[-1] if sweeps else None,
+                       "inner_sweeps_mean": float(np.mean([sum(s) for s in sweeps])) if sweeps else None,
+                       "final_cost": cost},
+            "roofline": {"kernel": "nnf_xty_kernel (W^T X)", "bound": "mfma", "achieved": achieved,
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                         "traffic": None, "launch_ms": xty_ms,
+                         "algorithmic_bytes": xty_bytes, "hbm_gbs": xty_bytes / (xty_ms * 1e-3) / 1e9,
+                         "hbm_frac_of_8TBs": xty_bytes / (xty_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.rule, beta)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -100,7 +100,8 @@ int nnf_hals_sweeps_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float
 /* mu_betadivmin (mu.py:79-97) for the left factor, transposed storage:
  *   Ut_out[k,i] = max(Ut[k,i] * (num[k,i]/den[k,i])^gamma(beta), 1e-12),
  *   num = ((UV)^(beta-2) .* X) V^T, den = (UV)^(beta-1) V^T       (beta=1: den = rowsum(V); beta=2: Gram form)
- * One pass over X; U@V is never materialised.  Ut_out may alias Ut only if it is the same pointer. */
+ * One pass over X; U@V is never materialised.  Ut_out must not alias Ut.  beta != 2 needs r <= 64 (else
+ * NNF_ERR_UNSUPPORTED). */
 int nnf_mu_left_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
                     const float* V, int64_t ldv, int r, double beta, float* Ut_out, int64_t lduo, void* stream);
 

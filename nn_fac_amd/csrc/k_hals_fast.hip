@@ -87,8 +87,11 @@ __global__ __launch_bounds__(256, 2) void nnf_hals_kernel(hals_args a) {
     };
     auto store_col = [&](int voff) {
 #pragma unroll
-        for (int k = 0; k < RP; ++k)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2[k / 2][k & 1]), rv, voff, k * ldv4, 0);
+        for (int k = 0; k < RP; ++k) {
+            // NB: __builtin_bit_cast straight from an ext-vector element reads element 0 (hipcc 7.2): go through a scalar
+            const float val = v2[k / 2][k & 1];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rv, voff, k * ldv4, 0);
+        }
     };
     const int voff0 = gtid < a.ncols ? (int)(gtid * 4) : (int)0x7ffffff0;
     if constexpr (RES) load_col(voff0);

@@ -1,5 +1,325 @@
-// MTTKRP of a dense 3-way tensor (ntf.py:448-449).  Placeholder entry point until the kernel lands.
+// MTTKRP of a dense 3-way tensor T[I x J x K] (C order, k fastest) with the Khatri-Rao product of the two other factors
+// generated on the fly -- replaces khatri_rao + np.dot(unfolded[mode], krao) of nn_fac/ntf.py:448-449.
+//
+// The reference materialises all three unfoldings (ntf.py:309-311) and the (250000 x R) Khatri-Rao matrix.  Here the
+// tensor is read in place, ONCE per mode, and a Khatri-Rao row is two factor entries multiplied while the small
+// operand is staged into LDS:
+//   mode 0:  out[r][i] = sum_{j,k} T[i][j][k] F1t[r][j] F2t[r][k]     rows i (ld J*K), segments j (offset j*K), inner k
+//   mode 1:  out[r][j] = sum_{i,k} T[i][j][k] F0t[r][i] F2t[r][k]     rows j (ld K),   segments i (offset i*J*K), inner k
+//            -> both are "V X^T"-shaped (reduction along the contiguous axis): one segmented kernel, split over segments
+//   mode 2:  out[r][k] = sum_{i,j} T[i][j][k] F0t[r][i] F1t[r][j]     T seen as an (I*J) x K matrix, reduction over rows
+//            -> "W^T X"-shaped, split over rows
+// Same MFMA / buffer-load / fragment-order machinery as k_stream.hip; partial slabs are summed in fp64 in a fixed order.
+// unfold/khatri_rao index conventions follow tensorly 0.6.0 (first remaining mode slowest), see SURVEY.md appendix B.
 #include "k_stream_common.h"
 
-extern "C" int nnf_mttkrp3_f32(nnf_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const float*,
-                               int64_t, const float*, int64_t, int, int, float*, int64_t, void*) { return NNF_ERR_UNSUPPORTED; }
+// ---------------------------------------------------------------------------------------------------------
+// segmented V X^T:  out[rk][row] = sum_{s in split} Fs[rk][s] * sum_k Fk[rk][k] * T[row*ldrow + s*segstride + k]
+//   grid = row blocks (256 rows) x segment splits; slab[split][rk][row]
+// ---------------------------------------------------------------------------------------------------------
+template <int MT, bool VEC>
+__global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_seg_kernel(
+    const float* __restrict__ T, int64_t nrows, int64_t ldrow, int64_t nseg, int64_t segstride, int64_t klen,
+    const float* __restrict__ Fs, int64_t lds_, const float* __restrict__ Fk, int64_t ldk, int r,
+    float* __restrict__ slabs, int64_t ldp, int nrb, int nsplit, int64_t seg_per_split, int fk_vec_ok) {
+    __shared__ f32x4 ldsA[2][MT * 256];
+    int sp, rb;
+    nnf_xcd_map(blockIdx.x, nrb, sp, rb);
+    if (sp >= nsplit) return;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ii = lane & 15, g = lane >> 4;
+    const int64_t s_begin = (int64_t)sp * seg_per_split;
+    const int64_t s_end = (s_begin + seg_per_split < nseg) ? (s_begin + seg_per_split) : nseg;
+    const int64_t i0w = (int64_t)rb * 256 + 64 * w;
+    int64_t rows = nrows - i0w;
+    if (rows > 64) rows = 64;
+    const int cps = (int)((klen + 63) >> 6);               // chunks per segment
+    const int nchunk = (int)(s_end - s_begin) * cps;
+    const int ldr4 = (int)(ldrow * 4);
+    const int voff = (int)(((int64_t)ii * ldrow + 4 * g) * 4);
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 xb[4][4];
+    f32x4 areg[MT];
+
+    // A tile of chunk q: KR values Fs[row][s] * Fk[row][k0 + ...], zero past the segment end
+    auto genA = [&](int q) {
+        const int64_t s = s_begin + q / cps;
+        const int64_t k0 = (int64_t)(q % cps) * 64;
+        stageA_load<MT>(Fk, ldk, r, (q < nchunk) ? klen : 0, k0, fk_vec_ok, areg);
+        if (q < nchunk) {
+            const int L = threadIdx.x & 63;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = 16 * mt + (L & 15);
+                const float f = (row < r) ? Fs[(int64_t)row * lds_ + s] : 0.f;
+                areg[mt] *= f;
+            }
+        }
+    };
+    // one descriptor per segment (32-bit offsets stay inside the wave's 64 rows of one segment)
+    auto seg_rsrc = [&](int q) -> rsrc_t {
+        const int64_t s = s_begin + q / cps;
+        const bool live = (q < nchunk) && rows > 0;
+        const float* base = T + (live ? (i0w * ldrow + s * segstride) : 0);
+        const uint32_t bytes = live ? (uint32_t)(((rows - 1) * ldrow + klen) * 4) : 0u;
+        return nnf_make_rsrc(base, bytes);
+    };
+    auto loadX = [&](int q, int t) {
+        const rsrc_t rs = seg_rsrc(q);
+        const int kb = (q % cps) * 256 + 64 * t;            // byte offset of the k-group inside the segment
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldr4 + kb);
+    };
+
+    genA(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) loadX(0, t);
+    stageA_store<MT>(ldsA[0], areg);
+    __syncthreads();
+
+    for (int q = 0; q < nchunk; ++q) {
+        const f32x4* img = ldsA[q & 1];
+        genA(q + 1);
+        const int64_t kbase = (int64_t)(q % cps) * 64;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 af[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = img[(mt * 4 + t) * 64 + lane];
+            // ragged segment tail: the bytes past klen belong to the next tensor row
+            const int64_t krem = klen - (kbase + 16 * t + 4 * g);
+            if (krem < 4) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c >= krem) xb[t][nt][c] = 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(af[mt][c], xb[t][nt][c], acc[mt][nt]);
+            loadX(q + 1, t);
+        }
+        stageA_store<MT>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
+        __syncthreads();
+    }
+    float* sl = slabs + (int64_t)sp * r * ldp;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int64_t i = i0w + 16 * nt + ii;
+        if (i < nrows) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int rk = 16 * mt + 4 * g + reg;
+                    if (rk < r) sl[(int64_t)rk * ldp + i] = acc[mt][nt][reg];
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// mode 2:  slab[split][rk][k] = sum_{row in split} Fa[rk][row / nb] * Fb[rk][row % nb] * M[row][k],  M = T as (I*J) x K
+// ---------------------------------------------------------------------------------------------------------
+template <int MT, bool VEC>
+__global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_rows_kernel(
+    const float* __restrict__ M, int64_t m, int64_t n, int64_t ldx, const float* __restrict__ Fa, int64_t lda,
+    const float* __restrict__ Fb, int64_t ldb, int64_t nb, int r, float* __restrict__ slabs, int64_t ldp, int ncb,
+    int nsplit, int64_t rows_per_split) {
+    __shared__ f32x4 ldsA[2][MT * 256];
+    int ks, cb;
+    nnf_xcd_map(blockIdx.x, ncb, ks, cb);
+    if (ks >= nsplit) return;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jj = lane & 15, g = lane >> 4;
+    const int64_t i_begin = (int64_t)ks * rows_per_split;
+    const int64_t i_end = (i_begin + rows_per_split < m) ? (i_begin + rows_per_split) : m;
+    const int nchunk = (int)((i_end - i_begin + 63) >> 6);
+    const int64_t jl = (int64_t)cb * 256 + w * 64 + 4 * jj;
+    const rsrc_t rs = nnf_make_rsrc(M + i_begin * ldx, (uint32_t)(((i_end - i_begin - 1) * ldx + n) * 4));
+    const int voff = (jl < n) ? (int)(((int64_t)4 * g * ldx + jl) * 4) : (int)0x7ffffff0;
+    const int ldx4 = (int)(ldx * 4);
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) acc[mt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 xb[4][4];
+    f32x4 areg[MT];
+    auto genA = [&](int q) {   // areg[mt].c = Fa[row][i] * Fb[row][j] for tensor row (i*nb + j) = i_begin + 64q + 16t + 4g + c
+        const int t = threadIdx.x >> 6, L = threadIdx.x & 63;
+        const int64_t rr = i_begin + 64 * (int64_t)q + 16 * t + 4 * (L >> 4);
+        const int64_t ia0 = rr / nb, ib0 = rr - ia0 * nb;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = 16 * mt + (L & 15);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < r) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (rr + c < i_end) {
+                        int64_t ia = ia0, ib = ib0 + c;   // one division per thread and chunk, then carry
+                        while (ib >= nb) { ib -= nb; ++ia; }
+                        v[c] = Fa[(int64_t)row * lda + ia] * Fb[(int64_t)row * ldb + ib];
+                    }
+                }
+            }
+            areg[mt] = v;
+        }
+    };
+    genA(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, (16 * t + c) * ldx4);
+    stageA_store<MT>(ldsA[0], areg);
+    __syncthreads();
+    for (int q = 0; q < nchunk; ++q) {
+        const f32x4* img = ldsA[q & 1];
+        genA(q + 1);
+        const int soff_next = (q + 1) * 64 * ldx4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 af[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = img[(mt * 4 + t) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) acc[mt][cc] = MFMA16(af[mt][c], xb[t][c][cc], acc[mt][cc]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, soff_next + (16 * t + c) * ldx4);
+        }
+        stageA_store<MT>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
+        __syncthreads();
+    }
+    if (jl < ldp) {
+        float* sl = slabs + (int64_t)ks * r * ldp;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rk = 16 * mt + 4 * g + reg;
+                if (rk < r)
+                    *reinterpret_cast<f32x4*>(sl + (int64_t)rk * ldp + jl) =
+                        f32x4{acc[mt][0][reg], acc[mt][1][reg], acc[mt][2][reg], acc[mt][3][reg]};
+            }
+    }
+}
+
+template <int MT, bool VEC>
+static int launch_seg(nnf_ctx* ctx, const float* T, int64_t nrows, int64_t ldrow, int64_t nseg, int64_t segstride,
+                      int64_t klen, const float* Fs, int64_t lds_, const float* Fk, int64_t ldk, int r, float* out,
+                      int64_t ldo, hipStream_t st) {
+    if ((64 * ldrow + klen + 256) * 4 >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
+    const int nrb = (int)nnf_cdiv(nrows, 256);
+    const int64_t ldp = nnf_rup(nrows, 4);
+    int64_t nsplit = 2 * (int64_t)ctx->num_cus / nrb;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > nseg) nsplit = nseg;
+    nnf_ws_cursor cur(ctx);
+    const int64_t slab_elems = (int64_t)r * ldp;
+    const int64_t ws_max = (int64_t)(cur.remaining() / 4) / slab_elems;
+    if (ws_max < 1) return NNF_ERR_WORKSPACE;
+    if (nsplit > ws_max) nsplit = ws_max;
+    const int64_t sps = nnf_cdiv(nseg, nsplit);
+    nsplit = nnf_cdiv(nseg, sps);
+    float* slabs = (float*)cur.take((size_t)nsplit * slab_elems * 4);
+    if (!slabs) return NNF_ERR_WORKSPACE;
+    const int fk_vec_ok = ((((uintptr_t)Fk) & 15) == 0 && (ldk & 3) == 0) ? 1 : 0;
+    const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * nrb;
+    hipLaunchKernelGGL((nnf_mttkrp_seg_kernel<MT, VEC>), dim3(grid), dim3(256), 0, st, T, nrows, ldrow, nseg, segstride,
+                       klen, Fs, lds_, Fk, ldk, r, slabs, ldp, nrb, (int)nsplit, sps, fk_vec_ok);
+    NNF_CHECK_LAUNCH();
+    return nnf_launch_reduce_slabs(slabs, (int)nsplit, slab_elems, r, nrows, ldp, out, ldo, st);
+}
+
+template <int MT, bool VEC>
+static int launch_rows(nnf_ctx* ctx, const float* M, int64_t m, int64_t n, const float* Fa, int64_t lda, const float* Fb,
+                       int64_t ldb, int64_t nb, int r, float* out, int64_t ldo, hipStream_t st) {
+    const int ncb = (int)nnf_cdiv(n, 256);
+    const int64_t ldp = nnf_rup(n, 4);
+    int64_t nsplit = 2 * (int64_t)ctx->num_cus / ncb;
+    if (nsplit < 1) nsplit = 1;
+    const int64_t max_split = nnf_cdiv(m, 64);
+    if (nsplit > max_split) nsplit = max_split;
+    nnf_ws_cursor cur(ctx);
+    const int64_t slab_elems = (int64_t)r * ldp;
+    const int64_t ws_max = (int64_t)(cur.remaining() / 4) / slab_elems;
+    if (ws_max < 1) return NNF_ERR_WORKSPACE;
+    if (nsplit > ws_max) nsplit = ws_max;
+    int64_t rps = nnf_rup(nnf_cdiv(m, nsplit), 64);
+    while ((rps + 128) * n * 4 >= (int64_t)0x7fff0000) {
+        if (rps <= 64) return NNF_ERR_UNSUPPORTED;
+        rps = nnf_rup(rps / 2, 64);
+    }
+    nsplit = nnf_cdiv(m, rps);
+    if (nsplit > ws_max) return NNF_ERR_WORKSPACE;
+    float* slabs = (float*)cur.take((size_t)nsplit * slab_elems * 4);
+    if (!slabs) return NNF_ERR_WORKSPACE;
+    const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * ncb;
+    hipLaunchKernelGGL((nnf_mttkrp_rows_kernel<MT, VEC>), dim3(grid), dim3(256), 0, st, M, m, n, n, Fa, lda, Fb, ldb, nb, r,
+                       slabs, ldp, ncb, (int)nsplit, rps);
+    NNF_CHECK_LAUNCH();
+    return nnf_launch_reduce_slabs(slabs, (int)nsplit, slab_elems, r, n, ldp, out, ldo, st);
+}
+
+#define MTTKRP_MT(FN, VEC, ...)                       \
+    switch (MT) {                                     \
+        case 1: return FN<1, VEC>(__VA_ARGS__);       \
+        case 2: return FN<2, VEC>(__VA_ARGS__);       \
+        case 3: return FN<3, VEC>(__VA_ARGS__);       \
+        case 4: return FN<4, VEC>(__VA_ARGS__);       \
+        case 5: return FN<5, VEC>(__VA_ARGS__);       \
+        case 6: return FN<6, VEC>(__VA_ARGS__);       \
+        case 7: return FN<7, VEC>(__VA_ARGS__);       \
+        default: return FN<8, VEC>(__VA_ARGS__);      \
+    }
+
+static int seg_dispatch(nnf_ctx* ctx, const float* T, int64_t nrows, int64_t ldrow, int64_t nseg, int64_t segstride,
+                        int64_t klen, const float* Fs, int64_t lds_, const float* Fk, int64_t ldk, int R, float* out,
+                        int64_t ldo, hipStream_t st) {
+    const int MT = (R + 15) / 16;
+    const bool vec = ((((uintptr_t)T) & 15) == 0) && (ldrow % 4 == 0) && (segstride % 4 == 0);
+    if (vec) { MTTKRP_MT(launch_seg, true, ctx, T, nrows, ldrow, nseg, segstride, klen, Fs, lds_, Fk, ldk, R, out, ldo, st) }
+    else { MTTKRP_MT(launch_seg, false, ctx, T, nrows, ldrow, nseg, segstride, klen, Fs, lds_, Fk, ldk, R, out, ldo, st) }
+}
+
+static int rows_dispatch(nnf_ctx* ctx, const float* M, int64_t m, int64_t n, const float* Fa, int64_t lda,
+                         const float* Fb, int64_t ldb, int64_t nb, int R, float* out, int64_t ldo, hipStream_t st) {
+    const int MT = (R + 15) / 16;
+    if (x_vec_ok(M, n)) { MTTKRP_MT(launch_rows, true, ctx, M, m, n, Fa, lda, Fb, ldb, nb, R, out, ldo, st) }
+    else { MTTKRP_MT(launch_rows, false, ctx, M, m, n, Fa, lda, Fb, ldb, nb, R, out, ldo, st) }
+}
+
+extern "C" int nnf_mttkrp3_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t K, const float* Ft0,
+                               int64_t ld0, const float* Ft1, int64_t ld1, const float* Ft2, int64_t ld2, int R, int mode,
+                               float* out, int64_t ldo, void* stream) {
+    if (!ctx || !T || !Ft0 || !Ft1 || !Ft2 || !out || I < 1 || J < 1 || K < 1 || R < 1 || ld0 < I || ld1 < J || ld2 < K)
+        return NNF_ERR_ARG;
+    if (mode < 0 || mode > 2) return NNF_ERR_ARG;
+    if (R > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) {
+        if (ldo < I) return NNF_ERR_ARG;
+        return seg_dispatch(ctx, T, I, J * K, J, K, K, Ft1, ld1, Ft2, ld2, R, out, ldo, st);
+    }
+    if (mode == 1) {
+        if (ldo < J) return NNF_ERR_ARG;
+        return seg_dispatch(ctx, T, J, K, I, J * K, K, Ft0, ld0, Ft2, ld2, R, out, ldo, st);
+    }
+    if (ldo < K) return NNF_ERR_ARG;
+    return rows_dispatch(ctx, T, I * J, K, Ft0, ld0, Ft1, ld1, J, R, out, ldo, st);
+}

@@ -1,10 +1,529 @@
-// beta-divergence multiplicative updates and cost (mu.py:79-97, beta_divergence.py:45-52).  Placeholder entry points
-// until the fused two-GEMM kernels land (they return NNF_ERR_UNSUPPORTED; the Python host raises).
+// beta-divergence multiplicative updates (nn_fac/update_rules/mu.py:79-97) fused with the product K = U V.
+//
+//   left  (mu_betadivmin on U):   Ut_new[k,i] = max(Ut[k,i] * (num[k,i]/den[k,i])^gamma, 1e-12)
+//            num = ((K^(b-2) .* X) V^T)^T,  den = (K^(b-1) V^T)^T          (b = 1: den[k] = rowsum(V)[k])
+//   right (switch_alternate_mu "V"): V_new[k,j] = max(V[k,j] * (num/den)^gamma, 1e-12)
+//            num = U^T (K^(b-2) .* X),      den = U^T K^(b-1)              (b = 1: den[k] = colsum(U)[k])
+//   b = 2 needs no K at all: num = X V^T (xht) / U^T X (xty), den = (V V^T) U^T / (U^T U) V  (Gram form).
+//
+// One pass over X per update.  Per 16 x 64 (right) or 64 x 16 (left) block of X a wave runs
+//   MFMA #1 : P = U V tile, k over the rank            (operands in LDS: "F_K" image + resident fragments)
+//   VALU    : R = K^(b-2) .* X  [and K^(b-1)] in the accumulator layout (masked outside the matrix)
+//   MFMA #2 : num (+den) += factor-fragment * R, k over the block's rows (right) / columns (left): the accumulator
+//             tile of MFMA #1 is used AS the B operand of MFMA #2 with no lane movement, because P is computed in the
+//             orientation whose row index is the contracted one (cdna_hip_programming.md s.3, "accumulator as operand").
+// X goes HBM -> VGPR once, 16 bytes per lane; K is never written anywhere.
+// Built for r <= 64 (MT <= 4); larger ranks return NNF_ERR_UNSUPPORTED for beta != 2.
 #include "k_stream_common.h"
+#include <math.h>
 
-extern "C" int nnf_mu_left_f32(nnf_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const float*,
-                               int64_t, int, double, float*, int64_t, void*) { return NNF_ERR_UNSUPPORTED; }
-extern "C" int nnf_mu_right_f32(nnf_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const float*,
-                                int64_t, int, double, float*, int64_t, void*) { return NNF_ERR_UNSUPPORTED; }
-extern "C" int nnf_betadiv_f32(nnf_ctx*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, const float*,
-                               int64_t, int, double, double*, void*) { return NNF_ERR_UNSUPPORTED; }
+enum { BM_KL = 1, BM_GEN = 9 };
+
+// F_K image of a 64-wide chunk of a row-major r x K matrix A (the rank index is the MFMA k index):
+//   img[(t*MT + s4)*64 + lane].c = A[16*s4 + 4*c + (lane>>4)][k0 + 16*t + (lane&15)]       (zero outside r x K)
+template <int MT>
+__device__ __forceinline__ void stageK(const float* __restrict__ A, int64_t lda, int r, int64_t K, int64_t k0,
+                                       f32x4* __restrict__ img) {
+    const int t = threadIdx.x >> 6, L = threadIdx.x & 63;
+    const int64_t col = k0 + 16 * t + (L & 15);
+#pragma unroll
+    for (int s4 = 0; s4 < MT; ++s4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (col < K) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int row = 16 * s4 + 4 * c + (L >> 4);
+                if (row < r) v[c] = A[(int64_t)row * lda + col];
+            }
+        }
+        img[(t * MT + s4) * 64 + L] = v;
+    }
+}
+
+template <int MT>
+__device__ __forceinline__ void stageA_direct(const float* __restrict__ A, int64_t lda, int r, int64_t K, int64_t k0,
+                                              bool vec_ok, f32x4* __restrict__ img) {
+    f32x4 regs[MT];
+    stageA_load<MT>(A, lda, r, K, k0, vec_ok, regs);
+    stageA_store<MT>(img, regs);
+}
+
+template <int BM>
+__device__ __forceinline__ void mu_elem(float x, float p, float beta, float& r1, float& r2) {
+    if constexpr (BM == BM_KL) {
+        r1 = x * __builtin_amdgcn_rcpf(p);
+        r2 = 0.f;
+    } else {
+        // r2 = p^(beta-1), r1 = p^(beta-2) x
+        const float lp = __builtin_amdgcn_logf(p);               // log2
+        r2 = __builtin_amdgcn_exp2f((beta - 1.f) * lp);
+        r1 = r2 * __builtin_amdgcn_rcpf(p) * x;
+    }
+}
+
+// =========================================================================================================
+// right update: slabs of num (and den) [ks][r][ldp], split over the rows of X like xty.
+// =========================================================================================================
+template <int MT, int BM, bool VEC>
+__global__ __launch_bounds__(256, 1) void nnf_mu_right_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+                                                              const float* __restrict__ Ut, int64_t ldu,
+                                                              const float* __restrict__ V, int64_t ldv, int r, float beta,
+                                                              float* __restrict__ snum, float* __restrict__ sden,
+                                                              int64_t ldp, int ncb, int nsplit, int64_t rows_per_split,
+                                                              int a_vec_ok) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KS = (r + 3) >> 2;
+    f32x4* ldsVf = reinterpret_cast<f32x4*>(smem);                 // [4][KS][64]: V[4s+g][jw+4jj..+3]
+    f32x4* ldsA = ldsVf + (size_t)4 * KS * 64;                       // [2][MT*256]  F_A image of the Ut chunk
+    f32x4* ldsK = ldsA + (size_t)2 * MT * 256;                       // [2][MT*256]  F_K image of the Ut chunk
+    int ks, cb;
+    nnf_xcd_map(blockIdx.x, ncb, ks, cb);
+    if (ks >= nsplit) return;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jj = lane & 15, g = lane >> 4;
+    const int64_t i_begin = (int64_t)ks * rows_per_split;
+    const int64_t i_end = (i_begin + rows_per_split < m) ? (i_begin + rows_per_split) : m;
+    const int nchunk = (int)((i_end - i_begin + 63) >> 6);
+    const int64_t jw = (int64_t)cb * 256 + w * 64, jl = jw + 4 * jj;
+    const rsrc_t rs = nnf_make_rsrc(X + i_begin * ldx, (uint32_t)(((i_end - i_begin - 1) * ldx + n) * 4));
+    const int voff = (jl < n) ? (int)(((int64_t)4 * g * ldx + jl) * 4) : (int)0x7ffffff0;
+    const int ldx4 = (int)(ldx * 4);
+
+    // resident V fragments of this workgroup's 256 columns
+    for (int e = threadIdx.x; e < 4 * KS * 64; e += 256) {
+        const int ww = e / (KS * 64), rem = e - ww * KS * 64, s = rem >> 6, L = rem & 63;
+        const int k = 4 * s + (L >> 4);
+        const int64_t j = (int64_t)cb * 256 + ww * 64 + 4 * (L & 15);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < r && j < n) {
+            const float* p = V + (int64_t)k * ldv + j;
+            v[0] = p[0];
+            if (j + 1 < n) v[1] = p[1];
+            if (j + 2 < n) v[2] = p[2];
+            if (j + 3 < n) v[3] = p[3];
+        }
+        ldsVf[e] = v;
+    }
+    f32x4 num[MT][4], den[BM == BM_GEN ? MT : 1][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            num[mt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BM == BM_GEN) den[mt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    f32x4 xb[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, (16 * t + c) * ldx4);
+    stageA_direct<MT>(Ut, ldu, r, i_end, i_begin, a_vec_ok, ldsA);
+    stageK<MT>(Ut, ldu, r, i_end, i_begin, ldsK);
+    __syncthreads();
+    const f32x4* vf = ldsVf + (size_t)w * KS * 64 + lane;
+
+    for (int q = 0; q < nchunk; ++q) {
+        const f32x4* imgA = ldsA + (size_t)(q & 1) * MT * 256;
+        const f32x4* imgK = ldsK + (size_t)(q & 1) * MT * 256;
+        if (q + 1 < nchunk) {
+            stageA_direct<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), a_vec_ok, ldsA + (size_t)((q + 1) & 1) * MT * 256);
+            stageK<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), ldsK + (size_t)((q + 1) & 1) * MT * 256);
+        }
+        const int soff_next = (q + 1) * 64 * ldx4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // MFMA #1: P[i0+16t+4g+reg][jw+4jj+cc]
+            f32x4 accP[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) accP[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < MT; ++s4) {
+                const f32x4 ak = imgK[(t * MT + s4) * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (4 * s4 + c < KS) {
+                        const f32x4 bv = vf[(4 * s4 + c) * 64];
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) accP[cc] = MFMA16(ak[c], bv[cc], accP[cc]);
+                    }
+                }
+            }
+            // element-wise, masked past the split's last row (0/0 otherwise)
+            const int64_t rowrem = (i_end - i_begin) - (64 * (int64_t)q + 16 * t + 4 * g);
+            f32x4 R1[4], R2[BM == BM_GEN ? 4 : 1];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    float r1, r2;
+                    mu_elem<BM>(xb[t][reg][cc], accP[cc][reg], beta, r1, r2);
+                    const bool ok = reg < rowrem;
+                    R1[cc][reg] = ok ? r1 : 0.f;
+                    if constexpr (BM == BM_GEN) R2[cc][reg] = ok ? r2 : 0.f;
+                }
+            // MFMA #2: num[rk][j] += Ut[rk][i] * R[i][j], k = the block's 16 rows
+            f32x4 af[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = imgA[(mt * 4 + t) * 64 + lane];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        num[mt][cc] = MFMA16(af[mt][reg], R1[cc][reg], num[mt][cc]);
+                        if constexpr (BM == BM_GEN) den[mt][cc] = MFMA16(af[mt][reg], R2[cc][reg], den[mt][cc]);
+                    }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, soff_next + (16 * t + c) * ldx4);
+        }
+        __syncthreads();
+    }
+    if (jl < ldp) {
+        float* sn = snum + (int64_t)ks * r * ldp;
+        float* sd = (BM == BM_GEN) ? sden + (int64_t)ks * r * ldp : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rk = 16 * mt + 4 * g + reg;
+                if (rk < r) {
+                    *reinterpret_cast<f32x4*>(sn + (int64_t)rk * ldp + jl) =
+                        f32x4{num[mt][0][reg], num[mt][1][reg], num[mt][2][reg], num[mt][3][reg]};
+                    if constexpr (BM == BM_GEN)
+                        *reinterpret_cast<f32x4*>(sd + (int64_t)rk * ldp + jl) =
+                            f32x4{den[mt][0][reg], den[mt][1][reg], den[mt][2][reg], den[mt][3][reg]};
+                }
+            }
+    }
+}
+
+// F_new = max(F * (num/den)^gamma, 1e-12); num/den summed over slabs in fp64 (fixed order); den_vec: per-row denominator (KL)
+__global__ __launch_bounds__(256) void nnf_mu_finish_kernel(const float* __restrict__ F, int64_t ldf, int r, int64_t cols,
+                                                            const float* __restrict__ snum, const float* __restrict__ sden,
+                                                            int nslab, int64_t slab_stride, int64_t lds,
+                                                            const double* __restrict__ den_vec, float gamma,
+                                                            float* __restrict__ out, int64_t ldo) {
+    const int64_t total = (int64_t)r * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t k = e / cols, j = e - k * cols;
+        double nu = 0.0, de = 0.0;
+        for (int s = 0; s < nslab; ++s) nu += (double)snum[(int64_t)s * slab_stride + k * lds + j];
+        if (den_vec) de = den_vec[k];
+        else
+            for (int s = 0; s < nslab; ++s) de += (double)sden[(int64_t)s * slab_stride + k * lds + j];
+        float ratio = (float)(nu / de);
+        if (gamma != 1.f) ratio = powf(ratio, gamma);
+        out[k * ldo + j] = fmaxf(F[k * ldf + j] * ratio, 1e-12f);
+    }
+}
+
+// out[k] = sum_j A[k][j]  (fp64)
+__global__ __launch_bounds__(256) void nnf_rowsum_kernel(const float* __restrict__ A, int64_t lda, int64_t K,
+                                                         double* __restrict__ out) {
+    __shared__ double red[4];
+    const float* p = A + (int64_t)blockIdx.x * lda;
+    double s = 0.0;
+    for (int64_t j = threadIdx.x; j < K; j += 256) s += (double)p[j];
+    const double t = nnf_block_sum_f64(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+
+// =========================================================================================================
+// left update: workgroup = 256 rows of X (wave: 64 rows as four 16-row N tiles), sweeping all columns; no split.
+// =========================================================================================================
+template <int MT, int BM, bool VEC>
+__global__ __launch_bounds__(256, 1) void nnf_mu_left_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+                                                             const float* __restrict__ Ut, int64_t ldu,
+                                                             const float* __restrict__ V, int64_t ldv, int r, float beta,
+                                                             const double* __restrict__ den_vec, float gamma,
+                                                             float* __restrict__ Ut_out, int64_t lduo, int a_vec_ok) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KS = (r + 3) >> 2;
+    f32x4* ldsUf = reinterpret_cast<f32x4*>(smem);                 // [4][KS][64]: comps nt: Ut[4s+g][i0w+16nt+ii]
+    f32x4* ldsA = ldsUf + (size_t)4 * KS * 64;                       // [2][MT*256]  F_A image of the V chunk
+    f32x4* ldsK = ldsA + (size_t)2 * MT * 256;                       // [2][MT*256]  F_K image of the V chunk
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ii = lane & 15, g = lane >> 4;
+    const int64_t i0w = (int64_t)blockIdx.x * 256 + 64 * w;
+    int64_t rows = m - i0w;
+    if (rows > 64) rows = 64;
+    const uint32_t bytes = rows > 0 ? (uint32_t)(((rows - 1) * ldx + n) * 4) : 0u;
+    const rsrc_t rs = nnf_make_rsrc(X + (rows > 0 ? i0w : 0) * ldx, bytes);
+    const int voff = (int)(((int64_t)ii * ldx + 4 * g) * 4);
+    const int ldx4 = (int)(ldx * 4);
+    const int nchunk = (int)((n + 63) >> 6);
+
+    for (int e = threadIdx.x; e < 4 * KS * 64; e += 256) {
+        const int ww = e / (KS * 64), rem = e - ww * KS * 64, s = rem >> 6, L = rem & 63;
+        const int k = 4 * s + (L >> 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < r) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int64_t i = (int64_t)blockIdx.x * 256 + 64 * ww + 16 * nt + (L & 15);
+                if (i < m) v[nt] = Ut[(int64_t)k * ldu + i];
+            }
+        }
+        ldsUf[e] = v;
+    }
+    f32x4 num[MT][4], den[BM == BM_GEN ? MT : 1][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            num[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BM == BM_GEN) den[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    f32x4 xb[4][4];  // [t][nt]: X[i0w+16nt+ii][64q+16t+4g .. +3]
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 64 * t);
+    stageA_direct<MT>(V, ldv, r, n, 0, a_vec_ok, ldsA);
+    stageK<MT>(V, ldv, r, n, 0, ldsK);
+    __syncthreads();
+    const f32x4* uf = ldsUf + (size_t)w * KS * 64 + lane;
+
+    for (int q = 0; q < nchunk; ++q) {
+        const f32x4* imgA = ldsA + (size_t)(q & 1) * MT * 256;
+        const f32x4* imgK = ldsK + (size_t)(q & 1) * MT * 256;
+        if (q + 1 < nchunk) {
+            stageA_direct<MT>(V, ldv, r, n, 64 * (int64_t)(q + 1), a_vec_ok, ldsA + (size_t)((q + 1) & 1) * MT * 256);
+            stageK<MT>(V, ldv, r, n, 64 * (int64_t)(q + 1), ldsK + (size_t)((q + 1) & 1) * MT * 256);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // MFMA #1 (transposed product): accP[nt][reg] = P[i0w+16nt+ii][64q+16t+4g+reg]
+            f32x4 accP[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) accP[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < MT; ++s4) {
+                const f32x4 ak = imgK[(t * MT + s4) * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (4 * s4 + c < KS) {
+                        const f32x4 bu = uf[(4 * s4 + c) * 64];
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) accP[nt] = MFMA16(ak[c], bu[nt], accP[nt]);
+                    }
+                }
+            }
+            const int64_t colrem = n - (64 * (int64_t)q + 16 * t + 4 * g);
+            f32x4 R1[4], R2[BM == BM_GEN ? 4 : 1];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const bool rowok = (16 * nt + ii) < rows;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    float r1, r2;
+                    mu_elem<BM>(xb[t][nt][reg], accP[nt][reg], beta, r1, r2);
+                    const bool ok = rowok && (reg < colrem);
+                    R1[nt][reg] = ok ? r1 : 0.f;
+                    if constexpr (BM == BM_GEN) R2[nt][reg] = ok ? r2 : 0.f;
+                }
+            }
+            // MFMA #2: num[rk][i] += V[rk][j] * R[j][i], k = the block's 16 columns
+            f32x4 af[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = imgA[(mt * 4 + t) * 64 + lane];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        num[mt][nt] = MFMA16(af[mt][reg], R1[nt][reg], num[mt][nt]);
+                        if constexpr (BM == BM_GEN) den[mt][nt] = MFMA16(af[mt][reg], R2[nt][reg], den[mt][nt]);
+                    }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * (q + 1) + 64 * t);
+        }
+        __syncthreads();
+    }
+    // epilogue: tile (mt, nt): rk = 16mt+4g+reg, i = i0w+16nt+ii
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int64_t i = i0w + 16 * nt + ii;
+        if (i < m) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int rk = 16 * mt + 4 * g + reg;
+                    if (rk < r) {
+                        float d;
+                        if constexpr (BM == BM_GEN) d = den[mt][nt][reg]; else d = (float)den_vec[rk];
+                        float ratio = num[mt][nt][reg] / d;
+                        if (gamma != 1.f) ratio = powf(ratio, gamma);
+                        Ut_out[(int64_t)rk * lduo + i] = fmaxf(Ut[(int64_t)rk * ldu + i] * ratio, 1e-12f);
+                    }
+                }
+        }
+    }
+}
+
+// beta = 2 (Gram form): out[k][j] = max(F[k][j] * num[k][j] / (sum_l G[k][l] F[l][j]), 1e-12)
+__global__ __launch_bounds__(256) void nnf_mu2_finish_kernel(const float* __restrict__ F, int64_t ldf, int r, int64_t cols,
+                                                             const float* __restrict__ G, const float* __restrict__ num,
+                                                             int64_t ldn, float* __restrict__ out, int64_t ldo) {
+    __shared__ float Gs[NNF_MAX_RANK * NNF_MAX_RANK];
+    for (int e = threadIdx.x; e < r * r; e += 256) Gs[e] = G[e];
+    __syncthreads();
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < cols; j += (int64_t)gridDim.x * 256) {
+        for (int k = 0; k < r; ++k) {
+            float d = 0.f;
+            for (int l = 0; l < r; ++l) d = fmaf(Gs[k * r + l], F[(int64_t)l * ldf + j], d);
+            out[(int64_t)k * ldo + j] = fmaxf(F[(int64_t)k * ldf + j] * (num[(int64_t)k * ldn + j] / d), 1e-12f);
+        }
+    }
+}
+
+static float gamma_of(double beta) { return beta < 1.0 ? (float)(1.0 / (2.0 - beta)) : (beta > 2.0 ? (float)(1.0 / (beta - 1.0)) : 1.f); }
+
+static size_t mu_shm(int MT, int r) { return ((size_t)4 * ((r + 3) / 4) * 64 + (size_t)4 * MT * 256) * 16; }
+
+template <int MT, int BM, bool VEC>
+static int launch_mu_right(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx,
+                           const float* Ut, int64_t ldu, const float* V, int64_t ldv, int r, double beta, float* V_out,
+                           int64_t ldvo, hipStream_t st) {
+    const int ncb = (int)nnf_cdiv(n, 256);
+    const int64_t ldp = nnf_rup(n, 4);
+    const int nacc = (BM == BM_GEN) ? 2 : 1;
+    int64_t nsplit = (int64_t)ctx->num_cus / ncb;   // one 4-wave workgroup per CU (LDS-bound occupancy)
+    if (nsplit < 1) nsplit = 1;
+    const int64_t max_split = nnf_cdiv(m, 64);
+    if (nsplit > max_split) nsplit = max_split;
+    const int64_t slab_elems = (int64_t)r * ldp;
+    double* dvec = (double*)cur.take((size_t)r * 8);
+    if (!dvec) return NNF_ERR_WORKSPACE;
+    const int64_t ws_max = (int64_t)(cur.remaining() / 4) / (slab_elems * nacc);
+    if (ws_max < 1) return NNF_ERR_WORKSPACE;
+    if (nsplit > ws_max) nsplit = ws_max;
+    int64_t rps = nnf_rup(nnf_cdiv(m, nsplit), 64);
+    while ((rps + 128) * ldx * 4 >= (int64_t)0x7fff0000) {
+        if (rps <= 64) return NNF_ERR_UNSUPPORTED;
+        rps = nnf_rup(rps / 2, 64);
+    }
+    nsplit = nnf_cdiv(m, rps);
+    if (nsplit > ws_max) return NNF_ERR_WORKSPACE;
+    float* snum = (float*)cur.take((size_t)nsplit * slab_elems * 4);
+    float* sden = nacc == 2 ? (float*)cur.take((size_t)nsplit * slab_elems * 4) : nullptr;
+    if (!snum || (nacc == 2 && !sden)) return NNF_ERR_WORKSPACE;
+    const int a_vec_ok = ((((uintptr_t)Ut) & 15) == 0 && (ldu & 3) == 0) ? 1 : 0;
+    const size_t shm = mu_shm(MT, r);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_mu_right_kernel<MT, BM, VEC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (BM == BM_KL) {  // den[k] = colsum(U)[k] = rowsum(Ut)[k]   (mu.py:86-87 on the transposed problem)
+        hipLaunchKernelGGL(nnf_rowsum_kernel, dim3(r), dim3(256), 0, st, Ut, ldu, m, dvec);
+        NNF_CHECK_LAUNCH();
+    }
+    const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * ncb;
+    hipLaunchKernelGGL((nnf_mu_right_kernel<MT, BM, VEC>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
+                       (float)beta, snum, sden, ldp, ncb, (int)nsplit, rps, a_vec_ok);
+    NNF_CHECK_LAUNCH();
+    int64_t fg = nnf_cdiv((int64_t)r * n, 256);
+    if (fg > 2048) fg = 2048;
+    hipLaunchKernelGGL(nnf_mu_finish_kernel, dim3((int)fg), dim3(256), 0, st, V, ldv, r, n, snum, sden, (int)nsplit,
+                       slab_elems, ldp, BM == BM_KL ? dvec : (const double*)nullptr, gamma_of(beta), V_out, ldvo);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+
+template <int MT, int BM, bool VEC>
+static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx,
+                          const float* Ut, int64_t ldu, const float* V, int64_t ldv, int r, double beta, float* Ut_out,
+                          int64_t lduo, hipStream_t st) {
+    if (64 * ldx * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
+    double* dvec = (double*)cur.take((size_t)r * 8);
+    if (!dvec) return NNF_ERR_WORKSPACE;
+    const int a_vec_ok = ((((uintptr_t)V) & 15) == 0 && (ldv & 3) == 0) ? 1 : 0;
+    const size_t shm = mu_shm(MT, r);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_mu_left_kernel<MT, BM, VEC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (BM == BM_KL) {  // den[k] = rowsum(V)[k]   (mu.py:86-87)
+        hipLaunchKernelGGL(nnf_rowsum_kernel, dim3(r), dim3(256), 0, st, V, ldv, n, dvec);
+        NNF_CHECK_LAUNCH();
+    }
+    const int grid = (int)nnf_cdiv(m, 256);
+    hipLaunchKernelGGL((nnf_mu_left_kernel<MT, BM, VEC>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
+                       (float)beta, dvec, gamma_of(beta), Ut_out, lduo, a_vec_ok);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+
+#define MU_DISPATCH(FN, ...)                                                                              \
+    do {                                                                                                  \
+        const int MT = (r + 15) / 16;                                                                     \
+        const bool vec = x_vec_ok(X, ldx);                                                                \
+        const bool kl = (beta == 1.0);                                                                    \
+        switch (MT) {                                                                                     \
+            case 1: return kl ? (vec ? FN<1, BM_KL, true>(__VA_ARGS__) : FN<1, BM_KL, false>(__VA_ARGS__))  \
+                              : (vec ? FN<1, BM_GEN, true>(__VA_ARGS__) : FN<1, BM_GEN, false>(__VA_ARGS__)); \
+            case 2: return kl ? (vec ? FN<2, BM_KL, true>(__VA_ARGS__) : FN<2, BM_KL, false>(__VA_ARGS__))  \
+                              : (vec ? FN<2, BM_GEN, true>(__VA_ARGS__) : FN<2, BM_GEN, false>(__VA_ARGS__)); \
+            case 3: return kl ? (vec ? FN<3, BM_KL, true>(__VA_ARGS__) : FN<3, BM_KL, false>(__VA_ARGS__))  \
+                              : (vec ? FN<3, BM_GEN, true>(__VA_ARGS__) : FN<3, BM_GEN, false>(__VA_ARGS__)); \
+            case 4: return kl ? (vec ? FN<4, BM_KL, true>(__VA_ARGS__) : FN<4, BM_KL, false>(__VA_ARGS__))  \
+                              : (vec ? FN<4, BM_GEN, true>(__VA_ARGS__) : FN<4, BM_GEN, false>(__VA_ARGS__)); \
+            default: return NNF_ERR_UNSUPPORTED;                                                          \
+        }                                                                                                 \
+    } while (0)
+
+static int mu_args_ok(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                      const float* V, int64_t ldv, int r, double beta, const float* out) {
+    if (!ctx || !X || !Ut || !V || !out || m < 1 || n < 1 || r < 1 || ldx < n || ldu < m || ldv < n) return NNF_ERR_ARG;
+    if (!(beta >= 0.0)) return NNF_ERR_ARG;
+    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    return NNF_OK;
+}
+
+extern "C" int nnf_mu_left_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
+                               int64_t ldu, const float* V, int64_t ldv, int r, double beta, float* Ut_out, int64_t lduo,
+                               void* stream) {
+    int rc = mu_args_ok(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, Ut_out);
+    if (rc != NNF_OK) return rc;
+    if (lduo < m) return NNF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    nnf_ws_cursor cur(ctx);
+    if (beta == 2.0) {  // U * (X V^T) / (U (V V^T))   (mu.py:89-91 reordered through the r x r Gram)
+        float* G = (float*)cur.take((size_t)r * r * 4);
+        float* num = (float*)cur.take((size_t)r * nnf_rup(m, 4) * 4);
+        if (!G || !num) return NNF_ERR_WORKSPACE;
+        if ((rc = nnf_gram_impl(ctx, cur, V, r, n, ldv, G, r, st)) != NNF_OK) return rc;
+        if ((rc = nnf_xht_impl(ctx, cur, X, m, n, ldx, V, r, ldv, num, nnf_rup(m, 4), st)) != NNF_OK) return rc;
+        int64_t fg = nnf_cdiv(m, 256);
+        if (fg > 2048) fg = 2048;
+        hipLaunchKernelGGL(nnf_mu2_finish_kernel, dim3((int)fg), dim3(256), 0, st, Ut, ldu, r, m, G, num, nnf_rup(m, 4),
+                           Ut_out, lduo);
+        NNF_CHECK_LAUNCH();
+        return NNF_OK;
+    }
+    MU_DISPATCH(launch_mu_left, ctx, cur, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, Ut_out, lduo, st);
+}
+
+extern "C" int nnf_mu_right_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
+                                int64_t ldu, const float* V, int64_t ldv, int r, double beta, float* V_out, int64_t ldvo,
+                                void* stream) {
+    int rc = mu_args_ok(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, V_out);
+    if (rc != NNF_OK) return rc;
+    if (ldvo < n) return NNF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    nnf_ws_cursor cur(ctx);
+    if (beta == 2.0) {  // V * (U^T X) / ((U^T U) V)
+        float* G = (float*)cur.take((size_t)r * r * 4);
+        float* num = (float*)cur.take((size_t)r * nnf_rup(n, 4) * 4);
+        if (!G || !num) return NNF_ERR_WORKSPACE;
+        if ((rc = nnf_gram_impl(ctx, cur, Ut, r, m, ldu, G, r, st)) != NNF_OK) return rc;
+        if ((rc = nnf_xty_impl(ctx, cur, X, m, n, ldx, Ut, r, ldu, num, nnf_rup(n, 4), st)) != NNF_OK) return rc;
+        int64_t fg = nnf_cdiv(n, 256);
+        if (fg > 2048) fg = 2048;
+        hipLaunchKernelGGL(nnf_mu2_finish_kernel, dim3((int)fg), dim3(256), 0, st, V, ldv, r, n, G, num, nnf_rup(n, 4),
+                           V_out, ldvo);
+        NNF_CHECK_LAUNCH();
+        return NNF_OK;
+    }
+    MU_DISPATCH(launch_mu_right, ctx, cur, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, V_out, ldvo, st);
+}

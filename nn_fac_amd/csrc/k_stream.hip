@@ -3,7 +3,7 @@
 //   xty : out[r x n] = Ut[r x m] * X[m x n]          ("W^T X",  nmf.py:433)   split over m, slab reduce
 //   xht : out[r x m] = V [r x n] * X[m x n]^T        ("X H^T",  nmf.py:408)
 //   gram: G  [r x r] = A [r x K] * A^T               (nmf.py:407,432; ntf.py:442-445)
-//   frob: sum (X - Ut^T V)^2                         (nmf.py:452) product never materialised
+//   cost: sum f(X, Ut^T V)                           (nmf.py:452,455; beta_divergence.py:45-52) product never materialised
 //
 // Common design
 //   * v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles/issue/SIMD; MI355X_MICROARCH "Matrix cores").  The 16-granular M tile
@@ -131,7 +131,7 @@ int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, 
 }
 
 template <int MT, bool VEC>
-static int launch_xty(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int r,
+static int launch_xty(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int r,
                       int64_t ldu, float* out, int64_t ldo, hipStream_t st) {
     const int ncb = (int)nnf_cdiv(n, 256);
     const int64_t ldp = nnf_rup(n, 4);
@@ -142,7 +142,7 @@ static int launch_xty(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_
     if (nsplit > max_split) nsplit = max_split;
     // workspace bound
     const int64_t slab_elems = (int64_t)r * ldp;
-    const int64_t ws_max = (int64_t)(ctx->ws_bytes / 4) / slab_elems;
+    const int64_t ws_max = (int64_t)(cur.remaining() / 4) / slab_elems;
     if (ws_max < 1) return NNF_ERR_WORKSPACE;
     if (nsplit > ws_max) nsplit = ws_max;
     int64_t rows_per_split = nnf_rup(nnf_cdiv(m, nsplit), 64);
@@ -153,7 +153,6 @@ static int launch_xty(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_
     }
     nsplit = nnf_cdiv(m, rows_per_split);
     if (nsplit > ws_max) return NNF_ERR_WORKSPACE;
-    nnf_ws_cursor cur(ctx);
     float* slabs = (float*)cur.take((size_t)nsplit * slab_elems * 4);
     if (!slabs) return NNF_ERR_WORKSPACE;
     const int a_vec_ok = ((((uintptr_t)Ut) & 15) == 0 && (ldu & 3) == 0) ? 1 : 0;
@@ -249,7 +248,7 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_xht_kernel(const f
 }
 
 template <int MT, bool VEC>
-static int launch_xht(nnf_ctx*, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r, int64_t ldv,
+static int launch_xht(nnf_ctx*, nnf_ws_cursor&, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r, int64_t ldv,
                       float* out, int64_t ldo, hipStream_t st) {
     if (64 * ldx * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
     const int a_vec_ok = ((((uintptr_t)V) & 15) == 0 && (ldv & 3) == 0) ? 1 : 0;
@@ -323,15 +322,15 @@ __global__ __launch_bounds__(256) void nnf_gram_kernel(const float* __restrict__
 }
 
 template <int MT>
-static int launch_gram(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
+static int launch_gram(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
                        hipStream_t st) {
-    int64_t nsplit = 2 * (int64_t)ctx->num_cus;
+    // few, long splits: the r x r slab reduction is serial in the split count and the operand is only r*K*4 bytes
+    int64_t nsplit = ctx->num_cus / 4 > 8 ? ctx->num_cus / 4 : 8;
     const int64_t max_split = nnf_cdiv(K, 64);
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
     const int64_t kps = nnf_rup(nnf_cdiv(K, nsplit), 64);
     nsplit = nnf_cdiv(K, kps);
-    nnf_ws_cursor cur(ctx);
     float* slabs = (float*)cur.take((size_t)nsplit * r * r * 4);
     if (!slabs) return NNF_ERR_WORKSPACE;
     const int a_vec_ok = ((((uintptr_t)A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
@@ -348,11 +347,11 @@ static int launch_gram(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t l
 //   which is exactly what a lane's float4 load of X[row][j0+4jj..+3] holds.
 //   The rank loop is a run-time loop (both operands come from LDS), so one kernel serves every r <= 128.
 // =========================================================================================================
-template <bool VEC>
-__global__ __launch_bounds__(256, 2) void nnf_frob_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+template <int OP, bool VEC>
+__global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                           const float* __restrict__ Ut, int64_t ldu,
                                                           const float* __restrict__ V, int64_t ldv, int r,
-                                                          double* __restrict__ partial) {
+                                                          float beta, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KS = (r + 3) >> 2;                               // k-steps of 4
     float* ldsU = reinterpret_cast<float*>(smem);              // [wave 4][rt 2][KS][64]
@@ -427,12 +426,13 @@ __global__ __launch_bounds__(256, 2) void nnf_frob_kernel(const float* __restric
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
+            for (int reg = 0; reg < 4; ++reg) {
+                if (16 * rt + 4 * g + reg >= rows) continue;   // rows past the end of the matrix
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
-                    const float d = (cc < jrem) ? (xb[rt][reg][cc] - acc[rt][cc][reg]) : 0.f;
-                    loc = fmaf(d, d, loc);
+                    if (cc < jrem) loc += nnf_cost_term<OP>(xb[rt][reg][cc], acc[rt][cc][reg], beta);
                 }
+            }
         dsum += (double)loc;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -447,12 +447,12 @@ __global__ __launch_bounds__(256, 2) void nnf_frob_kernel(const float* __restric
 
 // sum of `count` doubles in index order by one workgroup -> out[0]
 __global__ __launch_bounds__(256) void nnf_sum_partials_kernel(const double* __restrict__ partial, int64_t count,
-                                                               double* __restrict__ out) {
+                                                               double scale, double* __restrict__ out) {
     __shared__ double red[4];
     double s = 0.0;
     for (int64_t e = threadIdx.x; e < count; e += 256) s += partial[e];
     const double t = nnf_block_sum_f64(s, red);
-    if (threadIdx.x == 0) out[0] = t;
+    if (threadIdx.x == 0) out[0] = t * scale;
 }
 
 
@@ -468,56 +468,67 @@ __global__ __launch_bounds__(256) void nnf_sum_partials_kernel(const double* __r
         default: return FN<8, VEC>(__VA_ARGS__);          \
     }
 
-extern "C" int nnf_xty_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int r,
-                           int64_t ldu, float* out, int64_t ldo, void* stream) {
+int nnf_xty_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
+                 int r, int64_t ldu, float* out, int64_t ldo, hipStream_t st) {
     if (!ctx || !X || !Ut || !out || m < 1 || n < 1 || r < 1 || ldx < n || ldu < m || ldo < n) return NNF_ERR_ARG;
     if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
     const int MT = (r + 15) / 16;
     if (x_vec_ok(X, ldx)) {
-        DISPATCH_MT(launch_xty, true, ctx, X, m, n, ldx, Ut, r, ldu, out, ldo, st)
+        DISPATCH_MT(launch_xty, true, ctx, cur, X, m, n, ldx, Ut, r, ldu, out, ldo, st)
     } else {
-        DISPATCH_MT(launch_xty, false, ctx, X, m, n, ldx, Ut, r, ldu, out, ldo, st)
+        DISPATCH_MT(launch_xty, false, ctx, cur, X, m, n, ldx, Ut, r, ldu, out, ldo, st)
     }
 }
+extern "C" int nnf_xty_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int r,
+                           int64_t ldu, float* out, int64_t ldo, void* stream) {
+    if (!ctx) return NNF_ERR_ARG;
+    nnf_ws_cursor cur(ctx);
+    return nnf_xty_impl(ctx, cur, X, m, n, ldx, Ut, r, ldu, out, ldo, (hipStream_t)stream);
+}
 
-extern "C" int nnf_xht_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r,
-                           int64_t ldv, float* out, int64_t ldo, void* stream) {
+int nnf_xht_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V,
+                 int r, int64_t ldv, float* out, int64_t ldo, hipStream_t st) {
     if (!ctx || !X || !V || !out || m < 1 || n < 1 || r < 1 || ldx < n || ldv < n || ldo < m) return NNF_ERR_ARG;
     if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
     const int MT = (r + 15) / 16;
     if (x_vec_ok(X, ldx)) {
-        DISPATCH_MT(launch_xht, true, ctx, X, m, n, ldx, V, r, ldv, out, ldo, st)
+        DISPATCH_MT(launch_xht, true, ctx, cur, X, m, n, ldx, V, r, ldv, out, ldo, st)
     } else {
-        DISPATCH_MT(launch_xht, false, ctx, X, m, n, ldx, V, r, ldv, out, ldo, st)
+        DISPATCH_MT(launch_xht, false, ctx, cur, X, m, n, ldx, V, r, ldv, out, ldo, st)
     }
 }
+extern "C" int nnf_xht_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r,
+                           int64_t ldv, float* out, int64_t ldo, void* stream) {
+    if (!ctx) return NNF_ERR_ARG;
+    nnf_ws_cursor cur(ctx);
+    return nnf_xht_impl(ctx, cur, X, m, n, ldx, V, r, ldv, out, ldo, (hipStream_t)stream);
+}
 
-extern "C" int nnf_gram_f32(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
-                            void* stream) {
+int nnf_gram_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
+                  hipStream_t st) {
     if (!ctx || !A || !G || r < 1 || K < 1 || lda < K || ldg < r) return NNF_ERR_ARG;
     if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
     switch ((r + 15) / 16) {
-        case 1: return launch_gram<1>(ctx, A, r, K, lda, G, ldg, st);
-        case 2: return launch_gram<2>(ctx, A, r, K, lda, G, ldg, st);
-        case 3: return launch_gram<3>(ctx, A, r, K, lda, G, ldg, st);
-        case 4: return launch_gram<4>(ctx, A, r, K, lda, G, ldg, st);
-        case 5: return launch_gram<5>(ctx, A, r, K, lda, G, ldg, st);
-        case 6: return launch_gram<6>(ctx, A, r, K, lda, G, ldg, st);
-        case 7: return launch_gram<7>(ctx, A, r, K, lda, G, ldg, st);
-        default: return launch_gram<8>(ctx, A, r, K, lda, G, ldg, st);
+        case 1: return launch_gram<1>(ctx, cur, A, r, K, lda, G, ldg, st);
+        case 2: return launch_gram<2>(ctx, cur, A, r, K, lda, G, ldg, st);
+        case 3: return launch_gram<3>(ctx, cur, A, r, K, lda, G, ldg, st);
+        case 4: return launch_gram<4>(ctx, cur, A, r, K, lda, G, ldg, st);
+        case 5: return launch_gram<5>(ctx, cur, A, r, K, lda, G, ldg, st);
+        case 6: return launch_gram<6>(ctx, cur, A, r, K, lda, G, ldg, st);
+        case 7: return launch_gram<7>(ctx, cur, A, r, K, lda, G, ldg, st);
+        default: return launch_gram<8>(ctx, cur, A, r, K, lda, G, ldg, st);
     }
 }
+extern "C" int nnf_gram_f32(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
+                            void* stream) {
+    if (!ctx) return NNF_ERR_ARG;
+    nnf_ws_cursor cur(ctx);
+    return nnf_gram_impl(ctx, cur, A, r, K, lda, G, ldg, (hipStream_t)stream);
+}
 
-extern "C" int nnf_frob_resid_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
-                                  int64_t ldu, const float* V, int64_t ldv, int r, double* out_f64, void* stream) {
-    if (!ctx || !X || !Ut || !V || !out_f64 || m < 1 || n < 1 || r < 1 || ldx < n || ldu < m || ldv < n)
-        return NNF_ERR_ARG;
-    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
-    if (32 * ldx * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
+template <int OP>
+static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                       const float* V, int64_t ldv, int r, float beta, double scale, double* out_f64, hipStream_t st) {
     const int grid = (int)nnf_cdiv(m, 128);
     nnf_ws_cursor cur(ctx);
     double* partial = (double*)cur.take((size_t)grid * 8);
@@ -525,17 +536,48 @@ extern "C" int nnf_frob_resid_f32(nnf_ctx* ctx, const float* X, int64_t m, int64
     const int KS = (r + 3) / 4;
     const size_t shm = (size_t)4 * 2 * KS * 64 * 4 + (size_t)2 * KS * 64 * 16 + 64;
     if (shm > 48 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_frob_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_frob_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_cost_kernel<OP, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_cost_kernel<OP, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     }
     if (x_vec_ok(X, ldx))
-        hipLaunchKernelGGL((nnf_frob_kernel<true>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
-                           partial);
+        hipLaunchKernelGGL((nnf_cost_kernel<OP, true>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
+                           beta, partial);
     else
-        hipLaunchKernelGGL((nnf_frob_kernel<false>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
-                           partial);
+        hipLaunchKernelGGL((nnf_cost_kernel<OP, false>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
+                           beta, partial);
     NNF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nnf_sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)grid, out_f64);
+    hipLaunchKernelGGL(nnf_sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)grid, scale, out_f64);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
+}
+
+static int cost_args_ok(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                        const float* V, int64_t ldv, int r, double* out) {
+    if (!ctx || !X || !Ut || !V || !out || m < 1 || n < 1 || r < 1 || ldx < n || ldu < m || ldv < n) return NNF_ERR_ARG;
+    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    if (32 * ldx * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
+    return NNF_OK;
+}
+
+extern "C" int nnf_frob_resid_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
+                                  int64_t ldu, const float* V, int64_t ldv, int r, double* out_f64, void* stream) {
+    const int rc = cost_args_ok(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, out_f64);
+    if (rc != NNF_OK) return rc;
+    return launch_cost<NNF_COST_FROB>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 2.f, 1.0, out_f64, (hipStream_t)stream);
+}
+
+extern "C" int nnf_betadiv_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
+                               int64_t ldu, const float* V, int64_t ldv, int r, double beta, double* out_f64,
+                               void* stream) {
+    const int rc = cost_args_ok(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, out_f64);
+    if (rc != NNF_OK) return rc;
+    if (!(beta >= 0.0)) return NNF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (beta == 2.0)  // 1/2 ||X - UV||^2  (beta_divergence.py:51-52 with beta = 2)
+        return launch_cost<NNF_COST_FROB>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 2.f, 0.5, out_f64, st);
+    if (beta == 1.0) return launch_cost<NNF_COST_KL>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 1.f, 1.0, out_f64, st);
+    if (beta == 0.0) return launch_cost<NNF_COST_IS>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 0.f, 1.0, out_f64, st);
+    return launch_cost<NNF_COST_GEN>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, (float)beta, 1.0, out_f64, st);
 }

@@ -61,3 +61,48 @@ __device__ __forceinline__ void stageA_store(f32x4* __restrict__ img, const f32x
 
 
 static inline bool x_vec_ok(const float* X, int64_t ldx) { return (((uintptr_t)X) & 15) == 0 && (ldx & 3) == 0; }
+
+// ---------------------------------------------------------------------------------------------------------
+// Element-wise terms of the cost functions (beta_divergence.py:45-52), written so that fp32 does not cancel:
+//   h(t) = t - log1p(t)   (series below 1/4)
+//   KL  : x log(x/p) - x + p = x h((p-x)/x)            (x = 0 -> p)
+//   IS  : x/p - log(x/p) - 1 = h((x-p)/p)
+//   gen : (x^b + (b-1) p^b - b x p^(b-1)) / (b(b-1)) = p^b phi((x-p)/p),
+//         phi(u) = ((1+u)^b - 1 - b u)/(b(b-1))        (binomial series below 1/10)
+// Inputs must be strictly positive for the divergences, as in the reference.
+// ---------------------------------------------------------------------------------------------------------
+enum { NNF_COST_FROB = 0, NNF_COST_KL = 1, NNF_COST_IS = 2, NNF_COST_GEN = 3 };
+
+__device__ __forceinline__ float nnf_h(float t) {
+    if (fabsf(t) < 0.25f) {
+        float s = 1.f / 14.f;
+#pragma unroll
+        for (int k = 11; k >= 0; --k) s = fmaf(s, -t, 1.f / (float)(k + 2));
+        return t * t * s;
+    }
+    return t - log1pf(t);
+}
+
+template <int OP>
+__device__ __forceinline__ float nnf_cost_term(float x, float p, float beta) {
+    if constexpr (OP == NNF_COST_FROB) {
+        const float d = x - p;
+        return d * d;
+    } else if constexpr (OP == NNF_COST_KL) {
+        return x > 0.f ? x * nnf_h((p - x) / x) : p;
+    } else if constexpr (OP == NNF_COST_IS) {
+        return nnf_h((x - p) / p);
+    } else {
+        const float u = (x - p) / p;
+        float phi;
+        if (fabsf(u) < 0.1f) {
+            float s = 1.f;
+#pragma unroll
+            for (int k = 8; k >= 3; --k) s = fmaf(s, (beta - (float)(k - 1)) * u / (float)k, 1.f);
+            phi = 0.5f * u * u * s;
+        } else {
+            phi = (powf(1.f + u, beta) - 1.f - beta * u) / (beta * (beta - 1.f));
+        }
+        return powf(p, beta) * phi;
+    }
+}

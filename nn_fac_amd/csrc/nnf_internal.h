@@ -32,6 +32,10 @@ struct nnf_ws_cursor {
         off = a + bytes;
         return base + a;
     }
+    __host__ size_t remaining() const {
+        const size_t a = (off + 255) & ~size_t(255);
+        return a < cap ? cap - a : 0;
+    }
 };
 
 // ---- device helpers -------------------------------------------------------------------------------------
@@ -68,3 +72,10 @@ __device__ __forceinline__ void nnf_xcd_map(int bid, int members, int& group, in
 // kernels / launchers implemented in the .hip files
 int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, int rows, int64_t cols, int64_t lds,
                             float* out, int64_t ldo, hipStream_t st);
+
+int nnf_xty_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
+                 int r, int64_t ldu, float* out, int64_t ldo, hipStream_t st);
+int nnf_xht_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V,
+                 int r, int64_t ldv, float* out, int64_t ldo, hipStream_t st);
+int nnf_gram_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
+                  hipStream_t st);

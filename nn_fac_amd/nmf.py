@@ -26,6 +26,7 @@ from .utils import errors as err
 from .utils import initialize_factors as init_factors
 from . import engine as _engine
 from ._convert import device_of, to_dev, to_dev_t, like_input
+from . import dist as _dist
 
 
 def nmf(data, rank, init="random", U_0=None, V_0=None, n_iter_max=100, tol=1e-8,
@@ -138,6 +139,7 @@ class _StepBuffers:
         # one block read back per iteration: HALS status of the first / second solve at [0:8] / [8:16], cost at [16]
         self.block = torch.zeros(24, dtype=torch.float64, device=X.device)
         self.cost = self.block[16:17]
+        self.guess_u = _dist.SweepGuess()
 
 
 def _raise_on_status(host, nstat):
@@ -168,9 +170,14 @@ def _hals_call(eng, cross, gram, F, sparsity, normalize, deterministic, timer, s
 
 
 def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
-                      deterministic):
+                      deterministic, group=None):
     """Device-resident step.  Ut_in (r x m) and V_in (r x n) are not modified.  Returns the new factors and the number
-    of HALS solves run; the cost and the solves' status words are left in ws.block (read back by the caller)."""
+    of HALS solves run; the cost and the solves' status words are left in ws.block (read back by the caller).
+    With `group` (torch.distributed process group) X / Ut are this rank's row block and V is replicated (dist.py)."""
+    sharded = _dist.world(group) > 1
+    if sharded:
+        if update_rule != "hals" or not deterministic or normalize[0]:
+            raise NotImplementedError("row-sharded runs support deterministic HALS without U normalisation")
     if update_rule not in ["hals", "mu"]:
         raise err.InvalidArgumentValue(f"Invalid update rule: {update_rule}") from None
     if update_rule == "hals" and beta != 2:
@@ -194,8 +201,13 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                 torch.cuda.synchronize(dev)
                 timer = time.time() - t0
             Ut = Ut_in.clone()                          # solve starts from U_in^T (nmf.py:415)
-            _hals_call(eng, ws.VMt, ws.G, Ut, sparsity_coefficients[0], normalize[0], deterministic, timer,
-                       ws.block[8 * nstat:8 * nstat + 8])
+            if sharded:
+                eps, cnt, eps0 = _dist.sharded_hals_solve(eng, ws.VMt, ws.G, Ut, group, ws.guess_u, budget=100,
+                                                          delta=0.01, sparsity=sparsity_coefficients[0])
+                ws.block[8 * nstat:8 * nstat + 4] = torch.tensor([eps, cnt, eps0, 0.0], dtype=torch.float64)
+            else:
+                _hals_call(eng, ws.VMt, ws.G, Ut, sparsity_coefficients[0], normalize[0], deterministic, timer,
+                           ws.block[8 * nstat:8 * nstat + 8])
             nstat += 1
         else:
             Ut = eng.mu_left(X, Ut_in, V, beta)         # nmf.py:422
@@ -208,6 +220,9 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                 t0 = time.time()
             eng.gram(Ut, out=ws.G2)                     # UtU  (nmf.py:432)
             eng.xty(X, Ut, out=ws.UtM)                  # UtM  (nmf.py:433)
+            if sharded:                                 # sum over the row blocks: r x r and r x n over xGMI
+                _dist.allreduce_(ws.G2, group)
+                _dist.allreduce_(ws.UtM, group)
             if not deterministic:
                 torch.cuda.synchronize(dev)
                 timer = time.time() - t0
@@ -221,9 +236,14 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
     sp = [0 if s is None else s for s in sparsity_coefficients]
     if update_rule == "hals":
         eng.frob_resid(X, Ut, V, out=ws.cost)                     # nmf.py:452
+        if sharded:
+            _dist.allreduce_(ws.cost, group)
         if sp[0] or sp[1]:
             # matrix 1-norm (max column abs-sum, np.linalg.norm(., ord=1)) -- NOT the entry-wise l1 (nmf.py:452)
-            nU = Ut.abs().sum(dim=1).max().double()   # columns of U are rows of Ut
+            cs = Ut.abs().sum(dim=1).double()         # columns of U are rows of Ut
+            if sharded:
+                _dist.allreduce_(cs, group)
+            nU = cs.max()
             nV = V.abs().sum(dim=0).max().double()
             ws.cost.add_(2 * (sp[0] * nU + sp[1] * nV))
     else:

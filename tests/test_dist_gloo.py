@@ -1,0 +1,133 @@
+"""Row-sharded NMF step over torch.distributed, world_size 2, gloo on CPU.
+
+The HIP engine cannot run here, so the per-rank compute is a TEST DOUBLE backed by the CPU oracle (NumPy, fp64):
+what is under test is the host logic of nn_fac_amd/dist.py + nn_fac_amd/nmf.py -- the row partition, the all-reduce
+of the Gram / cross terms / cost, and the chunk-and-replay protocol for the global HALS stopping rule -- which must
+reproduce the unsharded oracle exactly (same sweep counts, same factors to fp64 round-off).
+"""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import nnfac_oracle as orc
+
+
+class OracleEngine:
+    """Engine double: same method names / in-place semantics as nn_fac_amd.engine.Engine, fp64 CPU tensors."""
+
+    def gram(self, A, out=None):
+        G = A @ A.T
+        return G if out is None else out.copy_(G)
+
+    def xht(self, X, V, out=None):
+        O = V @ X.T
+        return O if out is None else out.copy_(O)
+
+    def xty(self, X, Ut, out=None):
+        O = Ut @ X
+        return O if out is None else out.copy_(O)
+
+    def frob_resid(self, X, Ut, V, out=None):
+        c = torch.sum((X - Ut.T @ V) ** 2).reshape(1)
+        return c if out is None else out.copy_(c)
+
+    def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False):
+        log = []
+        Vn, *_ = orc.hals_nnls_acc(UtM.numpy(), UtU.numpy(), V.numpy(), maxiter=nsweeps, alpha=math.inf, delta=0.0,
+                                   sparsity_coefficient=sparsity, sweep_log=log)
+        V.copy_(torch.from_numpy(Vn))
+        return torch.tensor(log, dtype=torch.float64)
+
+    def hals_solve(self, UtM, UtU, V, max_sweeps, delta=0.01, sparsity=None, normalize=False, nonzero=False,
+                   status=None):
+        Vn, eps, cnt, _ = orc.hals_nnls_acc(UtM.numpy(), UtU.numpy(), V.numpy(), maxiter=max_sweeps, alpha=math.inf,
+                                            delta=delta, sparsity_coefficient=sparsity, normalize=normalize)
+        V.copy_(torch.from_numpy(Vn))
+        st = status if status is not None else torch.zeros(8, dtype=torch.float64)
+        st[0], st[1], st[3] = eps, cnt, 0.0
+        return st
+
+
+class _Bufs:
+    def __init__(self, X, r):
+        from nn_fac_amd import dist as nd
+        m, n = X.shape
+        kw = dict(dtype=torch.float64)
+        self.VMt, self.UtM = torch.empty((r, m), **kw), torch.empty((r, n), **kw)
+        self.G, self.G2 = torch.empty((r, r), **kw), torch.empty((r, r), **kw)
+        self.block = torch.zeros(24, **kw)
+        self.cost = self.block[16:17]
+        self.guess_u = nd.SweepGuess(first=3)     # small on purpose: exercises continue, exact-stop and replay
+
+
+def _worker(rank, nranks, port, m, n, r, iters, sparsity, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=nranks)
+    try:
+        from nn_fac_amd import nmf as nmf_mod, dist as nd
+        X, U0, V0 = orc.synth_nmf(m, n, r, seed=1, dtype=np.float64)
+        lo, hi = nd.shard_rows(m, rank, nranks)
+        Xl = torch.from_numpy(X[lo:hi].copy())
+        Ut = torch.from_numpy(U0[lo:hi].T.copy())
+        V = torch.from_numpy(V0.copy())
+        eng, ws = OracleEngine(), _Bufs(Xl, r)
+        costs, sweeps = [], []
+        for _ in range(iters):
+            Ut, V, nstat = nmf_mod._one_nmf_step_dev(eng, ws, Xl, r, Ut, V, "hals", 2, sparsity, [], [False, False],
+                                                     True, group=dist.group.WORLD)
+            costs.append(float(ws.block[16]))
+            sweeps += [int(ws.block[8 * i + 1]) - 1 for i in range(nstat)]
+        q.put((rank, lo, hi, Ut.numpy().T.copy(), V.numpy().copy(), costs, sweeps))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("sparsity", [[None, None], [0.05, 0.02]])
+def test_row_sharded_step_equals_unsharded_oracle(sparsity):
+    m, n, r, iters, nranks = 301, 40, 6, 4, 2          # odd m: unequal shards
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(k, nranks, port, m, n, r, iters, sparsity, q)) for k in range(nranks)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(nranks))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    X, U0, V0 = orc.synth_nmf(m, n, r, seed=1, dtype=np.float64)
+    sw = []
+    U, V, costs, _ = orc.compute_nmf(X, r, U0, V0, n_iter_max=iters, tol=0, update_rule="hals",
+                                     sparsity_coefficients=list(sparsity), return_costs=True, deterministic=True,
+                                     sweeps=sw)
+    Ucat = np.concatenate([x[3] for x in res], axis=0)
+    np.testing.assert_allclose(Ucat, U, rtol=1e-9, atol=1e-12)
+    for rank, lo, hi, Ul, Vl, cl, sl in res:
+        np.testing.assert_allclose(Vl, V, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(cl, costs, rtol=1e-9)
+        assert sl == sw                                   # identical inner sweep counts on every rank
+    assert np.array_equal(res[0][4], res[1][4])           # replicated V bitwise identical across ranks
+
+
+def test_shard_rows_partition():
+    from nn_fac_amd.dist import shard_rows
+    for m, k in ((10, 3), (100000, 8), (7, 8), (301, 2)):
+        edges = [shard_rows(m, i, k) for i in range(k)]
+        assert edges[0][0] == 0 and edges[-1][1] == m
+        assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+        sizes = [hi - lo for lo, hi in edges]
+        assert max(sizes) - min(sizes) <= 1

@@ -181,3 +181,54 @@ def test_hals_fixed_sweeps_mode(eng):
     nd = eng.hals_sweeps(dev(UtM), dev(UtU), Vd, 6).cpu().numpy()
     assert rel(Vd.cpu().numpy(), Vo) < 1e-4
     np.testing.assert_allclose(nd, log, rtol=5e-3)
+
+
+MU_SHAPES = [(200, 100, 10), (73, 25, 9), (1000, 260, 50), (513, 130, 33), (300, 7, 3), (5, 300, 2), (2000, 500, 64)]
+
+
+@pytest.mark.parametrize("m,n,r", MU_SHAPES)
+@pytest.mark.parametrize("beta", [0, 0.5, 1, 1.5, 2, 3, 4])
+def test_mu_and_betadiv_kernels(eng, m, n, r, beta):
+    rng = np.random.RandomState(m + n + r)
+    U = rng.rand(m, r) + 0.05
+    V = rng.rand(r, n) + 0.05
+    X = rng.rand(m, r) @ rng.rand(r, n) + 0.05
+    Xd, Utd, Vd = dev(X), dev(U.T), dev(V)
+    X32, U32, V32 = (a.astype(np.float32).astype(np.float64) for a in (X, U, V))
+    wantU = orc.mu_betadivmin(U32, V32, X32, beta)
+    wantV = orc.switch_alternate_mu(X32, U32, V32, beta, "V")
+    assert rel(eng.mu_left(Xd, Utd, Vd, beta).cpu().numpy().T, wantU) < 2e-5
+    assert rel(eng.mu_right(Xd, Utd, Vd, beta).cpu().numpy(), wantV) < 2e-5
+    want = orc.beta_divergence(X32, U32 @ V32, beta)
+    got = float(eng.betadiv(Xd, Utd, Vd, beta))
+    assert abs(got - want) <= 2e-5 * abs(want)
+
+
+def test_betadiv_near_convergence_has_no_cancellation(eng):
+    """K ~ X: the naive fp32 form of KL/IS loses everything; the h(t) = t - log1p(t) form does not."""
+    rng = np.random.RandomState(4)
+    m, n, r = 400, 300, 8
+    U, V = rng.rand(m, r) + 0.1, rng.rand(r, n) + 0.1
+    U32, V32 = U.astype(np.float32).astype(np.float64), V.astype(np.float32).astype(np.float64)
+    X = (U32 @ V32) * (1 + 1e-3 * rng.randn(m, n))
+    X32 = X.astype(np.float32).astype(np.float64)
+    for beta in (0, 1, 1.5, 3):
+        want = orc.beta_divergence(X32, U32 @ V32, beta)
+        got = float(eng.betadiv(dev(X32), dev(U32.T), dev(V32), beta))
+        assert abs(got - want) <= 2e-3 * want, (beta, got, want)
+
+
+def test_mu_dropin_signatures(golden):
+    from nn_fac_amd.update_rules.mu import mu_betadivmin, switch_alternate_mu
+    from nn_fac_amd.utils.beta_divergence import beta_divergence, gamma_beta
+    g = golden("g2_mu.npz")
+    U, V, M = g["U"], g["V"], g["M"]
+    for b in (0, 0.5, 1, 1.5, 2, 3, 4):
+        b = int(b) if float(b).is_integer() else b
+        gotU = switch_alternate_mu(M, U, V, b, "U")
+        gotV = switch_alternate_mu(M, U, V, b, "H")
+        assert isinstance(gotU, np.ndarray) and gotU.shape == U.shape and gotV.shape == V.shape
+        assert rel(gotU, g[f"muU_b{b}"]) < 2e-5 and rel(gotV, g[f"muV_b{b}"]) < 2e-5
+        assert rel(mu_betadivmin(U, V, M, b), g[f"muU_b{b}"]) < 2e-5
+        assert abs(beta_divergence(M, U @ V, b) - float(g[f"div_b{b}"])) <= 1e-5 * abs(float(g[f"div_b{b}"]))
+        assert gamma_beta(b) == float(g[f"gamma_b{b}"])

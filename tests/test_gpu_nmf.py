@@ -30,7 +30,12 @@ def test_reference_known_answers_hals(golden, built_lib):
     assert abs(U[0][0] - u00) < 2e-4 and abs(V[0][0] - v00) < 2e-4
     assert abs(costs[0] - c0) <= HALS_COST * c0 and abs(costs[-1] - c1) <= HALS_COST * c1
     assert rel(U, g["U_hals_b2_s0"]) < HALS_FRO and rel(V, g["V_hals_b2_s0"]) < HALS_FRO
-    assert len(costs) == len(g["costs_hals_b2_s0"]) == len(toc)
+    # tol=1e-8 on a cost of 8.8e-3 is below the fp32 noise of the residual (~1e-6 relative), so the early-stop
+    # index may differ by one from the fp64 reference (which ran 6 iterations); the reference test does not pin it
+    ref = g["costs_hals_b2_s0"]
+    assert len(costs) == len(toc) and abs(len(costs) - len(ref)) <= 1
+    k = min(len(costs), len(ref))
+    np.testing.assert_allclose(costs[:k], ref[:k], rtol=HALS_COST)
 
 
 def test_config_a_hals(golden, built_lib):
@@ -105,3 +110,47 @@ def test_non_deterministic_mode_runs(built_lib):
 def test_smoke_entry(built_lib):
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+# ---- multiplicative updates: stated fp32 tolerance rel_fro <= 2e-5, cost rel <= 1e-5 ----------
+MU_FRO, MU_COST = 2e-5, 1e-5
+
+
+@pytest.mark.parametrize("rule_beta_seed", [("mu", 2, 82), ("mu", 1, 82), ("mu", 0, 82)])
+def test_reference_known_answers_mu(golden, built_lib, rule_beta_seed):
+    """tests/NMF_tests.py:83-135 of the reference."""
+    from nn_fac_amd.nmf import nmf
+    rule, beta, seed = rule_beta_seed
+    g = golden("g0_known_answers.npz")
+    data, rank = g["data"], int(g["rank"])
+    U, V, costs, toc = nmf(data, rank, init="random", U_0=None, V_0=None, n_iter_max=10, tol=1e-8,
+                           update_rule=rule, beta=beta, sparsity_coefficients=[None, None], fixed_modes=[],
+                           normalize=[False, False], verbose=False, return_costs=True, deterministic=True, seed=seed)
+    tag = f"{rule}_b{beta}_s{seed}"
+    u00, v00, c0, c1 = g[f"known_{tag}"]
+    assert abs(U[0][0] - u00) < 1e-5 and abs(V[0][0] - v00) < 1e-5
+    assert abs(costs[0] - c0) <= 2e-5 * c0 and abs(costs[-1] - c1) <= 2e-5 * c1
+    assert rel(U, g[f"U_{tag}"]) < MU_FRO and rel(V, g[f"V_{tag}"]) < MU_FRO
+    np.testing.assert_allclose(costs, g[f"costs_{tag}"], rtol=2e-5)
+
+
+@pytest.mark.parametrize("beta", [2, 1, 0, 1.5, 3])
+def test_config_a_mu(golden, built_lib, beta):
+    from nn_fac_amd.nmf import compute_nmf
+    g = golden("g4_nmf_configA.npz")
+    X, U0, V0 = g["X"], g["U0"], g["V0"]
+    U, V, costs, _ = compute_nmf(X, 10, U0, V0, n_iter_max=10, tol=0, update_rule="mu", beta=beta,
+                                 return_costs=True, deterministic=True)
+    k = f"mu_b{beta}_f64"
+    assert rel(U, g[f"U_{k}"]) < 5e-5 and rel(V, g[f"V_{k}"]) < 5e-5
+    np.testing.assert_allclose(costs, g[f"costs_{k}"], rtol=5e-5)
+
+
+def test_mid_size_mu_kl(golden, built_lib):
+    from nn_fac_amd.nmf import compute_nmf
+    g = golden("g5_nmf_mid.npz")
+    X, U0, V0 = orc.synth_nmf(2000, 500, 50, seed=3, dtype=np.float32)
+    U, V, costs, _ = compute_nmf(X, 50, U0, V0, n_iter_max=5, tol=0, update_rule="mu", beta=1, return_costs=True,
+                                 deterministic=True)
+    assert rel(U[::16], g["U_mu_b1"]) < 5e-5 and rel(V[:, ::4], g["V_mu_b1"]) < 5e-5
+    np.testing.assert_allclose(costs, g["costs_mu_b1"], rtol=1e-4)

@@ -121,6 +121,12 @@ int nnf_mttkrp3_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t 
                     const float* Ft1, int64_t ld1, const float* Ft2, int64_t ld2, int R, int mode, float* out,
                     int64_t ldo, void* stream);
 
+/* beta_divergence(T, [[F0,F1,F2]], beta) for a dense 3-way tensor and its CP model (factors transposed, R x dim): the cost
+ * of ntf.py:470 (HALS: 2x the beta=2 value = ||T - model||^2) and ntf.py:473 (MU), Khatri-Rao operand generated on the fly. */
+int nnf_cp3_betadiv_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t K, const float* Ft0, int64_t ld0,
+                        const float* Ft1, int64_t ld1, const float* Ft2, int64_t ld2, int R, double beta, double* out_f64,
+                        void* stream);
+
 /* small helpers used by the drivers (all deterministic, fixed-order) */
 /* *out_f64 = sum_ij A[i,j]*B[i,j]   (fp64 accumulate)  -- inner products of ntf.py:470 */
 int nnf_dot_f32(nnf_ctx* ctx, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int64_t cols,

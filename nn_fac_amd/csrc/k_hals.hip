@@ -19,8 +19,9 @@
 // prep: padded Gram, 1/diag, zeroed barrier words and status
 __global__ void nnf_hals_prep_kernel(const float* __restrict__ UtU, int64_t ldg, int r, int RP, float* __restrict__ Gp,
                                      float* __restrict__ dinv, unsigned* counter, double* status) {
-    for (int e = threadIdx.x; e < RP * RP; e += blockDim.x) {
-        const int a = e / RP, b = e - a * RP;
+    const int RS = 32 * ((RP + 31) / 32);      // row stride of the padded Gram (32-float blocks, k_hals_fast.hip)
+    for (int e = threadIdx.x; e < RP * RS; e += blockDim.x) {
+        const int a = e / RS, b = e - a * RS;
         Gp[e] = (a < r && b < r) ? UtU[(int64_t)a * ldg + b] : 0.f;
     }
     for (int k = threadIdx.x; k < RP; k += blockDim.x) {
@@ -173,24 +174,29 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
         return NNF_ERR_ARG;
     if (MODE == 0 && !status) return NNF_ERR_ARG;
     if (MODE == 1 && !nodelta_out && nsweeps > 0) return NNF_ERR_ARG;
-    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    if (r > NNF_MAX_RANK || nsweeps > 1000) return NNF_ERR_UNSUPPORTED;   // exchange tags hold the sweep index in 10 bits
     if (flags & ~(NNF_HALS_SPARSITY | NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) return NNF_ERR_ARG;
     const int RP = pick_rp(r);
     const float sp = (flags & NNF_HALS_SPARSITY) ? sparsity : 0.f;
     const int max_blocks = 3 * ctx->num_cus > 2048 ? 3 * ctx->num_cus : 2048;
     nnf_ws_cursor cur(ctx);
-    float* Gp = (float*)cur.take((size_t)RP * RP * 4);
-    float* dinv = (float*)cur.take((size_t)RP * 4);
+    const int RS = 32 * ((RP + 31) / 32);
+    float* Gp = (float*)cur.take((size_t)(RP * RS + RP) * 4);   // padded Gram immediately followed by 1/diag
+    float* dinv = Gp ? Gp + (size_t)RP * RS : nullptr;
     unsigned* counter = (unsigned*)cur.take(256);
     double* slots = (double*)cur.take((size_t)2 * max_blocks * 4 * 8);
+    double* sslots = (MODE == 0) ? (double*)cur.take((size_t)(nsweeps + 2) * max_blocks * 16) : slots;
     double* sweep_partials = nullptr;
     if (MODE == 1) sweep_partials = (double*)cur.take((size_t)(nsweeps > 0 ? nsweeps : 1) * max_blocks * 8);
-    if (!Gp || !dinv || !counter || !slots || (MODE == 1 && !sweep_partials)) return NNF_ERR_WORKSPACE;
+    if (!Gp || !dinv || !counter || !slots || !sslots || (MODE == 1 && !sweep_partials))
+        return NNF_ERR_WORKSPACE;
     hipLaunchKernelGGL(nnf_hals_prep_kernel, dim3(1), dim3(256), 0, st, UtU, ldg, r, RP, Gp, dinv, counter,
                        MODE == 0 ? status : (double*)nullptr);
     NNF_CHECK_LAUNCH();
     if (nsweeps == 0) return NNF_OK;
-    hals_sync sy{counter, slots};
+    ctx->hals_epoch = (ctx->hals_epoch + 1u) & 0x3fffffu;   // tag = epoch*1024 + sweep stays below 2^32
+    if (ctx->hals_epoch == 0u) ctx->hals_epoch = 1u;
+    hals_sync sy{counter, slots, sslots, ctx->hals_epoch};
     int nblocks = 0, rc = NNF_OK;
     const bool generic = (flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) != 0;
     if (generic) {
@@ -207,7 +213,7 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
         const int64_t grid = nnf_cdiv(ncols, 128);
         if (grid > (int64_t)bpc * ctx->num_cus || grid > max_blocks) return NNF_ERR_UNSUPPORTED;
         nblocks = (int)grid;
-        hipLaunchKernelGGL((nnf_hals_generic_kernel<MODE>), dim3(nblocks), dim3(128), shm, st, UtM, ldm, Gp, dinv, RP, V,
+        hipLaunchKernelGGL((nnf_hals_generic_kernel<MODE>), dim3(nblocks), dim3(128), shm, st, UtM, ldm, Gp, dinv, RS, V,
                            ldv, r, ncols, nsweeps, delta, sp, flags, sy, status, sweep_partials);
         NNF_CHECK_LAUNCH();
     } else {

@@ -8,8 +8,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define HALS_SPIN_LIMIT (1u << 22)
 
 struct hals_sync {
-    unsigned* counter;   // monotonic arrival counter (zeroed by the prep kernel)
-    double* slots;       // [2][nblocks][4] partials, parity-double-buffered
+    unsigned* counter;   // generic path: monotonic arrival counter (zeroed by the prep kernel)
+    double* slots;       // generic path: [2][nblocks][4] partials, parity-double-buffered
+    double* sslots;      // fast path: [max_sweeps + 2][nblocks][2] tagged 8-byte granules (hals_publish)
+    unsigned epoch;      // fast path: per-call tag salt (nnf_ctx::hals_epoch)
 };
 
 // Exchange up to 3 doubles between all workgroups; returns sums of v0, v1 and the max of v2 in out[0..2].
@@ -75,6 +77,53 @@ __device__ __forceinline__ bool grid_exchange(const hals_sync& sy, unsigned epoc
     return ok;
 }
 
+
+// Fast path, non-blocking form of the exchange (cdna_hip_programming.md Guideline 16, form R2: the data IS the flag).
+// A workgroup's fp64 partial of sweep s travels as two 8-byte granules {tag, lo32} {tag, hi32}, each ONE write-through
+// (sc1) store: fire and forget, no drain, no counter.  tag = epoch*1024 + s with a per-call epoch from the context, so
+// words left behind by earlier solves never match (the workspace is zeroed once at context creation).
+// collect: every thread re-reads its share of the granules (sc1 loads) until both tags match (bounded), then all
+// workgroups sum all partials in index order -> the same double everywhere, bit for bit.
+__device__ __forceinline__ void hals_publish(const hals_sync& sy, int s, int nblocks, double mine) {
+    if (threadIdx.x == 0) {
+        const unsigned long long bits = __builtin_bit_cast(unsigned long long, mine);
+        const unsigned long long tag = (unsigned long long)(sy.epoch * 1024u + (unsigned)s) << 32;
+        unsigned long long* g = reinterpret_cast<unsigned long long*>(sy.sslots) + ((size_t)s * nblocks + blockIdx.x) * 2;
+        __hip_atomic_store(g, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ bool hals_collect(const hals_sync& sy, int s, int nblocks, double& total, double* red,
+                                             unsigned* lds_flag) {
+    if (threadIdx.x == 0) *lds_flag = 1u;
+    __syncthreads();
+    const unsigned tag = sy.epoch * 1024u + (unsigned)s;
+    const unsigned long long* base = reinterpret_cast<const unsigned long long*>(sy.sslots) + (size_t)s * nblocks * 2;
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+        unsigned long long g0, g1;
+        unsigned spins = 0;
+        for (;;) {
+            g0 = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g1 = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > HALS_SPIN_LIMIT) { *lds_flag = 0u; break; }
+        }
+        v += __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xffffffffull));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    const bool ok = (*lds_flag != 0);
+    double t = red[0];
+    for (int k = 1; k < nw; ++k) t += red[k];
+    total = t;
+    __syncthreads();
+    return ok;
+}
 
 struct hals_args {
     const float* UtM; int64_t ldm;

@@ -7,37 +7,62 @@
 #error "compile with -DHALS_PART=0..3"
 #endif
 
-typedef const __attribute__((address_space(4))) f32x2* cg2_t;   // constant address space -> s_load
-typedef const __attribute__((address_space(4))) float* cf_t;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Scalar (SMEM) loads issued by hand.  SMEM returns out of order, so the only usable wait is lgkmcnt(0) and hipcc cannot
+// software-pipeline such loads itself (it sinks every load to its use: one exposed scalar-cache round trip per 16 values).
+// Here a 32-float block of the Gram row is fetched while the previous block is being consumed: wait(current) ->
+// issue(next) -> 16 x v_pk_fma_f32 with SGPR-pair operands.  The loads are invisible to hipcc's counters (so it adds no
+// waits of its own); the "+s" wait statements carry the data dependence (cdna_hip_programming.md s.5.7 form (ii)).
+#define NNF_SLOAD2(d0, d1, base, off) \
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4" : "=s"(d0), "=s"(d1) : "s"(base), "i"((off) * 4), "i"((off) * 4 + 64))
+#define NNF_SLOAD2D(d0, d1, dd, base, off, doff) \
+    asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dword %2, %3, %6" \
+                 : "=s"(d0), "=s"(d1), "=s"(dd) : "s"(base), "i"((off) * 4), "i"((off) * 4 + 64), "i"((doff) * 4))
+#define NNF_SWAIT2(d0, d1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1))
+#define NNF_SWAIT3(d0, d1, dd) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1), "+s"(dd))
 
 // One Gauss-Seidel sweep (nnls.py:158-170) over the column held in v2 = {(v[0],v[1]), (v[2],v[3]), ...}.
 //   x     = (UtM[k] - UtU[k,:].v - sp) / UtU[k,k]
 //   v[k] <- max(v[k] + x, 0)            (== v[k] + max(x, -v[k]) of the reference, same rounding)
 //   step  = x if not clipped else -v[k]
-// The per-row asm ties do two things hipcc would otherwise undo: (1) the scalar loads of Gram row k cannot be issued
-// before row k-1 has finished (unconstrained, all RP^2 loads are clustered up front and thousands of SGPRs spill);
-// (2) nothing about row k is precomputed rows ahead (keeps the live set at the column itself).
+// Gp: padded Gram, row stride RS = 32*ceil(R/32) floats (zeros past r), followed by 1/diag (R floats, 0 = skip row).
 template <int R, bool KEEPB>
 __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const float (&b)[KEEPB ? R : 1], rsrc_t rb, int voff,
-                                                   int ldm4, const float* __restrict__ Gp, const float* __restrict__ dinv,
-                                                   float sp) {
+                                                   int ldm4, const float* __restrict__ Gp, float sp) {
+    constexpr int NBLK = (R + 31) / 32, RS = 32 * NBLK, P = R / 2, DOFF = R * RS;
+    const uint64_t base = (uint64_t)Gp;
+    f32x16 buf[2][2];
+    float dv[2];
     float nd = 0.f;
+    NNF_SLOAD2D(buf[0][0], buf[0][1], dv[0], base, 0, DOFF);
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        uint64_t pz = (uint64_t)Gp, dz = (uint64_t)dinv;
-        if (k > 0)
-            asm volatile("" : "+s"(pz), "+s"(dz), "+v"(v2[(k - 1) / 2]));
-        else
-            asm volatile("" : "+s"(pz), "+s"(dz));
-        cg2_t G2 = (cg2_t)(pz) + (k * R) / 2;
-        const float di = ((cf_t)dz)[k];
         f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+        float di = 0.f;
 #pragma unroll
-        for (int j = 0; j + 1 < R / 2; j += 2) {
-            a0 = __builtin_elementwise_fma(G2[j], v2[j], a0);
-            a1 = __builtin_elementwise_fma(G2[j + 1], v2[j + 1], a1);
+        for (int blk = 0; blk < NBLK; ++blk) {
+            const int jb = k * NBLK + blk, cur = jb & 1, nxt = cur ^ 1;
+            if (blk == 0) {
+                NNF_SWAIT3(buf[cur][0], buf[cur][1], dv[k & 1]);
+                di = dv[k & 1];
+            } else {
+                NNF_SWAIT2(buf[cur][0], buf[cur][1]);
+            }
+            // next block of the stream (next row's first block also brings that row's 1/diag)
+            if (blk + 1 < NBLK) {
+                NNF_SLOAD2(buf[nxt][0], buf[nxt][1], base, k * RS + 32 * (blk + 1));
+            } else if (k + 1 < R) {
+                NNF_SLOAD2D(buf[nxt][0], buf[nxt][1], dv[(k + 1) & 1], base, (k + 1) * RS, DOFF + k + 1);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (16 * blk + j < P)
+                    a0 = __builtin_elementwise_fma(f32x2{buf[cur][0][2 * j], buf[cur][0][2 * j + 1]}, v2[16 * blk + j], a0);
+                if (16 * blk + 8 + j < P)
+                    a1 = __builtin_elementwise_fma(f32x2{buf[cur][1][2 * j], buf[cur][1][2 * j + 1]}, v2[16 * blk + 8 + j], a1);
+            }
         }
-        if constexpr ((R / 2) & 1) a0 = __builtin_elementwise_fma(G2[R / 2 - 1], v2[R / 2 - 1], a0);
         const f32x2 a = a0 + a1;
         const float dot = a[0] + a[1];
         float bk;
@@ -57,12 +82,13 @@ __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const flo
         }
         v2[k / 2][k & 1] = vn;
         nd = fmaf(step, step, nd);
+        asm volatile("" : "+v"(nd));  // finish this row's bookkeeping here (otherwise it is sunk to the end of the sweep)
     }
     return nd;
 }
 
 template <int RP, bool RES>
-__global__ __launch_bounds__(256, 2) void nnf_hals_kernel(hals_args a) {
+__global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_args a) {
     constexpr bool KEEPB = (RP <= 64);
     __shared__ double red[4 * 3];
     __shared__ unsigned lds_flag;
@@ -96,36 +122,58 @@ __global__ __launch_bounds__(256, 2) void nnf_hals_kernel(hals_args a) {
     const int voff0 = gtid < a.ncols ? (int)(gtid * 4) : (int)0x7ffffff0;
     if constexpr (RES) load_col(voff0);
 
+    // Sweep loop.  mode 1: fixed count, per-sweep local partials, nothing to decide.
+    // mode 0, resident columns: lag-one speculation.  After sweep s the workgroup publishes its partial and goes straight
+    // on to sweep s+1 in registers; only then does it collect the global sum of sweep s (published by every workgroup a
+    // whole sweep ago, so the wait is normally free).  If that sum says "stop" (nnls.py:156) the registers are dropped:
+    // memory still holds V after sweep s, because V is stored only after a sweep has been confirmed.  Cost: one wasted
+    // sweep at the end instead of a grid-barrier stall in every sweep.  Strided mode keeps the blocking exchange.
     double eps0 = 0.0, eps = 1.0;
     int done = 0;
-    bool ok = true;
+    bool ok = true, stopped = false;
     for (int s = 1; s <= a.max_sweeps; ++s) {
         double nd = 0.0;
         if constexpr (RES) {
-            const float f = hals_sweep_column<RP, KEEPB>(v2, b, rb, voff0, ldm4, a.Gp, a.dinv, a.sp);
+            const float f = hals_sweep_column<RP, KEEPB>(v2, b, rb, voff0, ldm4, a.Gp, a.sp);
             nd = gtid < a.ncols ? (double)f : 0.0;
         } else {
             for (int64_t col = gtid; col < a.ncols; col += gthreads) {
                 const int voff = (int)(col * 4);
                 load_col(voff);
-                nd += (double)hals_sweep_column<RP, KEEPB>(v2, b, rb, voff, ldm4, a.Gp, a.dinv, a.sp);
+                nd += (double)hals_sweep_column<RP, KEEPB>(v2, b, rb, voff, ldm4, a.Gp, a.sp);
                 store_col(voff);
             }
         }
-        done = s;
         const double bs = nnf_block_sum_f64(nd, red);
         if (a.mode == 1) {
             if (threadIdx.x == 0) a.sweep_partials[(size_t)(s - 1) * nblocks + blockIdx.x] = bs;
-        } else {
-            double mine[1] = {bs}, tot[1];
-            ok = grid_exchange<1>(a.sy, (unsigned)s, nblocks, mine, tot, red, &lds_flag);
+            done = s;
+            continue;
+        }
+        hals_publish(a.sy, s, nblocks, bs);
+        const int c = RES ? s - 1 : s;          // sweep whose global sum is examined now
+        if (c >= 1) {
+            double tot;
+            ok = hals_collect(a.sy, c, nblocks, tot, red, &lds_flag);
             if (!ok) break;
-            if (s == 1) eps0 = tot[0];
-            eps = tot[0];
-            if (!(eps >= a.delta * eps0)) break;  // nnls.py:156
+            if (c == 1) eps0 = tot;
+            eps = tot;
+            done = c;
+            if (!(eps >= a.delta * eps0)) { stopped = true; break; }   // nnls.py:156: sweep c was the last one
+        }
+        if constexpr (RES) store_col(voff0);    // V after sweep s (sweep s-1 said "go on")
+    }
+    if (a.mode == 1) {
+        if constexpr (RES) store_col(voff0);
+    } else if (RES && ok && !stopped && a.max_sweeps >= 1) {
+        double tot;                             // ran to the sweep budget: the last sweep's sum is still due
+        ok = hals_collect(a.sy, a.max_sweeps, nblocks, tot, red, &lds_flag);
+        if (ok) {
+            if (a.max_sweeps == 1) eps0 = tot;
+            eps = tot;
+            done = a.max_sweeps;
         }
     }
-    if constexpr (RES) store_col(voff0);
     if (a.mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
         if (a.max_sweeps >= 1) {
             a.status[NNF_HALS_ST_EPS] = eps;

@@ -26,12 +26,16 @@
 //   grid: 8*ceil(nsplit/8)*ncb workgroups of 256 threads; workgroup = (row split ks, 256-column block cb);
 //   wave w owns columns cb*256 + 64w .. +63 (lane: 4*(l&15)+c), all MT row tiles; k runs over the split's rows.
 // =========================================================================================================
-template <int MT, bool VEC>
-__global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_xty_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+// REM > 0: rank = 16*MT + (1..REM) -- the MT full 16-row tiles run on MFMA, the REM leftover rows on the VALU pipe, which
+// is otherwise idle here (fp32 MFMA and fp32 VALU have the same peak on gfx950, so padding r=50 to 64 would burn 22 % of
+// the MFMA time on zeros).  The leftover rows' operand is the (MT+1)-th tile of the same LDS image, read as a broadcast.
+template <int MT, int REM, bool VEC>
+__global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xty_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                          const float* __restrict__ Ut, int64_t ldu, int r,
                                                          float* __restrict__ slabs, int64_t ldp, int ncb, int nsplit,
                                                          int64_t rows_per_split, int a_vec_ok) {
-    __shared__ f32x4 ldsA[2][MT * 256];
+    constexpr int MTA = MT + (REM > 0 ? 1 : 0);   // tiles staged in LDS
+    __shared__ f32x4 ldsA[2][MTA * 256];
     int ks, cb;
     nnf_xcd_map(blockIdx.x, ncb, ks, cb);
     if (ks >= nsplit) return;
@@ -54,20 +58,23 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_xty_kernel(const f
         for (int cc = 0; cc < 4; ++cc) acc[mt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x4 xb[4][4];  // [k-group t][k-step c]: row i_begin + 64q + 16t + 4g + c, columns jl..jl+3
-    f32x4 areg[MT];
+    f32x4 areg[MTA];
+    f32x4 ev[REM > 0 ? REM : 1];   // leftover rows: partial sums over this lane's rows, columns jl..jl+3
+#pragma unroll
+    for (int rr = 0; rr < (REM > 0 ? REM : 1); ++rr) ev[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stageA_load<MT>(Ut, ldu, r, i_end, i_begin, a_vec_ok, areg);
+    stageA_load<MTA>(Ut, ldu, r, i_end, i_begin, a_vec_ok, areg);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, (16 * t + c) * ldx4);
-    stageA_store<MT>(ldsA[0], areg);
+    stageA_store<MTA>(ldsA[0], areg);
     __syncthreads();
 
     for (int q = 0; q < nchunk; ++q) {
         const f32x4* img = ldsA[q & 1];
         // next chunk's A tile: global loads now, LDS write after the MFMAs (rows past i_end come back as zeros)
-        stageA_load<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), a_vec_ok, areg);
+        stageA_load<MTA>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), a_vec_ok, areg);
         const int soff_next = (q + 1) * 64 * ldx4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -80,11 +87,19 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_xty_kernel(const f
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) acc[mt][cc] = MFMA16(af[mt][c], xb[t][c][cc], acc[mt][cc]);
+            if constexpr (REM > 0) {
+#pragma unroll
+                for (int rr = 0; rr < REM; ++rr) {
+                    const f32x4 uv = img[(MT * 4 + t) * 64 + 16 * g + rr];   // Ut[16MT+rr][row 16t+4g+c], c = 0..3
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ev[rr] = __builtin_elementwise_fma(f32x4{uv[c], uv[c], uv[c], uv[c]}, xb[t][c], ev[rr]);
+                }
+            }
             // refill the registers just consumed with the same rows of the next chunk (past the end: zeros)
 #pragma unroll
             for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, soff_next + (16 * t + c) * ldx4);
         }
-        stageA_store<MT>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
+        stageA_store<MTA>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
         __syncthreads();
     }
 
@@ -101,6 +116,22 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_xty_kernel(const f
                     *reinterpret_cast<f32x4*>(sl + (int64_t)rk * ldp + jl) = o;
                 }
             }
+    }
+    if constexpr (REM > 0) {   // sum the four row groups (lanes l, l^16, l^32, l^48), lanes of group 0 store
+        float* sl = slabs + (int64_t)ks * r * ldp;
+#pragma unroll
+        for (int rr = 0; rr < REM; ++rr) {
+            f32x4 e = ev[rr];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float x = e[c];
+                x += __shfl_xor(x, 16, 64);
+                x += __shfl_xor(x, 32, 64);
+                e[c] = x;
+            }
+            const int rk = 16 * MT + rr;
+            if (g == 0 && rk < r && jl < ldp) *reinterpret_cast<f32x4*>(sl + (int64_t)rk * ldp + jl) = e;
+        }
     }
 }
 
@@ -130,7 +161,7 @@ int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, 
     return NNF_OK;
 }
 
-template <int MT, bool VEC>
+template <int MT, int REM, bool VEC>
 static int launch_xty(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int r,
                       int64_t ldu, float* out, int64_t ldo, hipStream_t st) {
     const int ncb = (int)nnf_cdiv(n, 256);
@@ -157,7 +188,7 @@ static int launch_xty(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t 
     if (!slabs) return NNF_ERR_WORKSPACE;
     const int a_vec_ok = ((((uintptr_t)Ut) & 15) == 0 && (ldu & 3) == 0) ? 1 : 0;
     const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * ncb;
-    hipLaunchKernelGGL((nnf_xty_kernel<MT, VEC>), dim3(grid), dim3(256), 0, st, X, m, n, ldx, Ut, ldu, r, slabs, ldp, ncb,
+    hipLaunchKernelGGL((nnf_xty_kernel<MT, REM, VEC>), dim3(grid), dim3(256), 0, st, X, m, n, ldx, Ut, ldu, r, slabs, ldp, ncb,
                        (int)nsplit, rows_per_split, a_vec_ok);
     NNF_CHECK_LAUNCH();
     return nnf_launch_reduce_slabs(slabs, (int)nsplit, slab_elems, r, n, ldp, out, ldo, st);
@@ -168,11 +199,12 @@ static int launch_xty(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t 
 //   workgroup = 256 rows of X (wave w: rows 64w..64w+63 as four 16-row N tiles), k runs over the n columns.
 //   B operand lane (ii = l&15, g = l>>4) of tile nt, k-group t: float4 X[i0w+16nt+ii][64q+16t+4g .. +3].
 // =========================================================================================================
-template <int MT, bool VEC>
-__global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_xht_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+template <int MT, int REM, bool VEC>
+__global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xht_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                          const float* __restrict__ V, int64_t ldv, int r,
                                                          float* __restrict__ out, int64_t ldo, int a_vec_ok) {
-    __shared__ f32x4 ldsA[2][MT * 256];
+    constexpr int MTA = MT + (REM > 0 ? 1 : 0);
+    __shared__ f32x4 ldsA[2][MTA * 256];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ii = lane & 15, g = lane >> 4;
     const int64_t i0w = (int64_t)blockIdx.x * 256 + 64 * w;
@@ -190,19 +222,24 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_xht_kernel(const f
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 xb[4][4];  // [k-group t][row tile nt]
-    f32x4 areg[MT];
+    f32x4 areg[MTA];
+    float ev[REM > 0 ? REM : 1][4];   // leftover rank rows x the four 16-row tiles: partial over this lane's k
+#pragma unroll
+    for (int rr = 0; rr < (REM > 0 ? REM : 1); ++rr)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) ev[rr][nt] = 0.f;
 
-    stageA_load<MT>(V, ldv, r, n, 0, a_vec_ok, areg);
+    stageA_load<MTA>(V, ldv, r, n, 0, a_vec_ok, areg);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 64 * t);
-    stageA_store<MT>(ldsA[0], areg);
+    stageA_store<MTA>(ldsA[0], areg);
     __syncthreads();
 
     for (int q = 0; q < nchunk; ++q) {
         const f32x4* img = ldsA[q & 1];
-        stageA_load<MT>(V, ldv, r, n, 64 * (int64_t)(q + 1), a_vec_ok, areg);
+        stageA_load<MTA>(V, ldv, r, n, 64 * (int64_t)(q + 1), a_vec_ok, areg);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f32x4 af[MT];
@@ -223,11 +260,24 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_xht_kernel(const f
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(af[mt][c], xb[t][nt][c], acc[mt][nt]);
+            if constexpr (REM > 0) {
+#pragma unroll
+                for (int rr = 0; rr < REM; ++rr) {
+                    const f32x4 uv = img[(MT * 4 + t) * 64 + 16 * g + rr];   // V[16MT+rr][64q+16t+4g+c], c = 0..3
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        float e = ev[rr][nt];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) e = fmaf(uv[c], xb[t][nt][c], e);
+                        ev[rr][nt] = e;
+                    }
+                }
+            }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
                 xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * (q + 1) + 64 * t);
         }
-        stageA_store<MT>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
+        stageA_store<MTA>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
         __syncthreads();
     }
 
@@ -245,15 +295,28 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_xht_kernel(const f
                 }
         }
     }
+    if constexpr (REM > 0) {
+#pragma unroll
+        for (int rr = 0; rr < REM; ++rr)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float x = ev[rr][nt];
+                x += __shfl_xor(x, 16, 64);
+                x += __shfl_xor(x, 32, 64);
+                const int64_t i = i0w + 16 * nt + ii;
+                const int rk = 16 * MT + rr;
+                if (g == 0 && rk < r && i < m) out[(int64_t)rk * ldo + i] = x;
+            }
+    }
 }
 
-template <int MT, bool VEC>
+template <int MT, int REM, bool VEC>
 static int launch_xht(nnf_ctx*, nnf_ws_cursor&, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r, int64_t ldv,
                       float* out, int64_t ldo, hipStream_t st) {
     if (64 * ldx * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
     const int a_vec_ok = ((((uintptr_t)V) & 15) == 0 && (ldv & 3) == 0) ? 1 : 0;
     const int grid = (int)nnf_cdiv(m, 256);
-    hipLaunchKernelGGL((nnf_xht_kernel<MT, VEC>), dim3(grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
+    hipLaunchKernelGGL((nnf_xht_kernel<MT, REM, VEC>), dim3(grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
                        a_vec_ok);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
@@ -351,7 +414,8 @@ template <int OP, bool VEC>
 __global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                           const float* __restrict__ Ut, int64_t ldu,
                                                           const float* __restrict__ V, int64_t ldv, int r,
-                                                          float beta, double* __restrict__ partial) {
+                                                          float beta, double* __restrict__ partial,
+                                                          const float* __restrict__ Vb, int64_t ldvb, int64_t nb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KS = (r + 3) >> 2;                               // k-steps of 4
     float* ldsU = reinterpret_cast<float*>(smem);              // [wave 4][rt 2][KS][64]
@@ -375,25 +439,52 @@ __global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restric
         const int64_t i = i0w + 16 * rt + (L & 15);
         ldsU[(w * 2 + rt) * KS * 64 + s * 64 + L] = (k < r && i < m) ? Ut[(int64_t)k * ldu + i] : 0.f;
     }
-    // V fragments of one 64-column block: img[s][lane] = float4 V[4s + (lane>>4)][j0 + 4(lane&15) .. +3]
-    auto stageV = [&](int blk, f32x4* img) {
+    // V fragments of one 64-column block: img[s][lane] = float4 V[4s + (lane>>4)][j0 + 4(lane&15) .. +3].
+    // Staged in two halves: global loads into registers before the MFMAs of the current block, LDS writes after them.
+    constexpr int NV = 8;                       // KS*64/256 <= 8 float4 per thread (r <= 128)
+    f32x4 vreg[NV];
+    auto stageV_load = [&](int blk) {
         const int64_t j0 = 64 * (int64_t)blk;
-        for (int e = threadIdx.x; e < KS * 64; e += 256) {
-            const int s = e >> 6, L = e & 63;
-            const int k = 4 * s + (L >> 4);
-            const int64_t j = j0 + 4 * (L & 15);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int e = threadIdx.x + 256 * u;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < r && j < n) {
-                const float* p = V + (int64_t)k * ldv + j;
-                v[0] = p[0];
-                if (j + 1 < n) v[1] = p[1];
-                if (j + 2 < n) v[2] = p[2];
-                if (j + 3 < n) v[3] = p[3];
+            if (e < KS * 64) {
+                const int s = e >> 6, L = e & 63;
+                const int k = 4 * s + (L >> 4);
+                const int64_t j = j0 + 4 * (L & 15);
+                if (k < r && j < n) {
+                    if (Vb == nullptr) {
+                        const float* p = V + (int64_t)k * ldv + j;
+                        v[0] = p[0];
+                        if (j + 1 < n) v[1] = p[1];
+                        if (j + 2 < n) v[2] = p[2];
+                        if (j + 3 < n) v[3] = p[3];
+                    } else {  // Khatri-Rao column j = (ja, jb), jb fastest: V[k][ja] * Vb[k][jb]
+                        const int64_t ja0 = j / nb, jb0 = j - ja0 * nb;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (j + c < n) {
+                                int64_t ja = ja0, jb = jb0 + c;
+                                while (jb >= nb) { jb -= nb; ++ja; }
+                                v[c] = V[(int64_t)k * ldv + ja] * Vb[(int64_t)k * ldvb + jb];
+                            }
+                        }
+                    }
+                }
             }
-            img[e] = v;
+            vreg[u] = v;
         }
     };
-    stageV(0, ldsV);
+    auto stageV_store = [&](f32x4* img) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            if (e < KS * 64) img[e] = vreg[u];
+        }
+    };
+    stageV_load(0);
+    stageV_store(ldsV);
     f32x4 xb[2][4];  // [rt][reg]: row i0w + 16rt + 4g + reg, columns j0+4jj..+3
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -405,12 +496,13 @@ __global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restric
     const float* uf = ldsU + (size_t)(w * 2) * KS * 64 + lane;
     for (int blk = 0; blk < nblk; ++blk) {
         const f32x4* img = ldsV + (size_t)(blk & 1) * KS * 64;
-        if (blk + 1 < nblk) stageV(blk + 1, ldsV + (size_t)((blk + 1) & 1) * KS * 64);
+        stageV_load(blk + 1);   // past the last block every entry is masked to zero (j >= n)
         f32x4 acc[2][4];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) acc[rt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
         for (int s = 0; s < KS; ++s) {
             const f32x4 bv = img[s * 64 + lane];
             const float a0 = uf[s * 64], a1 = uf[KS * 64 + s * 64];
@@ -439,6 +531,7 @@ __global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restric
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
                 xb[rt][reg] = nnf_bload4<VEC>(rs, voff, (16 * rt + reg) * ldx4 + 256 * (blk + 1));
+        stageV_store(ldsV + (size_t)((blk + 1) & 1) * KS * 64);
         __syncthreads();
     }
     const double bs = nnf_block_sum_f64(dsum, red);
@@ -456,27 +549,39 @@ __global__ __launch_bounds__(256) void nnf_sum_partials_kernel(const double* __r
 }
 
 
-#define DISPATCH_MT(FN, VEC, ...)                         \
+#define DISPATCH_MT(FN, REM, VEC, ...)                    \
     switch (MT) {                                         \
-        case 1: return FN<1, VEC>(__VA_ARGS__);           \
-        case 2: return FN<2, VEC>(__VA_ARGS__);           \
-        case 3: return FN<3, VEC>(__VA_ARGS__);           \
-        case 4: return FN<4, VEC>(__VA_ARGS__);           \
-        case 5: return FN<5, VEC>(__VA_ARGS__);           \
-        case 6: return FN<6, VEC>(__VA_ARGS__);           \
-        case 7: return FN<7, VEC>(__VA_ARGS__);           \
-        default: return FN<8, VEC>(__VA_ARGS__);          \
+        case 1: return FN<1, REM, VEC>(__VA_ARGS__);      \
+        case 2: return FN<2, REM, VEC>(__VA_ARGS__);      \
+        case 3: return FN<3, REM, VEC>(__VA_ARGS__);      \
+        case 4: return FN<4, REM, VEC>(__VA_ARGS__);      \
+        case 5: return FN<5, REM, VEC>(__VA_ARGS__);      \
+        case 6: return FN<6, REM, VEC>(__VA_ARGS__);      \
+        case 7: return FN<7, REM, VEC>(__VA_ARGS__);      \
+        default: return FN<8, REM, VEC>(__VA_ARGS__);     \
     }
+// rank -> (MFMA tiles, VALU leftover rows): r = 16q + (1..4), q >= 1 keeps q tiles on MFMA and 2 or 4 rows on VALU
+static inline void split_rank(int r, int& MT, int& REM) {
+    const int q = r / 16, rem = r % 16;
+    if (q >= 1 && q <= 7 && rem >= 1 && rem <= 4) { MT = q; REM = rem <= 2 ? 2 : 4; }
+    else { MT = (r + 15) / 16; REM = 0; }
+}
 
 int nnf_xty_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
                  int r, int64_t ldu, float* out, int64_t ldo, hipStream_t st) {
     if (!ctx || !X || !Ut || !out || m < 1 || n < 1 || r < 1 || ldx < n || ldu < m || ldo < n) return NNF_ERR_ARG;
     if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
-    const int MT = (r + 15) / 16;
-    if (x_vec_ok(X, ldx)) {
-        DISPATCH_MT(launch_xty, true, ctx, cur, X, m, n, ldx, Ut, r, ldu, out, ldo, st)
+    int MT, REM;
+    split_rank(r, MT, REM);
+    if (!x_vec_ok(X, ldx)) {
+        MT = (r + 15) / 16;
+        DISPATCH_MT(launch_xty, 0, false, ctx, cur, X, m, n, ldx, Ut, r, ldu, out, ldo, st)
+    } else if (REM == 2) {
+        DISPATCH_MT(launch_xty, 2, true, ctx, cur, X, m, n, ldx, Ut, r, ldu, out, ldo, st)
+    } else if (REM == 4) {
+        DISPATCH_MT(launch_xty, 4, true, ctx, cur, X, m, n, ldx, Ut, r, ldu, out, ldo, st)
     } else {
-        DISPATCH_MT(launch_xty, false, ctx, cur, X, m, n, ldx, Ut, r, ldu, out, ldo, st)
+        DISPATCH_MT(launch_xty, 0, true, ctx, cur, X, m, n, ldx, Ut, r, ldu, out, ldo, st)
     }
 }
 extern "C" int nnf_xty_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int r,
@@ -490,11 +595,17 @@ int nnf_xht_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, in
                  int r, int64_t ldv, float* out, int64_t ldo, hipStream_t st) {
     if (!ctx || !X || !V || !out || m < 1 || n < 1 || r < 1 || ldx < n || ldv < n || ldo < m) return NNF_ERR_ARG;
     if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
-    const int MT = (r + 15) / 16;
-    if (x_vec_ok(X, ldx)) {
-        DISPATCH_MT(launch_xht, true, ctx, cur, X, m, n, ldx, V, r, ldv, out, ldo, st)
+    int MT, REM;
+    split_rank(r, MT, REM);
+    if (!x_vec_ok(X, ldx)) {
+        MT = (r + 15) / 16;
+        DISPATCH_MT(launch_xht, 0, false, ctx, cur, X, m, n, ldx, V, r, ldv, out, ldo, st)
+    } else if (REM == 2) {
+        DISPATCH_MT(launch_xht, 2, true, ctx, cur, X, m, n, ldx, V, r, ldv, out, ldo, st)
+    } else if (REM == 4) {
+        DISPATCH_MT(launch_xht, 4, true, ctx, cur, X, m, n, ldx, V, r, ldv, out, ldo, st)
     } else {
-        DISPATCH_MT(launch_xht, false, ctx, cur, X, m, n, ldx, V, r, ldv, out, ldo, st)
+        DISPATCH_MT(launch_xht, 0, true, ctx, cur, X, m, n, ldx, V, r, ldv, out, ldo, st)
     }
 }
 extern "C" int nnf_xht_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r,
@@ -528,7 +639,8 @@ extern "C" int nnf_gram_f32(nnf_ctx* ctx, const float* A, int r, int64_t K, int6
 
 template <int OP>
 static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
-                       const float* V, int64_t ldv, int r, float beta, double scale, double* out_f64, hipStream_t st) {
+                       const float* V, int64_t ldv, int r, float beta, double scale, double* out_f64, hipStream_t st,
+                       const float* Vb = nullptr, int64_t ldvb = 0, int64_t nb = 1) {
     const int grid = (int)nnf_cdiv(m, 128);
     nnf_ws_cursor cur(ctx);
     double* partial = (double*)cur.take((size_t)grid * 8);
@@ -543,10 +655,10 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
     }
     if (x_vec_ok(X, ldx))
         hipLaunchKernelGGL((nnf_cost_kernel<OP, true>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
-                           beta, partial);
+                           beta, partial, Vb, ldvb, nb);
     else
         hipLaunchKernelGGL((nnf_cost_kernel<OP, false>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
-                           beta, partial);
+                           beta, partial, Vb, ldvb, nb);
     NNF_CHECK_LAUNCH();
     hipLaunchKernelGGL(nnf_sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)grid, scale, out_f64);
     NNF_CHECK_LAUNCH();
@@ -580,4 +692,26 @@ extern "C" int nnf_betadiv_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t 
     if (beta == 1.0) return launch_cost<NNF_COST_KL>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 1.f, 1.0, out_f64, st);
     if (beta == 0.0) return launch_cost<NNF_COST_IS>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 0.f, 1.0, out_f64, st);
     return launch_cost<NNF_COST_GEN>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, (float)beta, 1.0, out_f64, st);
+}
+
+// beta-divergence between a dense 3-way tensor and its CP model [[F0, F1, F2]]: the cost kernel on T seen as an
+// I x (J*K) matrix with the right operand V[k][(j,kk)] = F1t[k][j] * F2t[k][kk] generated while it is staged.
+// Replaces the cost lines of ntf.py:470-473 (the reference rebuilds the 500 x 250000 reconstruction explicitly).
+extern "C" int nnf_cp3_betadiv_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t K, const float* Ft0,
+                                   int64_t ld0, const float* Ft1, int64_t ld1, const float* Ft2, int64_t ld2, int R,
+                                   double beta, double* out_f64, void* stream) {
+    if (!ctx || !T || !Ft0 || !Ft1 || !Ft2 || !out_f64 || I < 1 || J < 1 || K < 1 || R < 1 || ld0 < I || ld1 < J ||
+        ld2 < K || !(beta >= 0.0))
+        return NNF_ERR_ARG;
+    if (R > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    const int64_t n = J * K;
+    if (32 * n * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (beta == 2.0)
+        return launch_cost<NNF_COST_FROB>(ctx, T, I, n, n, Ft0, ld0, Ft1, ld1, R, 2.f, 0.5, out_f64, st, Ft2, ld2, K);
+    if (beta == 1.0)
+        return launch_cost<NNF_COST_KL>(ctx, T, I, n, n, Ft0, ld0, Ft1, ld1, R, 1.f, 1.0, out_f64, st, Ft2, ld2, K);
+    if (beta == 0.0)
+        return launch_cost<NNF_COST_IS>(ctx, T, I, n, n, Ft0, ld0, Ft1, ld1, R, 0.f, 1.0, out_f64, st, Ft2, ld2, K);
+    return launch_cost<NNF_COST_GEN>(ctx, T, I, n, n, Ft0, ld0, Ft1, ld1, R, (float)beta, 1.0, out_f64, st, Ft2, ld2, K);
 }

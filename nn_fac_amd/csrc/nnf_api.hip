@@ -32,7 +32,9 @@ extern "C" int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_by
     c->num_cus = cus;
     c->ws_bytes = workspace_bytes ? workspace_bytes : (size_t)256 << 20;
     c->ws = nullptr;
+    c->hals_epoch = 0u;
     hipError_t e = hipMalloc((void**)&c->ws, c->ws_bytes);
+    if (e == hipSuccess) e = hipMemset(c->ws, 0, c->ws_bytes);   // exchange words must not start as look-alike tags
     (void)hipSetDevice(prev);
     if (e != hipSuccess) {
         delete c;

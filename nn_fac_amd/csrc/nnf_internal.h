@@ -9,7 +9,8 @@ struct nnf_ctx {
     int device;
     int num_cus;
     size_t ws_bytes;
-    char* ws;          // device scratch (split-K slabs, partial sums, barrier words)
+    char* ws;          // device scratch (split-K slabs, partial sums, barrier words); zeroed once at creation
+    unsigned hals_epoch;  // salt of the HALS exchange tags (k_hals_common.h)
 };
 
 #define NNF_CHECK_LAUNCH()                                   \

@@ -194,6 +194,19 @@ class Engine:
         return O
 
 
+    def cp3_betadiv(self, T, Ft, beta, out=None):
+        """beta-divergence between T (I x J x K) and the CP model of Ft = [F0^T, F1^T, F2^T]; float64 device scalar."""
+        if T.dim() != 3 or T.dtype != torch.float32 or not T.is_contiguous():
+            raise EngineError("cp3_betadiv: T must be a contiguous 3-way float32 tensor")
+        I, J, K = T.shape
+        R = Ft[0].shape[0]
+        o = out if out is not None else torch.empty(1, dtype=torch.float64, device=T.device)
+        _lib.check(self.lib.nnf_cp3_betadiv_f32(self.ctx, _ptr(T), I, J, K, _ptr(Ft[0]), Ft[0].stride(0), _ptr(Ft[1]),
+                                                Ft[1].stride(0), _ptr(Ft[2]), Ft[2].stride(0), R, float(beta), _ptr(o),
+                                                self._stream()), "nnf_cp3_betadiv_f32")
+        return o
+
+
 def get_engine(device=None):
     """Process-wide engine for `device` (default: current device)."""
     if not torch.cuda.is_available():

@@ -1,0 +1,213 @@
+"""NTF (nonnegative PARAFAC / CP) driver on the MI355X engine -- drop-in for nn_fac/ntf.py
+(ntf :19-199, compute_ntf :201-344, one_ntf_step :347-477) for 3-way tensors.
+
+Per updated mode the reference statements map to the C ABI as follows (factors kept transposed, R x dim):
+
+    cross = hadamard of the other factors' Grams   (ntf.py:442-445) -> nnf_gram_f32 + nnf_hadamard_f32
+    krao ; rhs = unfolded[mode] @ krao             (ntf.py:448-449) -> nnf_mttkrp3_f32 (one pass over the tensor IN PLACE:
+                                                     neither the unfoldings nor the Khatri-Rao matrix are materialised)
+    hals_nnls_acc(rhs^T, cross, F[mode]^T)         (ntf.py:454-456) -> nnf_hals_solve_f32
+    mu_betadivmin(F[mode], krao^T, unfolded[mode]) (ntf.py:459-460) -> nnf_mu_left_f32 on the unfolding (MU path only)
+    cost                                           (ntf.py:462-475) -> nnf_cp3_betadiv_f32: the reference's
+        ||T||^2 - 2<F,rhs> + ||F krao^T||^2 equals ||T - model||^2 exactly; it is evaluated directly (one more pass
+        over the tensor) because the difference form cancels catastrophically in fp32.
+
+Differences kept on purpose: ``one_ntf_step`` exposes ``alpha`` like the reference (default 0.5 = wall-clock dependent,
+ntf.py:349); ``compute_ntf`` adds ``alpha`` / ``delta`` keywords (default: the reference's) so that deterministic runs
+(alpha = inf) are reachable through the driver.  Only 3-way tensors are accelerated (NotImplementedError otherwise).
+"""
+import math
+import time
+
+import numpy as np
+import torch
+
+from .utils import errors as err
+from .utils import initialize_factors as init_factors
+from . import engine as _engine
+from ._convert import device_of, to_dev, to_dev_t, like_input
+from .update_rules.nnls import sweep_budget
+
+
+def ntf(tensor, rank, init="random", factors_0=[], n_iter_max=100, tol=1e-8,
+        update_rule="hals", beta=2,
+        sparsity_coefficients=[], fixed_modes=[], normalize=[],
+        verbose=False, return_costs=False):
+    """Nonnegative PARAFAC of `tensor` (reference docstring: ntf.py:23-179)."""
+    factors = []
+    nb_modes = len(tensor.shape)
+    if init.lower() == "custom":
+        factors = factors_0
+        if len(factors) != nb_modes:
+            raise err.CustomNotEngouhFactors("Custom initialization, but not enough factors")
+        else:
+            for array in factors:
+                if array is None:
+                    raise err.CustomNotValidFactors("Custom initialization, but (at least) one factor is set to 'None'")
+    else:
+        factors = init_factors.ntf_initialization(tensor, rank, init, deterministic=False, seed=0)
+
+    return compute_ntf(tensor, rank, factors, n_iter_max=n_iter_max, tol=tol,
+                       update_rule=update_rule, beta=beta,
+                       sparsity_coefficients=sparsity_coefficients, fixed_modes=fixed_modes, normalize=normalize,
+                       verbose=verbose, return_costs=return_costs)
+
+
+class _NtfState:
+    """Device-resident tensor, its squared norm and (MU only) the materialised unfoldings."""
+
+    def __init__(self, eng, T):
+        if T.dim() != 3:
+            raise NotImplementedError("the MI355X engine accelerates 3-way tensors (nnf_mttkrp3_f32)")
+        self.eng = eng
+        self.T = T.contiguous()
+        I, J, K = self.T.shape
+        t2 = self.T.view(I, J * K)
+        self.norm2 = eng.dot(t2, t2)          # float64 device scalar, ||T||^2
+        self._unf = {}
+        self.block = torch.zeros(8 * 3 + 8, dtype=torch.float64, device=T.device)   # 3 HALS status blocks + cost
+
+    def unfolded(self, mode):
+        """tl.unfold(T, mode) = moveaxis(mode -> 0).reshape(dim, -1)  (MU path; mode 0 is a view)."""
+        if mode not in self._unf:
+            self._unf[mode] = torch.movedim(self.T, mode, 0).reshape(self.T.shape[mode], -1).contiguous()
+        return self._unf[mode]
+
+
+def _krao_t(Ft, skip):
+    """khatri_rao(factors, skip_matrix=skip)^T as an R x prod(other dims) tensor, first remaining mode slowest."""
+    others = [f for i, f in enumerate(Ft) if i != skip]
+    res = others[0]
+    for f in others[1:]:
+        res = (res[:, :, None] * f[:, None, :]).reshape(res.shape[0], -1)
+    return res.contiguous()
+
+
+def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients, fixed_modes, normalize, alpha, delta):
+    eng = st.eng
+    if update_rule not in ["hals", "mu"]:
+        raise err.InvalidArgumentValue(f"Invalid update rule: {update_rule}") from None
+    if update_rule == "hals" and beta != 2:
+        raise err.InvalidArgumentValue(f"The hals is only valid for the frobenius norm, corresponding to the beta divergence with beta = 2. Here, beta was set to {beta}. To compute NMF with this value of beta, please use the mu update_rule.") from None
+    for fixed_value in fixed_modes:
+        sparsity_coefficients[fixed_value] = None
+    Ft = list(Ft_in)
+    dev = st.T.device
+    nstat = 0
+    for mode in [m for m in range(3) if m not in fixed_modes]:
+        if update_rule == "hals":
+            deterministic = math.isinf(alpha)
+            if not deterministic:
+                torch.cuda.synchronize(dev)
+                t0 = time.time()
+            cross = None
+            for i, f in enumerate(Ft):
+                if i != mode:
+                    g = eng.gram(f)
+                    cross = g if cross is None else eng.hadamard(cross, g)
+            rhs_t = eng.mttkrp3(st.T, Ft, mode)
+            budget = 100
+            new = Ft[mode].clone()
+            if not deterministic:
+                torch.cuda.synchronize(dev)
+                timer = time.time() - t0
+                probe = new.clone()
+                t0 = time.time()
+                eng.hals_sweeps(rhs_t, cross, probe, 1, sparsity=sparsity_coefficients[mode], normalize=normalize[mode])
+                torch.cuda.synchronize(dev)
+                rho = timer / max(time.time() - t0, 10e-7) if timer else 100000
+                budget = max(1, sweep_budget(100, alpha, rho))
+            eng.hals_solve(rhs_t, cross, new, budget, delta=delta, sparsity=sparsity_coefficients[mode],
+                           normalize=normalize[mode], status=st.block[8 * nstat:8 * nstat + 8])
+            nstat += 1
+            Ft[mode] = new
+        else:
+            Ft[mode] = eng.mu_left(st.unfolded(mode), Ft[mode], _krao_t(Ft, mode), beta)
+
+    cost = st.block[24:25]
+    if update_rule == "hals":
+        eng.cp3_betadiv(st.T, Ft, 2, out=cost)
+        cost.mul_(2.0)                               # ||T - model||^2
+    else:
+        eng.cp3_betadiv(st.T, Ft, beta, out=cost)
+    sparsity_error = None
+    for index, sparse in enumerate(sparsity_coefficients):
+        if sparse:
+            # np.linalg.norm(factor, ord=1): max column abs-sum of the dim x R factor = max row abs-sum of Ft
+            term = 2 * sparse * Ft[index].abs().sum(dim=1).max().double()
+            sparsity_error = term if sparsity_error is None else sparsity_error + term
+    if sparsity_error is not None:
+        cost.add_(sparsity_error)
+    cost.div_(st.norm2)
+    return Ft, nstat
+
+
+def compute_ntf(tensor_in, rank, factors_in, n_iter_max=100, tol=1e-8,
+                update_rule="hals", beta=2,
+                sparsity_coefficients=[], fixed_modes=[], normalize=[],
+                verbose=False, return_costs=False, alpha=0.5, delta=0.01, sweep_log=None):
+    """Outer loop of ntf.py:288-344.  Returns the list of factors (dim x R each) [, costs, toc]."""
+    dev = device_of(tensor_in, *factors_in)
+    eng = _engine.get_engine(dev)
+    T = to_dev(tensor_in, dev)
+    st = _NtfState(eng, T)
+    Ft = [to_dev_t(f, dev).clone() for f in factors_in]
+    nb_modes = T.dim()
+    if sparsity_coefficients is None or len(sparsity_coefficients) != nb_modes:
+        print("Irrelevant number of sparsity coefficient (different from the number of modes), they have been set to None.")
+        sparsity_coefficients = [None for i in range(nb_modes)]
+    if fixed_modes is None:
+        fixed_modes = []
+    if normalize is None or len(normalize) != nb_modes:
+        print("Irrelevant number of normalization booleans (different from the number of modes), they have been set to False.")
+        normalize = [False for i in range(nb_modes)]
+    cost_fct_vals, toc = [], []
+    tic = time.time()
+    for iteration in range(n_iter_max):
+        Ft, nstat = _one_ntf_step_dev(st, rank, Ft, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
+                                      alpha, delta)
+        host = st.block.cpu()
+        cost = float(host[24])
+        for i in range(nstat):
+            if int(host[8 * i + _engine.ST_ERR]) != 0:
+                raise err.EngineError("hals grid barrier timed out; result invalid")
+        if sweep_log is not None:
+            sweep_log.extend(int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(nstat))
+        toc.append(time.time() - tic)
+        cost_fct_vals.append(cost)
+        if verbose:
+            if iteration == 0:
+                print('Normalized cost function value={}'.format(cost))
+            else:
+                if cost_fct_vals[-2] - cost_fct_vals[-1] > 0:
+                    print('Normalized cost function value={}, variation={}.'.format(
+                        cost_fct_vals[-1], cost_fct_vals[-2] - cost_fct_vals[-1]))
+                else:
+                    print('\033[91m' + 'Normalized cost function value={}, variation={}.'.format(
+                        cost_fct_vals[-1], cost_fct_vals[-2] - cost_fct_vals[-1]) + '\033[0m')
+        if iteration > 0 and abs(cost_fct_vals[-2] - cost_fct_vals[-1]) < tol:
+            if verbose:
+                print('Converged in {} iterations.'.format(iteration))
+            break
+    # the reference returns np.array(factors), which needs equal mode sizes on NumPy >= 1.24; a list always works
+    factors = [like_input(f.t(), factors_in[i]) for i, f in enumerate(Ft)]
+    if return_costs:
+        return factors, cost_fct_vals, toc
+    return factors
+
+
+def one_ntf_step(unfolded_tensors, rank, in_factors, norm_tensor, update_rule, beta,
+                 sparsity_coefficients, fixed_modes, normalize,
+                 alpha=0.5, delta=0.01):
+    """One pass over the modes (ntf.py:422-477).  `unfolded_tensors` is the reference's list of unfoldings; the tensor is
+    rebuilt from the mode-0 unfolding (a plain reshape).  Returns (factors, cost)."""
+    dev = device_of(*unfolded_tensors, *in_factors)
+    eng = _engine.get_engine(dev)
+    dims = [int(u.shape[0]) for u in unfolded_tensors]
+    T = to_dev(unfolded_tensors[0], dev).reshape(dims)
+    st = _NtfState(eng, T)
+    Ft = [to_dev_t(f, dev) for f in in_factors]
+    Ft, nstat = _one_ntf_step_dev(st, rank, Ft, update_rule, beta, list(sparsity_coefficients), fixed_modes, normalize,
+                                  alpha, delta)
+    host = st.block.cpu()
+    return [like_input(f.t(), in_factors[i]) for i, f in enumerate(Ft)], float(host[24])

@@ -1,0 +1,103 @@
+"""MTTKRP kernels and the NTF driver against the oracle and the reference fixtures (g6).  Needs a MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import nnfac_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+@pytest.fixture(scope="module")
+def eng(built_lib):
+    from nn_fac_amd.engine import get_engine
+    return get_engine("cuda:0")
+
+
+@pytest.mark.parametrize("shape,R", [((12, 10, 8), 4), ((40, 40, 40), 6), ((33, 17, 21), 5), ((300, 64, 128), 30),
+                                     ((64, 300, 70), 17), ((5, 7, 260), 3), ((128, 128, 128), 64), ((70, 50, 90), 100)])
+def test_mttkrp_all_modes(eng, shape, R):
+    rng = np.random.RandomState(sum(shape) + R)
+    T = rng.rand(*shape).astype(np.float32)
+    F = [rng.rand(s, R).astype(np.float32) for s in shape]
+    Td, Ft = dev(T), [dev(f.T) for f in F]
+    T64, F64 = T.astype(np.float64), [f.astype(np.float64) for f in F]
+    for mode in range(3):
+        want = orc.unfold(T64, mode) @ orc.khatri_rao(F64, skip_matrix=mode)       # ntf.py:448-449
+        got = eng.mttkrp3(Td, Ft, mode).cpu().numpy().T
+        assert rel(got, want) < 1e-5, mode
+    model = np.einsum('ir,jr,kr->ijk', *F64)
+    Tp = (T64 + 0.1).astype(np.float32).astype(np.float64)
+    for beta in (2, 1, 0, 1.5):
+        want = orc.beta_divergence(Tp, model, beta)
+        got = float(eng.cp3_betadiv(dev(Tp), Ft, beta))
+        assert abs(got - want) <= 3e-5 * abs(want), (beta, got, want)
+
+
+@pytest.mark.parametrize("name", ["small", "cube", "ragged"])
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 2), ("mu", 1)])
+def test_ntf_against_reference_fixtures(golden, built_lib, name, rule, beta):
+    from nn_fac_amd.ntf import compute_ntf
+    g = golden("g6_ntf.npz")
+    T = g[f"{name}_T"]
+    F0 = [g[f"{name}_F0_{i}"] for i in range(3)]
+    R = F0[0].shape[1]
+    F, costs, toc = compute_ntf(T, R, F0, n_iter_max=5, tol=0, update_rule=rule, beta=beta,
+                                sparsity_coefficients=[None] * 3, fixed_modes=[], normalize=[False] * 3,
+                                return_costs=True, alpha=math.inf, delta=0.01)
+    tolF, tolC = (2e-3, 2e-3) if rule == "hals" else (5e-5, 5e-5)
+    for i in range(3):
+        assert isinstance(F[i], np.ndarray) and F[i].shape == F0[i].shape
+        assert rel(F[i], g[f"{name}_{rule}_b{beta}_F{i}"]) < tolF, i
+    np.testing.assert_allclose(costs, g[f"{name}_{rule}_b{beta}_costs"], rtol=tolC)
+
+
+def test_one_ntf_step_signature(golden, built_lib):
+    from nn_fac_amd.ntf import one_ntf_step, ntf
+    from nn_fac_amd.utils import errors as err
+    g = golden("g6_ntf.npz")
+    T = g["small_T"]
+    F0 = [g[f"small_F0_{i}"] for i in range(3)]
+    unf = [orc.unfold(T, m) for m in range(3)]
+    nrm = np.sqrt(np.sum(T ** 2))
+    F, c = one_ntf_step(unf, 4, F0, nrm, "hals", 2, [None] * 3, [], [False] * 3, alpha=math.inf)
+    Fo, co = orc.one_ntf_step(unf, 4, [f.copy() for f in F0], nrm, "hals", 2, [None] * 3, [], [False] * 3,
+                              alpha=math.inf)
+    assert abs(c - co) <= 2e-3 * co
+    for i in range(3):
+        assert rel(F[i], Fo[i]) < 2e-3
+    with pytest.raises(err.CustomNotEngouhFactors):
+        ntf(T, 4, init="custom", factors_0=F0[:2])
+    with pytest.raises(err.CustomNotValidFactors):
+        ntf(T, 4, init="custom", factors_0=[F0[0], None, F0[2]])
+    with pytest.raises(err.InvalidArgumentValue):
+        one_ntf_step(unf, 4, F0, nrm, "hals", 1, [None] * 3, [], [False] * 3)
+    # default alpha = 0.5: wall-clock dependent like the reference; must run and return finite costs
+    out = ntf(T, 4, init="custom", factors_0=F0, n_iter_max=3, return_costs=True)
+    assert np.isfinite(out[1]).all()
+
+
+def test_ntf_mid_size_vs_oracle(built_lib):
+    """120 x 100 x 80 rank 12 against the fp64 oracle (deterministic HALS)."""
+    from nn_fac_amd.ntf import compute_ntf
+    T, F0 = orc.synth_ntf((120, 100, 80), 12, seed=2, dtype=np.float32)
+    sw, swo = [], []
+    F, costs, _ = compute_ntf(T, 12, F0, n_iter_max=4, tol=0, update_rule="hals", return_costs=True, alpha=math.inf,
+                              sparsity_coefficients=[None] * 3, normalize=[False] * 3, sweep_log=sw)
+    Fo, co, _ = orc.compute_ntf(T.astype(np.float64), 12, [f.astype(np.float64) for f in F0], n_iter_max=4, tol=0,
+                                update_rule="hals", return_costs=True, alpha=math.inf, sweeps=swo)
+    for i in range(3):
+        assert rel(F[i], Fo[i]) < 2e-3
+    np.testing.assert_allclose(costs, co, rtol=2e-3)
+    assert sw == swo

@@ -152,6 +152,12 @@ def main():
     flops = 2.0 * R * M * N
     achieved = flops / (xty_ms * 1e-3) / 1e12
     xty_bytes = (M * N + R * M + R * N) * 4
+    traffic = None      # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), if present
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_xty_traffic.json")) as fh:
+            traffic = json.load(fh)["hbm_bytes_per_launch"]
+    except Exception:
+        pass
 
     if rank == 0:
         out = {
@@ -175,9 +181,10 @@ def main():
                        "inner_sweeps_per_step_last": sweeps[-1] if sweeps else None,
                        "inner_sweeps_mean": float(np.mean([sum(s) for s in sweeps])) if sweeps else None,
                        "final_cost": cost},
-            "roofline": {"kernel": "nnf_xty_kernel (W^T X)", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": "nnf_xty_f32 = nnf_xty_kernel + nnf_reduce_slabs_kernel (W^T X incl. its fixed-order "
+                                   "slab reduction; rocprof: ~204 us + ~16 us)", "bound": "mfma", "achieved": achieved,
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                         "traffic": None, "launch_ms": xty_ms,
+                         "traffic": traffic, "launch_ms": xty_ms,
                          "algorithmic_bytes": xty_bytes, "hbm_gbs": xty_bytes / (xty_ms * 1e-3) / 1e9,
                          "hbm_frac_of_8TBs": xty_bytes / (xty_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }

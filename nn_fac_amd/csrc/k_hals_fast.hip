@@ -35,6 +35,14 @@ __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const flo
     f32x16 buf[2][2];
     float dv[2];
     float nd = 0.f;
+    // UtM column not resident (R > 104): fetch it BPF rows ahead of its use (rows >= r: outside the descriptor -> 0)
+    constexpr int BPF = 8;
+    float bring[KEEPB ? 1 : BPF];
+    if constexpr (!KEEPB) {
+#pragma unroll
+        for (int i = 0; i < BPF; ++i)
+            bring[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, voff, i * ldm4, 0));
+    }
     NNF_SLOAD2D(buf[0][0], buf[0][1], dv[0], base, 0, DOFF);
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -66,20 +74,21 @@ __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const flo
         const f32x2 a = a0 + a1;
         const float dot = a[0] + a[1];
         float bk;
-        if constexpr (KEEPB)
+        if constexpr (KEEPB) {
             bk = b[k];
-        else  // rows >= r lie outside the descriptor: the load returns 0
-            bk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, voff, k * ldm4, 0));
-        const float vk = v2[k / 2][k & 1];
-        const float x = (bk - dot - sp) * di;
-        const float t = vk + x;
-        const bool keep = t > 0.f;
-        float vn = keep ? t : 0.f;
-        float step = keep ? x : -vk;
-        if (di == 0.f) {  // zero Gram diagonal (or padded row): row skipped (nnls.py:160)
-            vn = vk;
-            step = 0.f;
+        } else {
+            bk = bring[k % BPF];
+            if (k + BPF < R)
+                bring[k % BPF] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, voff, (k + BPF) * ldm4, 0));
         }
+        const float vk = v2[k / 2][k & 1];
+        // KEEPB: the resident column already holds UtM - sp.  A zero Gram diagonal (or a padded row) has di = 0: then
+        // x = 0 and the row must stay untouched whatever its sign (nnls.py:160) -> force "keep" with a scalar-side test.
+        const float x = (KEEPB ? (bk - dot) : (bk - dot - sp)) * di;
+        const float t = vk + x;
+        const bool keep = (t > 0.f) | (__builtin_bit_cast(unsigned, di) == 0u);
+        const float vn = keep ? t : 0.f;
+        const float step = keep ? x : -vk;
         v2[k / 2][k & 1] = vn;
         nd = fmaf(step, step, nd);
         asm volatile("" : "+v"(nd));  // finish this row's bookkeeping here (otherwise it is sunk to the end of the sweep)
@@ -89,7 +98,7 @@ __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const flo
 
 template <int RP, bool RES>
 __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_args a) {
-    constexpr bool KEEPB = (RP <= 64);
+    constexpr bool KEEPB = (RP <= 104);   // UtM column resident in VGPRs next to the V column (fits 256 registers)
     __shared__ double red[4 * 3];
     __shared__ unsigned lds_flag;
     const int nblocks = gridDim.x;
@@ -107,8 +116,8 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
 #pragma unroll
         for (int k = 0; k < RP; ++k) {
             v2[k / 2][k & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, k * ldv4, 0));
-            if constexpr (KEEPB)
-                b[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, voff, k * ldm4, 0));
+            if constexpr (KEEPB)   // the sparsity constant is folded in once (rows >= r: di = 0, value irrelevant)
+                b[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, voff, k * ldm4, 0)) - a.sp;
         }
     };
     auto store_col = [&](int voff) {

@@ -22,8 +22,8 @@ enum { BM_KL = 1, BM_GEN = 9 };
 // F_K image of a 64-wide chunk of a row-major r x K matrix A (the rank index is the MFMA k index):
 //   img[(t*MT + s4)*64 + lane].c = A[16*s4 + 4*c + (lane>>4)][k0 + 16*t + (lane&15)]       (zero outside r x K)
 template <int MT>
-__device__ __forceinline__ void stageK(const float* __restrict__ A, int64_t lda, int r, int64_t K, int64_t k0,
-                                       f32x4* __restrict__ img) {
+__device__ __forceinline__ void stageK_load(const float* __restrict__ A, int64_t lda, int r, int64_t K, int64_t k0,
+                                            f32x4 (&regs)[MT]) {
     const int t = threadIdx.x >> 6, L = threadIdx.x & 63;
     const int64_t col = k0 + 16 * t + (L & 15);
 #pragma unroll
@@ -36,8 +36,21 @@ __device__ __forceinline__ void stageK(const float* __restrict__ A, int64_t lda,
                 if (row < r) v[c] = A[(int64_t)row * lda + col];
             }
         }
-        img[(t * MT + s4) * 64 + L] = v;
+        regs[s4] = v;
     }
+}
+template <int MT>
+__device__ __forceinline__ void stageK_store(f32x4* __restrict__ img, const f32x4 (&regs)[MT]) {
+    const int t = threadIdx.x >> 6, L = threadIdx.x & 63;
+#pragma unroll
+    for (int s4 = 0; s4 < MT; ++s4) img[(t * MT + s4) * 64 + L] = regs[s4];
+}
+template <int MT>
+__device__ __forceinline__ void stageK(const float* __restrict__ A, int64_t lda, int r, int64_t K, int64_t k0,
+                                       f32x4* __restrict__ img) {
+    f32x4 regs[MT];
+    stageK_load<MT>(A, lda, r, K, k0, regs);
+    stageK_store<MT>(img, regs);
 }
 
 template <int MT>
@@ -125,10 +138,10 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_right_kernel(const float* __res
     for (int q = 0; q < nchunk; ++q) {
         const f32x4* imgA = ldsA + (size_t)(q & 1) * MT * 256;
         const f32x4* imgK = ldsK + (size_t)(q & 1) * MT * 256;
-        if (q + 1 < nchunk) {
-            stageA_direct<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), a_vec_ok, ldsA + (size_t)((q + 1) & 1) * MT * 256);
-            stageK<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), ldsK + (size_t)((q + 1) & 1) * MT * 256);
-        }
+        // next chunk's operand images: global loads now, LDS writes after this chunk's MFMAs (past the end: zeros)
+        f32x4 sa[MT], sk[MT];
+        stageA_load<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), a_vec_ok, sa);
+        stageK_load<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), sk);
         const int soff_next = (q + 1) * 64 * ldx4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -177,6 +190,8 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_right_kernel(const float* __res
 #pragma unroll
             for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, soff_next + (16 * t + c) * ldx4);
         }
+        stageA_store<MT>(ldsA + (size_t)((q + 1) & 1) * MT * 256, sa);
+        stageK_store<MT>(ldsK + (size_t)((q + 1) & 1) * MT * 256, sk);
         __syncthreads();
     }
     if (jl < ldp) {
@@ -288,10 +303,9 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_left_kernel(const float* __rest
     for (int q = 0; q < nchunk; ++q) {
         const f32x4* imgA = ldsA + (size_t)(q & 1) * MT * 256;
         const f32x4* imgK = ldsK + (size_t)(q & 1) * MT * 256;
-        if (q + 1 < nchunk) {
-            stageA_direct<MT>(V, ldv, r, n, 64 * (int64_t)(q + 1), a_vec_ok, ldsA + (size_t)((q + 1) & 1) * MT * 256);
-            stageK<MT>(V, ldv, r, n, 64 * (int64_t)(q + 1), ldsK + (size_t)((q + 1) & 1) * MT * 256);
-        }
+        f32x4 sa[MT], sk[MT];
+        stageA_load<MT>(V, ldv, r, n, 64 * (int64_t)(q + 1), a_vec_ok, sa);
+        stageK_load<MT>(V, ldv, r, n, 64 * (int64_t)(q + 1), sk);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             // MFMA #1 (transposed product): accP[nt][reg] = P[i0w+16nt+ii][64q+16t+4g+reg]
@@ -341,6 +355,8 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_left_kernel(const float* __rest
             for (int nt = 0; nt < 4; ++nt)
                 xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * (q + 1) + 64 * t);
         }
+        stageA_store<MT>(ldsA + (size_t)((q + 1) & 1) * MT * 256, sa);
+        stageK_store<MT>(ldsK + (size_t)((q + 1) & 1) * MT * 256, sk);
         __syncthreads();
     }
     // epilogue: tile (mt, nt): rk = 16mt+4g+reg, i = i0w+16nt+ii

@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restric
                                                           const float* __restrict__ Ut, int64_t ldu,
                                                           const float* __restrict__ V, int64_t ldv, int r,
                                                           float beta, double* __restrict__ partial,
-                                                          const float* __restrict__ Vb, int64_t ldvb, int64_t nb) {
+                                                          const float* __restrict__ Vb, int64_t ldvb, int64_t nb,
+                                                          const float* __restrict__ Ub, int64_t ldub, int64_t nbu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KS = (r + 3) >> 2;                               // k-steps of 4
     float* ldsU = reinterpret_cast<float*>(smem);              // [wave 4][rt 2][KS][64]
@@ -437,7 +438,15 @@ __global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restric
         const int rt = e / (KS * 64), rem = e - rt * KS * 64, s = rem >> 6, L = rem & 63;
         const int k = 4 * s + (L >> 4);
         const int64_t i = i0w + 16 * rt + (L & 15);
-        ldsU[(w * 2 + rt) * KS * 64 + s * 64 + L] = (k < r && i < m) ? Ut[(int64_t)k * ldu + i] : 0.f;
+        float uval = 0.f;
+        if (k < r && i < m) {
+            if (Ub == nullptr) uval = Ut[(int64_t)k * ldu + i];
+            else {  // Khatri-Rao row i = (ia, ib), ib fastest
+                const int64_t ia = i / nbu, ib = i - ia * nbu;
+                uval = Ut[(int64_t)k * ldu + ia] * Ub[(int64_t)k * ldub + ib];
+            }
+        }
+        ldsU[(w * 2 + rt) * KS * 64 + s * 64 + L] = uval;
     }
     // V fragments of one 64-column block: img[s][lane] = float4 V[4s + (lane>>4)][j0 + 4(lane&15) .. +3].
     // Staged in two halves: global loads into registers before the MFMAs of the current block, LDS writes after them.
@@ -640,7 +649,8 @@ extern "C" int nnf_gram_f32(nnf_ctx* ctx, const float* A, int r, int64_t K, int6
 template <int OP>
 static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
                        const float* V, int64_t ldv, int r, float beta, double scale, double* out_f64, hipStream_t st,
-                       const float* Vb = nullptr, int64_t ldvb = 0, int64_t nb = 1) {
+                       const float* Vb = nullptr, int64_t ldvb = 0, int64_t nb = 1, const float* Ub = nullptr,
+                       int64_t ldub = 0, int64_t nbu = 1) {
     const int grid = (int)nnf_cdiv(m, 128);
     nnf_ws_cursor cur(ctx);
     double* partial = (double*)cur.take((size_t)grid * 8);
@@ -655,10 +665,10 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
     }
     if (x_vec_ok(X, ldx))
         hipLaunchKernelGGL((nnf_cost_kernel<OP, true>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
-                           beta, partial, Vb, ldvb, nb);
+                           beta, partial, Vb, ldvb, nb, Ub, ldub, nbu);
     else
         hipLaunchKernelGGL((nnf_cost_kernel<OP, false>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
-                           beta, partial, Vb, ldvb, nb);
+                           beta, partial, Vb, ldvb, nb, Ub, ldub, nbu);
     NNF_CHECK_LAUNCH();
     hipLaunchKernelGGL(nnf_sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)grid, scale, out_f64);
     NNF_CHECK_LAUNCH();
@@ -704,14 +714,15 @@ extern "C" int nnf_cp3_betadiv_f32(nnf_ctx* ctx, const float* T, int64_t I, int6
         ld2 < K || !(beta >= 0.0))
         return NNF_ERR_ARG;
     if (R > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
-    const int64_t n = J * K;
-    if (32 * n * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
+    // T seen as an (I*J) x K matrix: row (i,j) of the left operand is F0[i,:].*F1[j,:] (generated while it is staged),
+    // the right operand is F2^T as is.  I*J rows give the kernel its parallelism (one workgroup per 128 rows).
+    const int64_t m = I * J;
+    if (32 * K * 4 + 4 * (K + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (beta == 2.0)
-        return launch_cost<NNF_COST_FROB>(ctx, T, I, n, n, Ft0, ld0, Ft1, ld1, R, 2.f, 0.5, out_f64, st, Ft2, ld2, K);
-    if (beta == 1.0)
-        return launch_cost<NNF_COST_KL>(ctx, T, I, n, n, Ft0, ld0, Ft1, ld1, R, 1.f, 1.0, out_f64, st, Ft2, ld2, K);
-    if (beta == 0.0)
-        return launch_cost<NNF_COST_IS>(ctx, T, I, n, n, Ft0, ld0, Ft1, ld1, R, 0.f, 1.0, out_f64, st, Ft2, ld2, K);
-    return launch_cost<NNF_COST_GEN>(ctx, T, I, n, n, Ft0, ld0, Ft1, ld1, R, (float)beta, 1.0, out_f64, st, Ft2, ld2, K);
+#define CP3(OP, B, SC) launch_cost<OP>(ctx, T, m, K, K, Ft0, ld0, Ft2, ld2, R, B, SC, out_f64, st, nullptr, 0, 1, Ft1, ld1, J)
+    if (beta == 2.0) return CP3(NNF_COST_FROB, 2.f, 0.5);
+    if (beta == 1.0) return CP3(NNF_COST_KL, 1.f, 1.0);
+    if (beta == 0.0) return CP3(NNF_COST_IS, 0.f, 1.0);
+    return CP3(NNF_COST_GEN, (float)beta, 1.0);
+#undef CP3
 }

@@ -68,19 +68,23 @@ static inline bool x_vec_ok(const float* X, int64_t ldx) { return (((uintptr_t)X
 //   KL  : x log(x/p) - x + p = x h((p-x)/x)            (x = 0 -> p)
 //   IS  : x/p - log(x/p) - 1 = h((x-p)/p)
 //   gen : (x^b + (b-1) p^b - b x p^(b-1)) / (b(b-1)) = p^b phi((x-p)/p),
-//         phi(u) = ((1+u)^b - 1 - b u)/(b(b-1))        (binomial series below 1/10)
+//         phi(u) = ((1+u)^b - 1 - b u)/(b(b-1))        (binomial series below 3/10)
 // Inputs must be strictly positive for the divergences, as in the reference.
 // ---------------------------------------------------------------------------------------------------------
 enum { NNF_COST_FROB = 0, NNF_COST_KL = 1, NNF_COST_IS = 2, NNF_COST_GEN = 3 };
 
+// hardware transcendental units (v_log_f32 = log2, v_exp_f32 = exp2, v_rcp_f32): ~1 ulp, a few issue slots each
+__device__ __forceinline__ float nnf_ln(float x) { return 0.69314718056f * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float nnf_pow(float x, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x)); }
+
 __device__ __forceinline__ float nnf_h(float t) {
-    if (fabsf(t) < 0.25f) {
-        float s = 1.f / 14.f;
+    // small |t|: alternating series (no cancellation); otherwise t - ln(1+t) directly (no cancellation left to fear)
+    float s = 1.f / 14.f;
 #pragma unroll
-        for (int k = 11; k >= 0; --k) s = fmaf(s, -t, 1.f / (float)(k + 2));
-        return t * t * s;
-    }
-    return t - log1pf(t);
+    for (int k = 11; k >= 0; --k) s = fmaf(s, -t, 1.f / (float)(k + 2));
+    const float series = t * t * s;
+    const float direct = t - nnf_ln(1.f + t);
+    return fabsf(t) < 0.25f ? series : direct;
 }
 
 template <int OP>
@@ -89,20 +93,17 @@ __device__ __forceinline__ float nnf_cost_term(float x, float p, float beta) {
         const float d = x - p;
         return d * d;
     } else if constexpr (OP == NNF_COST_KL) {
-        return x > 0.f ? x * nnf_h((p - x) / x) : p;
+        return x > 0.f ? x * nnf_h((p - x) * __builtin_amdgcn_rcpf(x)) : p;
     } else if constexpr (OP == NNF_COST_IS) {
-        return nnf_h((x - p) / p);
+        return nnf_h((x - p) * __builtin_amdgcn_rcpf(p));
     } else {
-        const float u = (x - p) / p;
-        float phi;
-        if (fabsf(u) < 0.1f) {
-            float s = 1.f;
+        const float u = (x - p) * __builtin_amdgcn_rcpf(p);
+        float s = 1.f;
 #pragma unroll
-            for (int k = 8; k >= 3; --k) s = fmaf(s, (beta - (float)(k - 1)) * u / (float)k, 1.f);
-            phi = 0.5f * u * u * s;
-        } else {
-            phi = (powf(1.f + u, beta) - 1.f - beta * u) / (beta * (beta - 1.f));
-        }
-        return powf(p, beta) * phi;
+        for (int k = 16; k >= 3; --k) s = fmaf(s, (beta - (float)(k - 1)) * u * (1.f / (float)k), 1.f);
+        const float series = 0.5f * u * u * s;
+        const float direct = (nnf_pow(1.f + u, beta) - 1.f - beta * u) / (beta * (beta - 1.f));
+        const float phi = fabsf(u) < 0.3f ? series : direct;
+        return nnf_pow(p, beta) * phi;
     }
 }

@@ -92,10 +92,12 @@ int nnf_hals_solve_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float*
 
 /* Same sweeps, fixed count, no stopping rule: runs exactly `nsweeps` sweeps and writes the LOCAL sum of squared steps of
  * each sweep to nodelta_f64[0..nsweeps).  Building block of the row-sharded solve (the stopping scalar is all-reduced by
- * the host between chunks). */
+ * the host between chunks).
+ * snapshots (may be NULL): nsweeps blocks of r x ncols floats (row stride ncols, block stride snap_stride elements); block s
+ * receives V after sweep s+1, so an overshoot of the global stopping rule is undone by copying one block (no replay). */
 int nnf_hals_sweeps_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V, int64_t ldv,
                         int r, int64_t ncols, int nsweeps, float sparsity, unsigned flags, double* nodelta_f64,
-                        void* stream);
+                        float* snapshots, int64_t snap_stride, void* stream);
 
 /* mu_betadivmin (mu.py:79-97) for the left factor, transposed storage:
  *   Ut_out[k,i] = max(Ut[k,i] * (num[k,i]/den[k,i])^gamma(beta), 1e-12),

@@ -169,7 +169,7 @@ static int pick_rp(int r) {
 template <int MODE>
 static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V, int64_t ldv,
                       int r, int64_t ncols, int nsweeps, double delta, float sparsity, unsigned flags, double* status,
-                      double* nodelta_out, hipStream_t st) {
+                      double* nodelta_out, hipStream_t st, float* snapshots = nullptr, int64_t snap_stride = 0) {
     if (!ctx || !UtM || !UtU || !V || r < 1 || ncols < 1 || ldm < ncols || ldv < ncols || ldg < r || nsweeps < 0)
         return NNF_ERR_ARG;
     if (MODE == 0 && !status) return NNF_ERR_ARG;
@@ -219,7 +219,8 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     } else {
         if ((((int64_t)(r - 1) * ldv + ncols) * 4) >= (int64_t)0x7fff0000 || (((int64_t)(r - 1) * ldm + ncols) * 4) >= (int64_t)0x7fff0000)
             return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
-        hals_args a{UtM, ldm, Gp, dinv, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status, sweep_partials};
+        hals_args a{UtM, ldm, Gp, dinv, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status, sweep_partials, snapshots,
+                    snap_stride};
         if (RP <= 48) rc = nnf_hals_fast_part0(ctx, RP, a, max_blocks, &nblocks, st);
         else if (RP <= 64) rc = nnf_hals_fast_part1(ctx, RP, a, max_blocks, &nblocks, st);
         else if (RP <= 104) rc = nnf_hals_fast_part2(ctx, RP, a, max_blocks, &nblocks, st);
@@ -243,7 +244,12 @@ extern "C" int nnf_hals_solve_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, c
 
 extern "C" int nnf_hals_sweeps_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V,
                                    int64_t ldv, int r, int64_t ncols, int nsweeps, float sparsity, unsigned flags,
-                                   double* nodelta_f64, void* stream) {
+                                   double* nodelta_f64, float* snapshots, int64_t snap_stride, void* stream) {
+    if (snapshots) {
+        // snapshots are written by the resident fast path only
+        if ((flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) || snap_stride < (int64_t)r * ncols) return NNF_ERR_ARG;
+        if (nnf_cdiv(ncols, 256) > (int64_t)ctx->num_cus) return NNF_ERR_UNSUPPORTED;   // conservative residency bound
+    }
     return hals_entry<1>(ctx, UtM, ldm, UtU, ldg, V, ldv, r, ncols, nsweeps, 0.0, sparsity, flags, nullptr, nodelta_f64,
-                         (hipStream_t)stream);
+                         (hipStream_t)stream, snapshots, snap_stride);
 }

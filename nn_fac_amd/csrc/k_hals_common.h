@@ -136,6 +136,8 @@ struct hals_args {
     hals_sync sy;
     double* status;
     double* sweep_partials;
+    float* snapshots;     // mode 1, optional: V after every sweep, [sweep][r][ncols]
+    int64_t snap_stride;
 };
 
 int nnf_hals_fast_part0(nnf_ctx*, int RP, const hals_args&, int max_blocks_cap, int* nblocks_out, hipStream_t);

@@ -46,7 +46,7 @@ __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const flo
     NNF_SLOAD2D(buf[0][0], buf[0][1], dv[0], base, 0, DOFF);
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};   // four chains: FMA latency > 2 issues
         float di = 0.f;
 #pragma unroll
         for (int blk = 0; blk < NBLK; ++blk) {
@@ -64,14 +64,18 @@ __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const flo
                 NNF_SLOAD2D(buf[nxt][0], buf[nxt][1], dv[(k + 1) & 1], base, (k + 1) * RS, DOFF + k + 1);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 8; j += 2) {
                 if (16 * blk + j < P)
                     a0 = __builtin_elementwise_fma(f32x2{buf[cur][0][2 * j], buf[cur][0][2 * j + 1]}, v2[16 * blk + j], a0);
                 if (16 * blk + 8 + j < P)
                     a1 = __builtin_elementwise_fma(f32x2{buf[cur][1][2 * j], buf[cur][1][2 * j + 1]}, v2[16 * blk + 8 + j], a1);
+                if (16 * blk + j + 1 < P)
+                    a2 = __builtin_elementwise_fma(f32x2{buf[cur][0][2 * j + 2], buf[cur][0][2 * j + 3]}, v2[16 * blk + j + 1], a2);
+                if (16 * blk + 8 + j + 1 < P)
+                    a3 = __builtin_elementwise_fma(f32x2{buf[cur][1][2 * j + 2], buf[cur][1][2 * j + 3]}, v2[16 * blk + 8 + j + 1], a3);
             }
         }
-        const f32x2 a = a0 + a1;
+        const f32x2 a = (a0 + a1) + (a2 + a3);
         const float dot = a[0] + a[1];
         float bk;
         if constexpr (KEEPB) {
@@ -156,6 +160,14 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
         const double bs = nnf_block_sum_f64(nd, red);
         if (a.mode == 1) {
             if (threadIdx.x == 0) a.sweep_partials[(size_t)(s - 1) * nblocks + blockIdx.x] = bs;
+            if constexpr (RES) {
+                if (a.snapshots != nullptr && gtid < a.ncols) {   // V after sweep s (fire-and-forget stores)
+                    float* sp_ = a.snapshots + (size_t)(s - 1) * a.snap_stride + gtid;
+#pragma unroll
+                    for (int k = 0; k < RP; ++k)
+                        if (k < a.r) sp_[(int64_t)k * a.ncols] = v2[k / 2][k & 1];
+                }
+            }
             done = s;
             continue;
         }

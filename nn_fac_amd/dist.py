@@ -38,22 +38,35 @@ def shard_rows(m, rank, nranks):
 
 
 class SweepGuess:
-    """Chunk length memory for the sharded solve (one per factor)."""
+    """Per-factor state of the sharded solve: chunk length memory and the reusable snapshot buffer."""
 
-    def __init__(self, first=8):
+    def __init__(self, first=16, max_chunk=48):
         self.value = first
+        self.max_chunk = max_chunk
+        self.snap = None
+
+    def snapshots(self, F, C):
+        if self.snap is None or self.snap.shape[0] < C or tuple(self.snap.shape[1:]) != tuple(F.shape) \
+                or self.snap.device != F.device or self.snap.dtype != F.dtype:
+            self.snap = torch.empty((max(C, min(self.max_chunk, 16)),) + tuple(F.shape), dtype=F.dtype, device=F.device)
+        return self.snap
 
 
 def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01, sparsity=None):
     """In-place HALS on the local columns F (r x m_local) with the GLOBAL stopping rule.  Returns (eps, cnt, eps0) of
-    the reference (cnt = sweeps + 1).  normalize / nonzero need row-level reductions across shards: not supported."""
+    the reference (cnt = sweeps + 1).  normalize / nonzero need row-level reductions across shards: not supported.
+
+    Chunks of C sweeps run blind; the kernel records every sweep's local sum of squared steps and a snapshot of F after
+    every sweep.  ONE all-reduce per chunk locates the sweep at which the reference stops; if that is before the end of the
+    chunk, F is restored from that sweep's snapshot (bitwise what a straight run would hold)."""
     done, eps0, eps = 0, 0.0, 1.0
     if budget < 1:
         return 1.0, 1, 0.0
+    C = max(1, min(int(guess.value), guess.max_chunk, budget))
     while done < budget:
-        C = max(1, min(int(guess.value), budget - done))
-        backup = F.clone()
-        nd = eng.hals_sweeps(cross, gram, F, C, sparsity=sparsity)
+        C = max(1, min(C, budget - done))
+        snap = guess.snapshots(F, C)
+        nd = eng.hals_sweeps(cross, gram, F, C, sparsity=sparsity, snapshots=snap)
         allreduce_(nd, group)
         ndh = nd.cpu().tolist()                    # one host round trip per chunk
         stop = None
@@ -66,11 +79,11 @@ def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01
                 break
         if stop is None:
             done += C
+            C = min(guess.max_chunk, 2 * C)        # keep going with longer chunks
             continue
-        if stop < C - 1:                           # overshoot: replay exactly stop+1 sweeps
-            F.copy_(backup)
-            eng.hals_sweeps(cross, gram, F, stop + 1, sparsity=sparsity)
+        if stop < C - 1:                           # overshoot: take the snapshot after sweep stop+1
+            F.copy_(snap[stop])
         done += stop + 1
         break
-    guess.value = max(1, done)
+    guess.value = max(8, min(done + 4, guess.max_chunk))
     return eps, done + 1, eps0

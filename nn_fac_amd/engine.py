@@ -138,14 +138,21 @@ class Engine:
                                                self._stream()), "nnf_hals_solve_f32")
         return st
 
-    def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False):
-        """Exactly `nsweeps` in-place sweeps; returns the per-sweep LOCAL sum of squared steps (float64, device)."""
+    def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False, snapshots=None):
+        """Exactly `nsweeps` in-place sweeps; returns the per-sweep LOCAL sum of squared steps (float64, device).
+        snapshots (optional, contiguous float32 [>= nsweeps, r, ncols]): block s receives V after sweep s+1."""
         _chk2d(UtM, "hals UtM"), _chk2d(UtU, "hals UtU"), _chk2d(V, "hals V")
         r, ncols = V.shape
         nd = torch.zeros(max(int(nsweeps), 1), dtype=torch.float64, device=V.device)
+        sp, ss = C.c_void_p(0), 0
+        if snapshots is not None:
+            if (snapshots.dtype != torch.float32 or not snapshots.is_contiguous() or snapshots.dim() != 3
+                    or snapshots.shape[0] < nsweeps or tuple(snapshots.shape[1:]) != (r, ncols)):
+                raise EngineError("hals_sweeps: snapshots must be a contiguous float32 [>= nsweeps, r, ncols] tensor")
+            sp, ss = _ptr(snapshots), snapshots.stride(0)
         _lib.check(self.lib.nnf_hals_sweeps_f32(self.ctx, _ptr(UtM), UtM.stride(0), _ptr(UtU), UtU.stride(0), _ptr(V),
                                                 V.stride(0), r, ncols, int(nsweeps), float(sparsity or 0.0),
-                                                self._hals_flags(sparsity, normalize, nonzero), _ptr(nd),
+                                                self._hals_flags(sparsity, normalize, nonzero), _ptr(nd), sp, ss,
                                                 self._stream()), "nnf_hals_sweeps_f32")
         return nd[:int(nsweeps)]
 

@@ -37,11 +37,15 @@ class OracleEngine:
         c = torch.sum((X - Ut.T @ V) ** 2).reshape(1)
         return c if out is None else out.copy_(c)
 
-    def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False):
+    def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False, snapshots=None):
         log = []
-        Vn, *_ = orc.hals_nnls_acc(UtM.numpy(), UtU.numpy(), V.numpy(), maxiter=nsweeps, alpha=math.inf, delta=0.0,
-                                   sparsity_coefficient=sparsity, sweep_log=log)
-        V.copy_(torch.from_numpy(Vn))
+        cur = V.numpy().copy()
+        for s in range(nsweeps):   # one sweep at a time so that every intermediate V can be snapshotted
+            cur, *_ = orc.hals_nnls_acc(UtM.numpy(), UtU.numpy(), cur, maxiter=1, alpha=math.inf, delta=0.0,
+                                        sparsity_coefficient=sparsity, sweep_log=log)
+            if snapshots is not None:
+                snapshots[s].copy_(torch.from_numpy(cur))
+        V.copy_(torch.from_numpy(cur))
         return torch.tensor(log, dtype=torch.float64)
 
     def hals_solve(self, UtM, UtU, V, max_sweeps, delta=0.01, sparsity=None, normalize=False, nonzero=False,
@@ -63,7 +67,7 @@ class _Bufs:
         self.G, self.G2 = torch.empty((r, r), **kw), torch.empty((r, r), **kw)
         self.block = torch.zeros(24, **kw)
         self.cost = self.block[16:17]
-        self.guess_u = nd.SweepGuess(first=3)     # small on purpose: exercises continue, exact-stop and replay
+        self.guess_u = nd.SweepGuess(first=3, max_chunk=5)   # small on purpose: exercises continue, exact stop, overshoot
 
 
 def _worker(rank, nranks, port, m, n, r, iters, sparsity, q):

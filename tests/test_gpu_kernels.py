@@ -232,3 +232,31 @@ def test_mu_dropin_signatures(golden):
         assert rel(mu_betadivmin(U, V, M, b), g[f"muU_b{b}"]) < 2e-5
         assert abs(beta_divergence(M, U @ V, b) - float(g[f"div_b{b}"])) <= 1e-5 * abs(float(g[f"div_b{b}"]))
         assert gamma_beta(b) == float(g[f"gamma_b{b}"])
+
+
+def test_hals_sweep_snapshots(eng):
+    """nnf_hals_sweeps_f32 with snapshots: block s must hold V after sweep s+1 (what a shorter run would return)."""
+    rng = np.random.RandomState(8)
+    r, n = 24, 5000
+    A = rng.rand(96, r)
+    UtU, UtM, V0 = dev(A.T @ A), dev(A.T @ (A @ rng.rand(r, n))), dev(rng.rand(r, n))
+    snaps = torch.empty((5, r, n), dtype=torch.float32, device="cuda")
+    Vfull = V0.clone()
+    nd = eng.hals_sweeps(UtM, UtU, Vfull, 5, snapshots=snaps)
+    assert torch.equal(snaps[4], Vfull)
+    for k in (1, 3):
+        Vk = V0.clone()
+        ndk = eng.hals_sweeps(UtM, UtU, Vk, k)
+        assert torch.equal(snaps[k - 1], Vk)                    # bitwise: the kernels are deterministic
+        assert torch.equal(ndk, nd[:k])
+
+
+def test_row_sharded_two_ranks_on_one_gpu(built_lib):
+    """Two gloo ranks sharing the GPU run the real sharded step (tools/dist_gpu_check.py) against the single-process run."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29533", os.path.join(root, "tools", "dist_gpu_check.py")],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert "DIST_GPU_CHECK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -26,7 +26,8 @@ __global__ void nnf_hals_prep_kernel(const float* __restrict__ UtU, int64_t ldg,
     }
     for (int k = threadIdx.x; k < RP; k += blockDim.x) {
         const float d = (k < r) ? UtU[(int64_t)k * ldg + k] : 0.f;
-        dinv[k] = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;
+        dinv[2 * k] = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;   // pair (1/diag, nz): nz = 0 = leave the row alone
+        dinv[2 * k + 1] = (d != 0.f) ? 1.f : 0.f;
     }
     if (threadIdx.x == 0) {
         *counter = 0u;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
     for (int s = 1; s <= max_sweeps && ok; ++s) {
         double nd = 0.0;
         for (int k = 0; k < r; ++k) {
-            const float di = dinv[k];
+            const float di = dinv[2 * k];
             if (di != 0.f) {
                 float dot = 0.f;
                 for (int i = 0; i < r; ++i) dot = fmaf(Gp[k * RP + i], mycol[i * 128], dot);
@@ -181,7 +182,7 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     const int max_blocks = 3 * ctx->num_cus > 2048 ? 3 * ctx->num_cus : 2048;
     nnf_ws_cursor cur(ctx);
     const int RS = 32 * ((RP + 31) / 32);
-    float* Gp = (float*)cur.take((size_t)(RP * RS + RP) * 4);   // padded Gram immediately followed by 1/diag
+    float* Gp = (float*)cur.take((size_t)(RP * RS + 2 * RP) * 4);   // padded Gram, then the (1/diag, nz) pairs
     float* dinv = Gp ? Gp + (size_t)RP * RS : nullptr;
     unsigned* counter = (unsigned*)cur.take(256);
     double* slots = (double*)cur.take((size_t)2 * max_blocks * 4 * 8);

@@ -8,6 +8,7 @@
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 // Scalar (SMEM) loads issued by hand.  SMEM returns out of order, so the only usable wait is lgkmcnt(0) and hipcc cannot
 // software-pipeline such loads itself (it sinks every load to its use: one exposed scalar-cache round trip per 16 values).
@@ -22,14 +23,126 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NNF_SWAIT2(d0, d1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1))
 #define NNF_SWAIT3(d0, d1, dd) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1), "+s"(dd))
 
+// ---- scalar-cache operand buffers -------------------------------------------------------------------------
+// W floats of a Gram row held in SGPRs as 16/8/4-dword pieces (s_load_dwordx16/x8/x4).  Scalar loads return out of
+// order, so the only usable wait is lgkmcnt(0): the schedule below is built so that everything outstanding at a wait
+// was issued at least ~half a row of FMAs earlier (tools/smem_probe.hip: ~60 ns for two x16 hits, ~105 ns from L2).
+template <int W>
+struct sgbuf {
+    f32x16 a, b;
+    f32x8 q;
+    f32x4 r;
+};
+template <int W, bool TIED>
+__device__ __forceinline__ void sg_issue(sgbuf<W>& d, uint64_t base, int off) {
+    constexpr int N16 = W / 16, N8 = (W % 16) / 8, N4 = (W % 8) / 4;
+    static_assert(W % 4 == 0 && N16 <= 2, "piece decomposition");
+    // TIED: the destination registers are the ones that held the previous row's piece (consumed just above)
+    if constexpr (TIED) {
+        if constexpr (N16 >= 1) asm volatile("s_load_dwordx16 %0, %1, %2" : "+s"(d.a) : "s"(base), "i"(off * 4));
+        if constexpr (N16 >= 2) asm volatile("s_load_dwordx16 %0, %1, %2" : "+s"(d.b) : "s"(base), "i"(off * 4 + 64));
+        if constexpr (N8 == 1) asm volatile("s_load_dwordx8 %0, %1, %2" : "+s"(d.q) : "s"(base), "i"(off * 4 + 64 * N16));
+        if constexpr (N4 == 1) asm volatile("s_load_dwordx4 %0, %1, %2" : "+s"(d.r) : "s"(base), "i"(off * 4 + 64 * N16 + 32 * N8));
+    } else {
+        if constexpr (N16 >= 1) asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(d.a) : "s"(base), "i"(off * 4));
+        if constexpr (N16 >= 2) asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(d.b) : "s"(base), "i"(off * 4 + 64));
+        if constexpr (N8 == 1) asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(d.q) : "s"(base), "i"(off * 4 + 64 * N16));
+        if constexpr (N4 == 1) asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(d.r) : "s"(base), "i"(off * 4 + 64 * N16 + 32 * N8));
+    }
+}
+// after s_waitcnt: tell the compiler the pieces now hold their loaded values (nothing may be read above this point)
+template <int W>
+__device__ __forceinline__ void sg_arrived(sgbuf<W>& d) {
+    constexpr int N16 = W / 16, N8 = (W % 16) / 8, N4 = (W % 8) / 4;
+    if constexpr (N16 >= 1) asm volatile("" : "+s"(d.a));
+    if constexpr (N16 >= 2) asm volatile("" : "+s"(d.b));
+    if constexpr (N8 == 1) asm volatile("" : "+s"(d.q));
+    if constexpr (N4 == 1) asm volatile("" : "+s"(d.r));
+}
+template <int W>
+__device__ __forceinline__ f32x2 sg_pair(const sgbuf<W>& d, int p) {   // floats 2p, 2p+1 of the buffer
+    constexpr int N16 = W / 16, N8 = (W % 16) / 8;
+    const int j = 2 * p;
+    if (N16 >= 1 && j < 16) return f32x2{d.a[j], d.a[j + 1]};
+    if (N16 >= 2 && j < 32) return f32x2{d.b[j - 16], d.b[j - 15]};
+    const int j2 = j - 16 * N16;
+    if (N8 == 1 && j2 < 8) return f32x2{d.q[j2], d.q[j2 + 1]};
+    const int j3 = j2 - 8 * N8;
+    return f32x2{d.r[j3], d.r[j3 + 1]};
+}
+
+// One Gauss-Seidel sweep for 32 < R <= 64 with the UtM column resident (b already holds UtM - sp).
+// A Gram row is split into X = columns [0, XW) and Y = columns [XW, XW+24).  Y is double-buffered and fetched a whole
+// row ahead; X is single-buffered and refilled for the next row as soon as its FMAs have issued, i.e. before the Y
+// part and the row bookkeeping -- so the single lgkmcnt(0) per row finds both in (or nearly in) the registers.
+// The row update is the reference's statement order (nnls.py:162-170): d = max(x, -v[k]); v[k] += d; nodelta += d*d;
+// rows with a zero Gram diagonal (and the padding rows) carry the pair (1/diag, nz) = (0, 0), which forces d = 0.
+template <int R>
+__device__ __forceinline__ float hals_sweep_column_xy(f32x2 (&v2)[R / 2], const float (&b)[R], const float* __restrict__ Gp) {
+    constexpr int RS = 64, P = R / 2, YW = 24, XW = (R - YW + 3) & ~3, XP = XW / 2, DOFF = R * RS;
+    static_assert(YW == 24, "the Y issue statement below is written for x16 + x8");
+    static_assert(R > 32 && R <= 64 && XW + YW <= RS && XW >= 8, "row split");
+    const uint64_t base = (uint64_t)Gp;
+    sgbuf<XW> X;
+    sgbuf<YW> Y[2];
+    f32x2 dv[2];
+    float nd = 0.f;
+    sg_issue<XW, false>(X, base, 0);
+    sg_issue<YW, false>(Y[0], base, XW);
+    asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(dv[0]) : "s"(base), "i"(DOFF * 4));
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int cur = k & 1, nxt = cur ^ 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dv[cur]));
+        sg_arrived<XW>(X);
+        sg_arrived<YW>(Y[cur]);
+        if (k + 1 < R)   // one statement, so that all three are issued here and not wherever the scheduler sinks them
+            asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx8 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6"
+                         : "=s"(Y[nxt].a), "=s"(Y[nxt].q), "=s"(dv[nxt])
+                         : "s"(base), "i"(((k + 1) * RS + XW) * 4), "i"(((k + 1) * RS + XW + 16) * 4), "i"((DOFF + 2 * (k + 1)) * 4));
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+            const f32x2 g = sg_pair<XW>(X, p);
+            if ((p & 3) == 0) a0 = __builtin_elementwise_fma(g, v2[p], a0);
+            if ((p & 3) == 1) a1 = __builtin_elementwise_fma(g, v2[p], a1);
+            if ((p & 3) == 2) a2 = __builtin_elementwise_fma(g, v2[p], a2);
+            if ((p & 3) == 3) a3 = __builtin_elementwise_fma(g, v2[p], a3);
+        }
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));   // X is consumed: its registers may be refilled
+        if (k + 1 < R) sg_issue<XW, true>(X, base, (k + 1) * RS);
+#pragma unroll
+        for (int p = XP; p < P; ++p) {
+            const f32x2 g = sg_pair<YW>(Y[cur], p - XP);
+            if ((p & 3) == 0) a0 = __builtin_elementwise_fma(g, v2[p], a0);
+            if ((p & 3) == 1) a1 = __builtin_elementwise_fma(g, v2[p], a1);
+            if ((p & 3) == 2) a2 = __builtin_elementwise_fma(g, v2[p], a2);
+            if ((p & 3) == 3) a3 = __builtin_elementwise_fma(g, v2[p], a3);
+        }
+        const f32x2 a = (a0 + a1) + (a2 + a3);
+        const float dot = a[0] + a[1];
+        const float di = dv[cur][0], nz = dv[cur][1];
+        const float vk = v2[k / 2][k & 1];
+        const float x = (b[k] - dot) * di;
+        float dl;   // max(x, -v[k]) in one instruction (fmaxf adds a canonicalising max for the negated operand)
+        asm("v_max_f32 %0, %1, -%2" : "=v"(dl) : "v"(x), "v"(vk));
+        dl *= nz;
+        v2[k / 2][k & 1] = vk + dl;
+        nd = fmaf(dl, dl, nd);
+        asm volatile("" : "+v"(nd));  // finish this row's bookkeeping here (otherwise it is sunk to the end of the sweep)
+    }
+    return nd;
+}
+
 // One Gauss-Seidel sweep (nnls.py:158-170) over the column held in v2 = {(v[0],v[1]), (v[2],v[3]), ...}.
 //   x     = (UtM[k] - UtU[k,:].v - sp) / UtU[k,k]
 //   v[k] <- max(v[k] + x, 0)            (== v[k] + max(x, -v[k]) of the reference, same rounding)
 //   step  = x if not clipped else -v[k]
-// Gp: padded Gram, row stride RS = 32*ceil(R/32) floats (zeros past r), followed by 1/diag (R floats, 0 = skip row).
+// Gp: padded Gram, row stride RS = 32*ceil(R/32) floats (zeros past r), followed by R pairs (1/diag, nz): (0, 0) = skip row.
 template <int R, bool KEEPB>
 __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const float (&b)[KEEPB ? R : 1], rsrc_t rb, int voff,
                                                    int ldm4, const float* __restrict__ Gp, float sp) {
+    if constexpr (KEEPB && R > 32 && R <= 64) return hals_sweep_column_xy<R>(v2, b, Gp);
     constexpr int NBLK = (R + 31) / 32, RS = 32 * NBLK, P = R / 2, DOFF = R * RS;
     const uint64_t base = (uint64_t)Gp;
     f32x16 buf[2][2];
@@ -61,7 +174,7 @@ __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const flo
             if (blk + 1 < NBLK) {
                 NNF_SLOAD2(buf[nxt][0], buf[nxt][1], base, k * RS + 32 * (blk + 1));
             } else if (k + 1 < R) {
-                NNF_SLOAD2D(buf[nxt][0], buf[nxt][1], dv[(k + 1) & 1], base, (k + 1) * RS, DOFF + k + 1);
+                NNF_SLOAD2D(buf[nxt][0], buf[nxt][1], dv[(k + 1) & 1], base, (k + 1) * RS, DOFF + 2 * (k + 1));
             }
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {

@@ -15,6 +15,7 @@
 //   stores (no cross-workgroup hand-off of V is ever needed).
 // Generic path (NORMALIZE / NONZERO, any r): columns in LDS, run-time rank loop, one grid reduction per row.
 #include "k_hals_common.h"
+#include <cstdlib>
 
 // prep: padded Gram, 1/diag, zeroed barrier words and status
 __global__ void nnf_hals_prep_kernel(const float* __restrict__ UtU, int64_t ldg, int r, int RP, float* __restrict__ Gp,
@@ -182,7 +183,16 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     const int max_blocks = 3 * ctx->num_cus > 2048 ? 3 * ctx->num_cus : 2048;
     nnf_ws_cursor cur(ctx);
     const int RS = 32 * ((RP + 31) / 32);
-    float* Gp = (float*)cur.take((size_t)(RP * RS + 2 * RP) * 4);   // padded Gram, then the (1/diag, nz) pairs
+    const bool generic = (flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) != 0;
+    // few columns: four lanes per column (k_hals_quad.hip); many: one lane per column (k_hals_fast.hip)
+    // NNF_HALS_FORCE=lane|quad pins the column layout (tests exercise both kernels on the same fixtures)
+    const char* force = getenv("NNF_HALS_FORCE");
+    const bool force_lane = force && force[0] == 'l', force_quad = force && force[0] == 'q';
+    const bool quad = !generic && !force_lane && (ncols <= 32768 || force_quad) && (int64_t)(r + 16) * (ldv > ldm ? ldv : ldm) * 4 < (int64_t)0x7fff0000 &&
+                      nnf_hals_quad_fits(ctx, r, ncols, max_blocks);
+    size_t gfloats = (size_t)RP * RS + 2 * RP;
+    if (quad && nnf_hals_quad_gram_floats(r) > gfloats) gfloats = nnf_hals_quad_gram_floats(r);
+    float* Gp = (float*)cur.take(gfloats * 4);   // padded Gram, then the (1/diag, nz) pairs (quad: scaled Gram, 1/diag)
     float* dinv = Gp ? Gp + (size_t)RP * RS : nullptr;
     unsigned* counter = (unsigned*)cur.take(256);
     double* slots = (double*)cur.take((size_t)2 * max_blocks * 4 * 8);
@@ -191,16 +201,25 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     if (MODE == 1) sweep_partials = (double*)cur.take((size_t)(nsweeps > 0 ? nsweeps : 1) * max_blocks * 8);
     if (!Gp || !dinv || !counter || !slots || !sslots || (MODE == 1 && !sweep_partials))
         return NNF_ERR_WORKSPACE;
-    hipLaunchKernelGGL(nnf_hals_prep_kernel, dim3(1), dim3(256), 0, st, UtU, ldg, r, RP, Gp, dinv, counter,
-                       MODE == 0 ? status : (double*)nullptr);
-    NNF_CHECK_LAUNCH();
-    if (nsweeps == 0) return NNF_OK;
+    if (!quad) {
+        hipLaunchKernelGGL(nnf_hals_prep_kernel, dim3(1), dim3(256), 0, st, UtU, ldg, r, RP, Gp, dinv, counter,
+                           MODE == 0 ? status : (double*)nullptr);
+        NNF_CHECK_LAUNCH();
+        if (nsweeps == 0) return NNF_OK;
+    }
     ctx->hals_epoch = (ctx->hals_epoch + 1u) & 0x3fffffu;   // tag = epoch*1024 + sweep stays below 2^32
     if (ctx->hals_epoch == 0u) ctx->hals_epoch = 1u;
     hals_sync sy{counter, slots, sslots, ctx->hals_epoch};
     int nblocks = 0, rc = NNF_OK;
-    const bool generic = (flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) != 0;
-    if (generic) {
+    if (quad) {
+        if ((((int64_t)(r - 1) * ldv + ncols) * 4) >= (int64_t)0x7fff0000 || (((int64_t)(r - 1) * ldm + ncols) * 4) >= (int64_t)0x7fff0000)
+            return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+        hals_args a{UtM, ldm, nullptr, nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status, sweep_partials, snapshots,
+                    snap_stride};
+        rc = nnf_hals_quad_run(ctx, UtU, ldg, Gp, counter, a, &nblocks, st);
+        if (rc != NNF_OK) return rc;
+        if (nsweeps == 0) return NNF_OK;
+    } else if (generic) {
         // one column per thread, all workgroups resident (row-level grid reductions)
         const size_t shm = (size_t)r * 128 * 4 + 16 + 3 * 2 * 8 + 64;
         hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_generic_kernel<MODE>),

@@ -102,9 +102,14 @@ def _kw(vec):
     return kw
 
 
-def test_hals_against_reference_fixtures(golden):
-    """hals_nnls_acc through the drop-in signature vs the reference outputs stored in g1 (57 cases)."""
+LAYOUTS = ["lane", "quad"]      # one lane per column (k_hals_fast.hip) / four lanes per column (k_hals_quad.hip)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_hals_against_reference_fixtures(golden, layout, monkeypatch):
+    """hals_nnls_acc through the drop-in signature vs the reference outputs stored in g1 (57 cases), both kernels."""
     from nn_fac_amd.update_rules.nnls import hals_nnls_acc
+    monkeypatch.setenv("NNF_HALS_FORCE", layout)
     g = golden("g1_hals.npz")
     bad = []
     for c in range(int(g["ncases"])):
@@ -136,6 +141,27 @@ def test_hals_zero_column_raises():
     assert V.shape == (15, 1)
 
 
+@pytest.mark.parametrize("r", [12, 50])
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_hals_zero_diagonal_row_is_left_alone(eng, layout, r, monkeypatch):
+    """nnls.py:160: a row whose Gram diagonal is 0 is skipped whatever it holds (negative entries included), and the
+    other rows keep seeing its values through the off-diagonal Gram entries."""
+    monkeypatch.setenv("NNF_HALS_FORCE", layout)
+    rng = np.random.RandomState(11)
+    n = 700
+    A = rng.rand(4 * r, r)
+    UtU = A.T @ A
+    UtU[5, 5] = 0.0
+    UtM, V0 = A.T @ rng.rand(4 * r, n), rng.rand(r, n)
+    V0[5] = -rng.rand(n)
+    Vo, epso, cnto, _ = orc.hals_nnls_acc(UtM, UtU, V0, maxiter=30, alpha=math.inf, delta=0.01)
+    Vd = dev(V0)
+    st = eng.hals_solve(dev(UtM), dev(UtU), Vd, 30, delta=0.01).cpu()
+    got = Vd.cpu().numpy()
+    assert np.array_equal(got[5], V0[5].astype(np.float32))
+    assert int(st[1]) == cnto and rel(got, Vo) < 2e-4
+
+
 def test_hals_does_not_modify_inputs(eng):
     from nn_fac_amd.update_rules.nnls import hals_nnls_acc
     r = np.random.RandomState(1)
@@ -146,9 +172,13 @@ def test_hals_does_not_modify_inputs(eng):
     assert torch.equal(V0, keep) and isinstance(V, torch.Tensor) and V.is_cuda and not torch.equal(V, V0)
 
 
-@pytest.mark.parametrize("r,ncols", [(50, 100000), (100, 20000), (30, 500), (50, 300000)])
-def test_hals_large_vs_oracle(eng, r, ncols):
+@pytest.mark.parametrize("r,ncols,layout", [(50, 100000, "lane"), (100, 20000, "lane"), (30, 500, "lane"), (50, 300000, "lane"),
+                                            (30, 500, "quad"), (50, 2000, "quad"), (96, 8000, "quad"), (70, 16000, "quad"),
+                                            (100, 20000, "auto")])
+def test_hals_large_vs_oracle(eng, r, ncols, layout, monkeypatch):
     """Resident and strided (ncols > resident threads) persistent solves vs the fp64 oracle; sweep counts equal."""
+    if layout != "auto":
+        monkeypatch.setenv("NNF_HALS_FORCE", layout)
     rng = np.random.RandomState(r + ncols)
     A = rng.rand(4 * r, r)
     cols = min(ncols, 4000)                     # oracle on a slice is not possible (global stop rule) -> tile the problem
@@ -170,7 +200,9 @@ def test_hals_large_vs_oracle(eng, r, ncols):
     assert abs(float(st[0]) - reps * epso) <= 5e-3 * reps * epso
 
 
-def test_hals_fixed_sweeps_mode(eng):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_hals_fixed_sweeps_mode(eng, layout, monkeypatch):
+    monkeypatch.setenv("NNF_HALS_FORCE", layout)
     rng = np.random.RandomState(3)
     r, n = 20, 3000
     A = rng.rand(80, r)
@@ -234,8 +266,10 @@ def test_mu_dropin_signatures(golden):
         assert gamma_beta(b) == float(g[f"gamma_b{b}"])
 
 
-def test_hals_sweep_snapshots(eng):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_hals_sweep_snapshots(eng, layout, monkeypatch):
     """nnf_hals_sweeps_f32 with snapshots: block s must hold V after sweep s+1 (what a shorter run would return)."""
+    monkeypatch.setenv("NNF_HALS_FORCE", layout)
     rng = np.random.RandomState(8)
     r, n = 24, 5000
     A = rng.rand(96, r)

@@ -56,6 +56,15 @@ def main():
         F = V.clone()
         ms = timeit(lambda: eng.hals_solve(VtM, VtV, F, k, delta=0.0), reps=5)
         print(f"hals_solve V-side x{k:<3d} {ms*1e3:9.1f} us  ({ms*1e3/k:7.1f} us/sweep)")
+    F = V.clone()
+    ms = timeit(lambda: eng.hals_sweeps(VtM, VtV, F, 100), reps=5)
+    print(f"hals_sweeps V-side x100 (no exchange) {ms*1e3:9.1f} us  ({ms*10:7.1f} us/sweep)")
+    import os
+    os.environ["NNF_HALS_FORCE"] = "lane"
+    F = V.clone()
+    ms = timeit(lambda: eng.hals_solve(VtM, VtV, F, 100, delta=0.0), reps=5)
+    print(f"hals_solve V-side x100 lane layout {ms*1e3:9.1f} us  ({ms*10:7.1f} us/sweep)")
+    del os.environ["NNF_HALS_FORCE"]
     # full NMF iterations
     from nn_fac_amd.nmf import compute_nmf
     U0 = torch.rand(m, r, device="cuda", generator=g)

@@ -93,27 +93,53 @@ __device__ __forceinline__ void hals_publish(const hals_sync& sy, int s, int nbl
         __hip_atomic_store(g + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// The granule loads of a collect can be issued a whole sweep ahead of their use (lag-one speculation: the sum of sweep
+// s-1 is only needed after sweep s has been computed): hals_collect_issue() starts them, hals_collect() consumes them
+// and falls back to re-reading (bounded spin) any granule whose tag had not arrived yet.  Every workgroup adds the
+// partials in the same order (thread-strided by index, DPP wave sum, waves in index order): same double everywhere.
+constexpr int HALS_PF = 2;   // granule pairs per thread that can be in flight (covers nblocks <= 2 * blockDim.x)
+struct hals_prefetch {
+    unsigned long long g0[HALS_PF], g1[HALS_PF];
+    int s;   // sweep the granules belong to (0: nothing issued)
+};
+__device__ __forceinline__ void hals_collect_issue(const hals_sync& sy, int s, int nblocks, hals_prefetch& pf) {
+    const unsigned long long* base = reinterpret_cast<const unsigned long long*>(sy.sslots) + (size_t)s * nblocks * 2;
+    pf.s = s;
+#pragma unroll
+    for (int i = 0; i < HALS_PF; ++i) {
+        const int b = threadIdx.x + i * blockDim.x;
+        pf.g0[i] = pf.g1[i] = 0ull;
+        if (b < nblocks) {
+            pf.g0[i] = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pf.g1[i] = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 __device__ __forceinline__ bool hals_collect(const hals_sync& sy, int s, int nblocks, double& total, double* red,
-                                             unsigned* lds_flag) {
+                                             unsigned* lds_flag, const hals_prefetch* pf = nullptr) {
     if (threadIdx.x == 0) *lds_flag = 1u;
     __syncthreads();
     const unsigned tag = sy.epoch * 1024u + (unsigned)s;
     const unsigned long long* base = reinterpret_cast<const unsigned long long*>(sy.sslots) + (size_t)s * nblocks * 2;
     double v = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-        unsigned long long g0, g1;
+    int i = 0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x, ++i) {
+        unsigned long long g0 = 0ull, g1 = 0ull;
+        if (pf != nullptr && pf->s == s) {   // prefetched copy (tag 0 never matches: epochs start at 1)
+#pragma unroll
+            for (int u = 0; u < HALS_PF; ++u)
+                if (u == i) { g0 = pf->g0[u]; g1 = pf->g1[u]; }
+        }
         unsigned spins = 0;
-        for (;;) {
+        while (!((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag)) {
+            if (spins > 0) __builtin_amdgcn_s_sleep(1);
+            if (++spins > HALS_SPIN_LIMIT) { *lds_flag = 0u; break; }
             g0 = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             g1 = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > HALS_SPIN_LIMIT) { *lds_flag = 0u; break; }
         }
         v += __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xffffffffull));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    v = nnf_wave_sum_f64(v);
     const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     if ((threadIdx.x & 63) == 0) red[w] = v;
     __syncthreads();

@@ -247,6 +247,11 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
     };
     const int voff0 = gtid < a.ncols ? (int)(gtid * 4) : (int)0x7ffffff0;
     if constexpr (RES) load_col(voff0);
+    // Speculation needs "V after the last confirmed sweep" when a stop arrives one sweep late.  Small ranks keep it in
+    // a second set of registers (one copy per sweep, V is written to memory once, at the end); larger ranks have no room
+    // and store V after every confirmed sweep instead (20 MB of stores per sweep at B's U side).
+    constexpr bool BACKUP = RES && RP <= 64;
+    f32x2 vb[BACKUP ? RP / 2 : 1];
 
     // Sweep loop.  mode 1: fixed count, per-sweep local partials, nothing to decide.
     // mode 0, resident columns: lag-one speculation.  After sweep s the workgroup publishes its partial and goes straight
@@ -257,9 +262,19 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
     double eps0 = 0.0, eps = 1.0;
     int done = 0;
     bool ok = true, stopped = false;
+    hals_prefetch pf;
+    pf.s = 0;
     for (int s = 1; s <= a.max_sweeps; ++s) {
         double nd = 0.0;
+        if constexpr (BACKUP) {
+            if (a.mode == 0) {
+#pragma unroll
+                for (int k = 0; k < RP / 2; ++k) vb[k] = v2[k];   // V after sweep s-1
+            }
+        }
         if constexpr (RES) {
+            if constexpr (RP <= 96)   // (the resident pair of columns leaves no registers for it beyond that)
+                if (a.mode == 0 && s >= 2) hals_collect_issue(a.sy, s - 1, nblocks, pf);   // consumed after this sweep
             const float f = hals_sweep_column<RP, KEEPB>(v2, b, rb, voff0, ldm4, a.Gp, a.sp);
             nd = gtid < a.ncols ? (double)f : 0.0;
         } else {
@@ -288,14 +303,23 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
         const int c = RES ? s - 1 : s;          // sweep whose global sum is examined now
         if (c >= 1) {
             double tot;
-            ok = hals_collect(a.sy, c, nblocks, tot, red, &lds_flag);
+            ok = hals_collect(a.sy, c, nblocks, tot, red, &lds_flag, &pf);
             if (!ok) break;
             if (c == 1) eps0 = tot;
             eps = tot;
             done = c;
             if (!(eps >= a.delta * eps0)) { stopped = true; break; }   // nnls.py:156: sweep c was the last one
         }
-        if constexpr (RES) store_col(voff0);    // V after sweep s (sweep s-1 said "go on")
+        if constexpr (RES && !BACKUP) store_col(voff0);    // V after sweep s (sweep s-1 said "go on")
+    }
+    if constexpr (BACKUP) {
+        if (a.mode == 0) {
+            if (stopped || !ok) {   // the registers hold one sweep too many: fall back to the copy
+#pragma unroll
+                for (int k = 0; k < RP / 2; ++k) v2[k] = vb[k];
+            }
+            if (a.max_sweeps >= 1) store_col(voff0);
+        }
     }
     if (a.mode == 1) {
         if constexpr (RES) store_col(voff0);

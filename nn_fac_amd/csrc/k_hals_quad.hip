@@ -187,7 +187,15 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
     double eps0 = 0.0, eps = 1.0;
     int done = 0;
     bool ok = true, stopped = false;
+    hals_prefetch pf;
+    pf.s = 0;
+    float vb[CH];   // V after the last confirmed sweep (a late "stop" falls back to it; V is stored once, at the end)
     for (int s = 1; s <= a.max_sweeps; ++s) {
+        if (a.mode == 0) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) vb[j] = v[j];
+            if (s >= 2) hals_collect_issue(a.sy, s - 1, nblocks, pf);   // consumed after this sweep
+        }
         float f;
         if (all_live) {
             f = quad_sweep_all_live<CH>(v, b, own, laddr);
@@ -211,18 +219,20 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
         const int c = s - 1;   // lag-one speculation (k_hals_fast.hip): sweep whose global sum is examined now
         if (c >= 1) {
             double tot;
-            ok = hals_collect(a.sy, c, nblocks, tot, red, &lds_flag);
+            ok = hals_collect(a.sy, c, nblocks, tot, red, &lds_flag, &pf);
             if (!ok) break;
             if (c == 1) eps0 = tot;
             eps = tot;
             done = c;
             if (!(eps >= a.delta * eps0)) { stopped = true; break; }   // nnls.py:156: sweep c was the last one
         }
-        store_col();   // V after sweep s (sweep s-1 said "go on")
     }
-    if (a.mode == 1) {
-        store_col();
-    } else if (ok && !stopped && a.max_sweeps >= 1) {
+    if (a.mode == 0 && (stopped || !ok)) {   // the registers hold one sweep too many
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[j] = vb[j];
+    }
+    if (a.max_sweeps >= 1) store_col();
+    if (a.mode == 0 && ok && !stopped && a.max_sweeps >= 1) {
         double tot;   // ran to the sweep budget: the last sweep's sum is still due
         ok = hals_collect(a.sy, a.max_sweeps, nblocks, tot, red, &lds_flag);
         if (ok) {

@@ -42,10 +42,28 @@ struct nnf_ws_cursor {
 // ---- device helpers -------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// v + (v moved by the DPP control CTRL); lanes of rows outside ROW_MASK add 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double nnf_dpp_add_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+    return v + __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+// Sum over the 64 lanes in a fixed order, all on the VALU (DPP; no LDS crossbar round trips): xor-1, xor-2, half-row and
+// row mirrors give every lane its 16-lane row sum, row_bcast15/31 chain the four rows into lane 63, which is broadcast.
+// The result is wave-uniform (valid in every lane).
 __device__ __forceinline__ double nnf_wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;  // valid in lane 0
+    v = nnf_dpp_add_f64<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = nnf_dpp_add_f64<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = nnf_dpp_add_f64<0x141, 0xf>(v);   // row_half_mirror
+    v = nnf_dpp_add_f64<0x140, 0xf>(v);   // row_mirror
+    v = nnf_dpp_add_f64<0x142, 0xa>(v);   // row_bcast15 into rows 1, 3
+    v = nnf_dpp_add_f64<0x143, 0xc>(v);   // row_bcast31 into rows 2, 3
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
 }
 
 // Block-wide fp64 sum in a fixed order (wave shuffle tree, then waves in index order).  Result in thread 0.

@@ -112,6 +112,19 @@ int nnf_mu_left_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t 
 int nnf_mu_right_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
                      const float* V, int64_t ldv, int r, double beta, float* V_out, int64_t ldvo, void* stream);
 
+/* Row-sharded right update (mu.py:79-97 on the transposed problem): the sums over the rows of X are
+ * additive over row blocks, so every rank accumulates
+ *   num = U^T((UV)^(beta-2) .* X)  (r x n)   and   den = U^T (UV)^(beta-1)  (r x n)
+ * for its block (beta = 1: den_vec_f64[k] = sum_i U[i,k], r doubles, `den` unused; beta = 2: num = U^T X,
+ * den = (U^T U) V), the caller all-reduces them, and nnf_mu_apply_f32 finishes:
+ *   out[k,j] = max(F[k,j] * (num[k,j]/den[k,j])^gamma(beta), 1e-12)    (den_vec_f64 != NULL: den[k,j] = den_vec_f64[k]). */
+int nnf_mu_right_accum_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                           const float* V, int64_t ldv, int r, double beta, float* num, int64_t ldnum, float* den,
+                           int64_t ldden, double* den_vec_f64, void* stream);
+int nnf_mu_apply_f32(nnf_ctx* ctx, const float* F, int64_t ldf, int r, int64_t cols, const float* num, int64_t ldnum,
+                     const float* den, int64_t ldden, const double* den_vec_f64, double beta, float* out, int64_t ldo,
+                     void* stream);
+
 /* beta_divergence(X, U@V, beta) (beta_divergence.py:45-52) fused with the product; *out_f64 = the sum. */
 int nnf_betadiv_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
                     const float* V, int64_t ldv, int r, double beta, double* out_f64, void* stream);

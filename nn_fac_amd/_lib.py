@@ -29,6 +29,8 @@ SIGNATURES = {
     "nnf_hals_sweeps_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _f32, _u32, _p, _p, _i64, _p]),
     "nnf_mu_left_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _i64, _p]),
     "nnf_mu_right_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _i64, _p]),
+    "nnf_mu_right_accum_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _i64, _p, _i64, _p, _p]),
+    "nnf_mu_apply_f32": (_i32, [_p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64, _p, _f64, _p, _i64, _p]),
     "nnf_betadiv_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _p]),
     "nnf_mttkrp3_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p]),
     "nnf_cp3_betadiv_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _p]),

@@ -404,7 +404,8 @@ static size_t mu_shm(int MT, int r) { return ((size_t)4 * ((r + 3) / 4) * 64 + (
 template <int MT, int BM, bool VEC>
 static int launch_mu_right(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx,
                            const float* Ut, int64_t ldu, const float* V, int64_t ldv, int r, double beta, float* V_out,
-                           int64_t ldvo, hipStream_t st) {
+                           int64_t ldvo, hipStream_t st, float* num_out = nullptr, int64_t ldnum = 0,
+                           float* den_out = nullptr, int64_t ldden = 0, double* den_vec_out = nullptr) {
     const int ncb = (int)nnf_cdiv(n, 256);
     const int64_t ldp = nnf_rup(n, 4);
     const int nacc = (BM == BM_GEN) ? 2 : 1;
@@ -433,13 +434,19 @@ static int launch_mu_right(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_mu_right_kernel<MT, BM, VEC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (BM == BM_KL) {  // den[k] = colsum(U)[k] = rowsum(Ut)[k]   (mu.py:86-87 on the transposed problem)
-        hipLaunchKernelGGL(nnf_rowsum_kernel, dim3(r), dim3(256), 0, st, Ut, ldu, m, dvec);
+        hipLaunchKernelGGL(nnf_rowsum_kernel, dim3(r), dim3(256), 0, st, Ut, ldu, m, num_out ? den_vec_out : dvec);
         NNF_CHECK_LAUNCH();
     }
     const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * ncb;
     hipLaunchKernelGGL((nnf_mu_right_kernel<MT, BM, VEC>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
                        (float)beta, snum, sden, ldp, ncb, (int)nsplit, rps, a_vec_ok);
     NNF_CHECK_LAUNCH();
+    if (num_out) {   // accumulate only (row-sharded runs): this block's numerator / denominator, slab-reduced in fixed order
+        int rc = nnf_launch_reduce_slabs(snum, (int)nsplit, slab_elems, r, n, ldp, num_out, ldnum, st);
+        if (rc != NNF_OK) return rc;
+        if (nacc == 2) return nnf_launch_reduce_slabs(sden, (int)nsplit, slab_elems, r, n, ldp, den_out, ldden, st);
+        return NNF_OK;
+    }
     int64_t fg = nnf_cdiv((int64_t)r * n, 256);
     if (fg > 2048) fg = 2048;
     hipLaunchKernelGGL(nnf_mu_finish_kernel, dim3((int)fg), dim3(256), 0, st, V, ldv, r, n, snum, sden, (int)nsplit,
@@ -542,4 +549,57 @@ extern "C" int nnf_mu_right_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t
         return NNF_OK;
     }
     MU_DISPATCH(launch_mu_right, ctx, cur, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, V_out, ldvo, st);
+}
+
+
+// ---- two-phase right update for row-sharded runs: every rank accumulates the numerator / denominator
+// of its row block, the host all-reduces them, nnf_mu_apply_f32 finishes.  beta = 2 goes through the Gram form
+// (num = Ut X, den = (Ut U) V, both linear in the row blocks); beta = 1 has den[k] = colsum(U)[k] (r doubles).
+__global__ __launch_bounds__(256) void nnf_small_gemm_kernel(const float* __restrict__ G, int r, const float* __restrict__ V,
+                                                             int64_t ldv, int64_t n, float* __restrict__ out, int64_t ldo) {
+    const int64_t total = (int64_t)r * n;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t k = e / n, j = e - k * n;
+        float s = 0.f;
+        for (int l = 0; l < r; ++l) s = fmaf(G[k * r + l], V[(int64_t)l * ldv + j], s);   // same order as nnf_mu2_finish_kernel
+        out[k * ldo + j] = s;
+    }
+}
+
+extern "C" int nnf_mu_right_accum_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
+                                      int64_t ldu, const float* V, int64_t ldv, int r, double beta, float* num, int64_t ldnum,
+                                      float* den, int64_t ldden, double* den_vec_f64, void* stream) {
+    int rc = mu_args_ok(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, num);
+    if (rc != NNF_OK) return rc;
+    if (ldnum < n) return NNF_ERR_ARG;
+    if (beta == 1.0 ? (den_vec_f64 == nullptr) : (den == nullptr || ldden < n)) return NNF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    nnf_ws_cursor cur(ctx);
+    if (beta == 2.0) {
+        float* G = (float*)cur.take((size_t)r * r * 4);
+        if (!G) return NNF_ERR_WORKSPACE;
+        if ((rc = nnf_gram_impl(ctx, cur, Ut, r, m, ldu, G, r, st)) != NNF_OK) return rc;
+        if ((rc = nnf_xty_impl(ctx, cur, X, m, n, ldx, Ut, r, ldu, num, ldnum, st)) != NNF_OK) return rc;
+        int64_t fg = nnf_cdiv((int64_t)r * n, 256);
+        if (fg > 2048) fg = 2048;
+        hipLaunchKernelGGL(nnf_small_gemm_kernel, dim3((int)fg), dim3(256), 0, st, G, r, V, ldv, n, den, ldden);
+        NNF_CHECK_LAUNCH();
+        return NNF_OK;
+    }
+    MU_DISPATCH(launch_mu_right, ctx, cur, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, nullptr, 0, st, num, ldnum, den, ldden,
+                den_vec_f64);
+}
+
+extern "C" int nnf_mu_apply_f32(nnf_ctx* ctx, const float* F, int64_t ldf, int r, int64_t cols, const float* num,
+                                int64_t ldnum, const float* den, int64_t ldden, const double* den_vec_f64, double beta,
+                                float* out, int64_t ldo, void* stream) {
+    if (!ctx || !F || !num || !out || r < 1 || cols < 1 || ldf < cols || ldnum < cols || ldo < cols || !(beta >= 0.0))
+        return NNF_ERR_ARG;
+    if (den_vec_f64 == nullptr && (den == nullptr || ldden != ldnum)) return NNF_ERR_ARG;
+    int64_t fg = nnf_cdiv((int64_t)r * cols, 256);
+    if (fg > 2048) fg = 2048;
+    hipLaunchKernelGGL(nnf_mu_finish_kernel, dim3((int)fg), dim3(256), 0, (hipStream_t)stream, F, ldf, r, cols, num, den, 1,
+                       (int64_t)0, ldnum, den_vec_f64, gamma_of(beta), out, ldo);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
 }

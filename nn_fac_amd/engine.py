@@ -177,6 +177,35 @@ class Engine:
                    "nnf_mu_right_f32")
         return O
 
+    def mu_right_accum(self, X, Ut, V, beta):
+        """This row block's numerator / denominator of the right update (row-sharded runs): returns (num r x n,
+        den r x n or None, den_vec r doubles or None); all three are sums over the rows and all-reduce additively."""
+        _chk2d(X, "mu X"), _chk2d(Ut, "mu Ut"), _chk2d(V, "mu V")
+        m, n = X.shape
+        r = Ut.shape[0]
+        num = torch.empty((r, n), dtype=torch.float32, device=X.device)
+        den = torch.empty((r, n), dtype=torch.float32, device=X.device) if float(beta) != 1.0 else None
+        dvec = torch.empty(r, dtype=torch.float64, device=X.device) if float(beta) == 1.0 else None
+        _lib.check(self.lib.nnf_mu_right_accum_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
+                                                   V.stride(0), r, float(beta), _ptr(num), num.stride(0),
+                                                   _ptr(den) if den is not None else None,
+                                                   den.stride(0) if den is not None else 0,
+                                                   _ptr(dvec) if dvec is not None else None, self._stream()),
+                   "nnf_mu_right_accum_f32")
+        return num, den, dvec
+
+    def mu_apply(self, F, num, den, den_vec, beta, out=None):
+        """out = max(F * (num/den)^gamma(beta), 1e-12) (mu.py:84-97) from already reduced numerator / denominator."""
+        _chk2d(F, "mu F"), _chk2d(num, "mu num")
+        r, cols = F.shape
+        O = out if out is not None else torch.empty_like(F)
+        _lib.check(self.lib.nnf_mu_apply_f32(self.ctx, _ptr(F), F.stride(0), r, cols, _ptr(num), num.stride(0),
+                                             _ptr(den) if den is not None else None,
+                                             den.stride(0) if den is not None else 0,
+                                             _ptr(den_vec) if den_vec is not None else None, float(beta), _ptr(O),
+                                             O.stride(0), self._stream()), "nnf_mu_apply_f32")
+        return O
+
     def betadiv(self, X, Ut, V, beta, out=None):
         _chk2d(X, "betadiv X"), _chk2d(Ut, "betadiv Ut"), _chk2d(V, "betadiv V")
         m, n = X.shape

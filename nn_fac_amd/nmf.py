@@ -176,8 +176,8 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
     With `group` (torch.distributed process group) X / Ut are this rank's row block and V is replicated (dist.py)."""
     sharded = _dist.world(group) > 1
     if sharded:
-        if update_rule != "hals" or not deterministic or normalize[0]:
-            raise NotImplementedError("row-sharded runs support deterministic HALS without U normalisation")
+        if update_rule == "hals" and (not deterministic or normalize[0]):
+            raise NotImplementedError("row-sharded HALS runs need deterministic=True and no U normalisation")
     if update_rule not in ["hals", "mu"]:
         raise err.InvalidArgumentValue(f"Invalid update rule: {update_rule}") from None
     if update_rule == "hals" and beta != 2:
@@ -231,7 +231,15 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                        ws.block[8 * nstat:8 * nstat + 8])
             nstat += 1
         else:
-            V = eng.mu_right(X, Ut, V_in, beta)         # nmf.py:447
+            if sharded:
+                # the sums over the rows of X are additive over the row blocks: numerator and denominator
+                # (beta = 1: the r column sums of U) are all-reduced, then every rank applies the same update
+                num, den, dvec = eng.mu_right_accum(X, Ut, V_in, beta)
+                _dist.allreduce_(num, group)
+                _dist.allreduce_(den if den is not None else dvec, group)
+                V = eng.mu_apply(V_in, num, den, dvec, beta)
+            else:
+                V = eng.mu_right(X, Ut, V_in, beta)     # nmf.py:447
 
     sp = [0 if s is None else s for s in sparsity_coefficients]
     if update_rule == "hals":
@@ -248,4 +256,6 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             ws.cost.add_(2 * (sp[0] * nU + sp[1] * nV))
     else:
         eng.betadiv(X, Ut, V, beta, out=ws.cost)                  # nmf.py:455
+        if sharded:
+            _dist.allreduce_(ws.cost, group)
     return Ut, V, nstat

@@ -58,6 +58,28 @@ class OracleEngine:
         return st
 
 
+    def mu_left(self, X, Ut, V, beta, out=None):
+        O = torch.from_numpy(orc.mu_betadivmin(Ut.numpy().T, V.numpy(), X.numpy(), beta).T.copy())
+        return O if out is None else out.copy_(O)
+
+    def mu_right_accum(self, X, Ut, V, beta):
+        U, K = Ut.T, Ut.T @ V
+        if beta == 1:
+            return U.T @ (X / K), None, U.sum(dim=0).double()
+        if beta == 2:
+            return U.T @ X, (U.T @ U) @ V, None
+        return U.T @ (K ** (beta - 2) * X), U.T @ K ** (beta - 1), None
+
+    def mu_apply(self, F, num, den, den_vec, beta, out=None):
+        d = den if den is not None else den_vec.reshape(-1, 1)
+        O = torch.clamp(F * (num / d) ** orc.gamma_beta(beta), min=1e-12)
+        return O if out is None else out.copy_(O)
+
+    def betadiv(self, X, Ut, V, beta, out=None):
+        c = torch.tensor([orc.beta_divergence(X.numpy(), (Ut.T @ V).numpy(), beta)], dtype=torch.float64)
+        return c if out is None else out.copy_(c)
+
+
 class _Bufs:
     def __init__(self, X, r):
         from nn_fac_amd import dist as nd
@@ -70,7 +92,7 @@ class _Bufs:
         self.guess_u = nd.SweepGuess(first=3, max_chunk=5)   # small on purpose: exercises continue, exact stop, overshoot
 
 
-def _worker(rank, nranks, port, m, n, r, iters, sparsity, q):
+def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=nranks)
     try:
@@ -83,7 +105,7 @@ def _worker(rank, nranks, port, m, n, r, iters, sparsity, q):
         eng, ws = OracleEngine(), _Bufs(Xl, r)
         costs, sweeps = [], []
         for _ in range(iters):
-            Ut, V, nstat = nmf_mod._one_nmf_step_dev(eng, ws, Xl, r, Ut, V, "hals", 2, sparsity, [], [False, False],
+            Ut, V, nstat = nmf_mod._one_nmf_step_dev(eng, ws, Xl, r, Ut, V, rule, beta, sparsity, [], [False, False],
                                                      True, group=dist.group.WORLD)
             costs.append(float(ws.block[16]))
             sweeps += [int(ws.block[8 * i + 1]) - 1 for i in range(nstat)]
@@ -125,6 +147,30 @@ def test_row_sharded_step_equals_unsharded_oracle(sparsity):
         np.testing.assert_allclose(cl, costs, rtol=1e-9)
         assert sl == sw                                   # identical inner sweep counts on every rank
     assert np.array_equal(res[0][4], res[1][4])           # replicated V bitwise identical across ranks
+
+
+@pytest.mark.parametrize("beta", [1, 2, 0.5, 3])
+def test_row_sharded_mu_step_equals_unsharded_oracle(beta):
+    """MU: left update local, right update from all-reduced numerator / denominator, cost all-reduced."""
+    m, n, r, iters, nranks = 203, 30, 5, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(k, nranks, port, m, n, r, iters, [None, None], q, "mu", beta))
+             for k in range(nranks)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(nranks))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    X, U0, V0 = orc.synth_nmf(m, n, r, seed=1, dtype=np.float64)
+    U, V, costs, _ = orc.compute_nmf(X, r, U0, V0, n_iter_max=iters, tol=0, update_rule="mu", beta=beta,
+                                     return_costs=True, deterministic=True)
+    np.testing.assert_allclose(np.concatenate([x[3] for x in res], axis=0), U, rtol=1e-9, atol=1e-12)
+    for rank, lo, hi, Ul, Vl, cl, sl in res:
+        np.testing.assert_allclose(Vl, V, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(cl, costs, rtol=1e-9)
 
 
 def test_shard_rows_partition():

@@ -285,12 +285,29 @@ def test_hals_sweep_snapshots(eng, layout, monkeypatch):
         assert torch.equal(ndk, nd[:k])
 
 
-def test_row_sharded_two_ranks_on_one_gpu(built_lib):
+@pytest.mark.parametrize("beta", [0.5, 1, 2, 3])
+def test_mu_right_accumulate_then_apply(eng, beta):
+    """Row-sharded right update: per-block numerator / denominator, summed, then applied == the one-shot kernel."""
+    rng = np.random.RandomState(5)
+    m, n, r = 3000, 260, 33
+    X, Ut, V = dev(rng.rand(m, n) + 0.1), dev(rng.rand(r, m) + 0.05), dev(rng.rand(r, n) + 0.05)
+    want = eng.mu_right(X, Ut, V, beta)
+    cut = 1111
+    parts = [eng.mu_right_accum(X[:cut], Ut[:, :cut], V, beta), eng.mu_right_accum(X[cut:], Ut[:, cut:], V, beta)]
+    num = parts[0][0] + parts[1][0]
+    den = parts[0][1] + parts[1][1] if parts[0][1] is not None else None
+    dvec = parts[0][2] + parts[1][2] if parts[0][2] is not None else None
+    got = eng.mu_apply(V, num, den, dvec, beta)
+    assert rel(got.cpu().numpy(), want.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 1), ("mu", 2)])
+def test_row_sharded_two_ranks_on_one_gpu(built_lib, rule, beta):
     """Two gloo ranks sharing the GPU run the real sharded step (tools/dist_gpu_check.py) against the single-process run."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", "29533", os.path.join(root, "tools", "dist_gpu_check.py")],
-                         capture_output=True, text=True, timeout=300, env=env)
+                          "127.0.0.1", "--master-port", "29533", os.path.join(root, "tools", "dist_gpu_check.py"), rule,
+                          str(beta)], capture_output=True, text=True, timeout=300, env=env)
     assert "DIST_GPU_CHECK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

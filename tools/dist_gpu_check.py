@@ -1,5 +1,5 @@
 """Two ranks sharing ONE GPU over gloo: the real HIP kernels inside the row-sharded step (dist.py) vs the
-single-process run.  Launch: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/dist_gpu_check.py"""
+single-process run.  Launch: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/dist_gpu_check.py [hals|mu] [beta]"""
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +11,9 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 torch.cuda.set_device(0)
 eng = get_engine("cuda:0")
+RULE = sys.argv[1] if len(sys.argv) > 1 else "hals"
+BETA = float(sys.argv[2]) if len(sys.argv) > 2 else 2
+BETA = int(BETA) if BETA == int(BETA) else BETA
 m, n, r, iters = 6001, 300, 20, 6
 X, U0, V0 = orc.synth_nmf(m, n, r, seed=4, dtype=np.float32)
 lo, hi = nd.shard_rows(m, rank, world)
@@ -21,7 +24,7 @@ ws = nm._StepBuffers(Xl, r)
 ws.guess_u = nd.SweepGuess(first=4, max_chunk=6)
 costs, sweeps = [], []
 for _ in range(iters):
-    Ut, V, nstat = nm._one_nmf_step_dev(eng, ws, Xl, r, Ut, V, "hals", 2, [None, None], [], [False, False], True,
+    Ut, V, nstat = nm._one_nmf_step_dev(eng, ws, Xl, r, Ut, V, RULE, BETA, [None, None], [], [False, False], True,
                                         group=dist.group.WORLD)
     h = ws.block.cpu(); costs.append(float(h[16])); sweeps += [int(h[8 * i + 1]) - 1 for i in range(nstat)]
 # single-process reference run of the same engine on rank 0
@@ -29,7 +32,7 @@ if rank == 0:
     Xd, Ud, Vd = torch.from_numpy(X).cuda(), torch.from_numpy(U0.T.copy()).cuda(), torch.from_numpy(V0).cuda()
     ws1 = nm._StepBuffers(Xd, r); c1, s1 = [], []
     for _ in range(iters):
-        Ud, Vd, nstat = nm._one_nmf_step_dev(eng, ws1, Xd, r, Ud, Vd, "hals", 2, [None, None], [], [False, False], True)
+        Ud, Vd, nstat = nm._one_nmf_step_dev(eng, ws1, Xd, r, Ud, Vd, RULE, BETA, [None, None], [], [False, False], True)
         h = ws1.block.cpu(); c1.append(float(h[16])); s1 += [int(h[8 * i + 1]) - 1 for i in range(nstat)]
     relV = float((V - Vd).norm() / Vd.norm()); relU = float((Ut - Ud[:, lo:hi]).norm() / Ud[:, lo:hi].norm())
     print("sharded sweeps", sweeps); print("single  sweeps", s1)

@@ -29,7 +29,7 @@ def _install_tensorly_standin():
     import nnfac_oracle as orc  # only for the tensor helper semantics (unfold/khatri_rao/...)
     tl = types.ModuleType("tensorly")
     tl.tensor = lambda x, **kw: np.array(x)
-    tl.ones, tl.abs, tl.dot, tl.transpose, tl.ndim = np.ones, np.abs, np.dot, np.transpose, np.ndim
+    tl.ones, tl.abs, tl.dot, tl.transpose, tl.ndim, tl.conj = np.ones, np.abs, np.dot, np.transpose, np.ndim, np.conj
     tl.unfold = orc.unfold
     tl.fold = orc.fold
     tl.tensor_to_vec = lambda t: t.reshape(-1)
@@ -255,6 +255,100 @@ def main():
             g6[f"{name}_{rule}_b{beta}_costs"] = np.array(costs)
     np.savez_compressed(os.path.join(OUT, "g6_ntf.npz"), **g6)
     print("G6 ok")
+
+    # ---------------- G7: NTD (ntd.py, mu.py:99-159) ----------------
+    # the reference's own known answers first (tests/NTD_tests.py:18-27 setUp, :138-155, :177-195, :217-255)
+    rnd = types.ModuleType("tensorly.random")
+    rnd.random_tucker = lambda shape, rank, full=True, random_state=None: orc.random_tucker_full(shape, rank, random_state)
+    sys.modules["tensorly.random"] = rnd
+    sys.modules["tensorly"].random = rnd
+    import random as pyrandom
+    import nn_fac.ntd as ref_ntd
+    np.random.seed(0)
+    pyrandom.seed(0)
+    ranks = (pyrandom.randint(3, 10), pyrandom.randint(3, 10), pyrandom.randint(3, 10))
+    shape = (pyrandom.randint(20, 100), pyrandom.randint(20, 100), pyrandom.randint(20, 100))
+    for mo in range(3):
+        np.random.rand(shape[mo], ranks[mo])        # setUp draws factors_0..2 and core before the tensor
+    np.random.rand(*ranks)
+    Tref = np.abs(rnd.random_tucker(shape, ranks, full=True, random_state=0)) + 1e-2 * np.random.rand(*shape)
+    assert abs(Tref[0][0][0] - 21.974433828159626) < 1e-7                       # NTD_tests.py:141
+    known = {("hals", 2): (0.5501411956914489, 0.9680069293664532, 0.965086018254149, 0.3744157888431357,
+                           2.6164388105612055e-08, 2.603936417799217e-08),     # :148-155
+             ("mu", 2): (0.5489250094099122, 0.9679994929177957, 0.9650887516147171, 0.3744138868288453,
+                         1.5935015225944391, 1.5931775725367523),             # :188-195
+             ("mu", 1): (0.5489424379755086, 0.9679939115774175, 0.9650587287572271, 0.3744133064030978,
+                         0.12936809612191502, 0.1293171172587153),            # :228-235
+             ("mu", 0): (0.5488704375518113, 0.9680879599528461, 0.9650465314632987, 0.3744250029550508,
+                         0.01749656252808407, 0.014723505531139436)}          # :248-255
+    g7 = {"ref_shape": np.array(shape), "ref_ranks": np.array(ranks)}
+    for (rule, beta), want in known.items():
+        core, facs, costs, toc = ref_ntd.ntd(Tref, list(ranks), init="random", n_iter_max=10, tol=1e-8, update_rule=rule,
+                                             beta=beta, sparsity_coefficients=[None] * 4, fixed_modes=[],
+                                             normalize=[False] * 4, verbose=False, return_costs=True, deterministic=True,
+                                             seed=0)
+        got = (facs[0][0][0], facs[1][0][0], facs[2][0][0], core[0, 0, 0], costs[0], costs[-1])
+        assert all(abs(a - b) < 5e-8 for a, b in zip(got, want)), (rule, beta, got, want)   # assertAlmostEqual: 7 places
+        c0, f0 = orc.ntd_random_init(shape, list(ranks), 0)
+        sw, pg = [], []
+        co, fo, cso, _ = orc.compute_ntd(Tref, list(ranks), c0, f0, n_iter_max=10, tol=1e-8, update_rule=rule, beta=beta,
+                                         sparsity_coefficients=[None] * 4, fixed_modes=[], normalize=[False] * 4,
+                                         return_costs=True, deterministic=True, sweeps=sw, pg_iters=pg)
+        assert np.allclose(co, core, rtol=1e-7, atol=1e-10) and np.allclose(cso, costs, rtol=1e-6, atol=1e-12)
+        tag = f"ref_{rule}_b{beta}"
+        g7[f"{tag}_core"], g7[f"{tag}_costs"] = core, np.array(costs)
+        for i in range(3):
+            assert np.allclose(fo[i], facs[i], rtol=1e-7, atol=1e-10)
+            g7[f"{tag}_F{i}"] = facs[i]
+        g7[f"{tag}_sweeps"], g7[f"{tag}_pg"] = np.array(sw), np.array(pg)
+    # small seeded problem: step functions called directly, options exercised
+    rs = np.random.RandomState(7)
+    shp, rk = (10, 9, 8), [4, 3, 2]
+    Ts = orc.multi_mode_dot(rs.rand(*rk), [rs.rand(shp[i], rk[i]) for i in range(3)]) + 0.05 * rs.rand(*shp)
+    c0 = rs.rand(*rk)
+    f0 = [rs.rand(shp[i], rk[i]) for i in range(3)]
+    g7["small_T"], g7["small_core0"] = Ts, c0
+    for i in range(3):
+        g7[f"small_F0_{i}"] = f0[i]
+    nrm = np.sqrt(np.sum(Ts ** 2))
+    cases = {"plain": dict(sp=[None] * 4, fixed=[], norm=[False] * 4, mcn=None),
+             "sparse": dict(sp=[0.01, None, 0.02, 0.05], fixed=[], norm=[False] * 4, mcn=None),
+             "norm": dict(sp=[None] * 4, fixed=[], norm=[True, False, True, True], mcn=1),
+             "fixed1": dict(sp=[None] * 4, fixed=[1], norm=[False] * 4, mcn=None)}
+    for name, cfg in cases.items():
+        cr, fr = c0.copy(), [f.copy() for f in f0]
+        co, fo = c0.copy(), [f.copy() for f in f0]
+        costs = []
+        for it in range(4):
+            cr, fr, c = ref_ntd.one_ntd_step(Ts, rk, cr, fr, nrm, list(cfg["sp"]), list(cfg["fixed"]), list(cfg["norm"]),
+                                             cfg["mcn"], alpha=math.inf, delta=0.01)
+            co, fo, c2 = orc.one_ntd_step(Ts, rk, co, fo, nrm, list(cfg["sp"]), list(cfg["fixed"]), list(cfg["norm"]),
+                                          cfg["mcn"], alpha=math.inf, delta=0.01)
+            assert np.isclose(c, c2, rtol=1e-8, atol=1e-13), (name, it, c, c2)
+            costs.append(c)
+        assert np.allclose(cr, co, rtol=1e-8, atol=1e-12)
+        g7[f"small_hals_{name}_core"], g7[f"small_hals_{name}_costs"] = cr, np.array(costs)
+        for i in range(3):
+            assert np.allclose(fr[i], fo[i], rtol=1e-8, atol=1e-12)
+            g7[f"small_hals_{name}_F{i}"] = fr[i]
+    for beta in (0, 0.5, 1, 2, 3):
+        cr, fr = c0.copy(), [f.copy() for f in f0]
+        co, fo = c0.copy(), [f.copy() for f in f0]
+        costs = []
+        for it in range(4):
+            cr, fr, c = ref_ntd.one_ntd_step_mu(Ts, rk, cr, fr, beta, nrm, [], [False] * 4, None)
+            co, fo, c2 = orc.one_ntd_step_mu(Ts, rk, co, fo, beta, nrm, [], [False] * 4, None)
+            assert np.isclose(c, c2, rtol=1e-9), (beta, it, c, c2)
+            costs.append(c)
+        assert np.allclose(cr, co, rtol=1e-9, atol=1e-13)
+        g7[f"small_mu_b{beta}_core"], g7[f"small_mu_b{beta}_costs"] = cr, np.array(costs)
+        for i in range(3):
+            assert np.allclose(fr[i], fo[i], rtol=1e-9, atol=1e-13)
+            g7[f"small_mu_b{beta}_F{i}"] = fr[i]
+        g7[f"small_mut_b{beta}"] = ref_mu.mu_tensorial(c0, f0, Ts, beta)
+        assert np.allclose(g7[f"small_mut_b{beta}"], orc.mu_tensorial(c0, f0, Ts, beta), rtol=1e-12)
+    np.savez_compressed(os.path.join(OUT, "g7_ntd.npz"), **g7)
+    print("G7 ok")
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"fixtures written to {os.path.normpath(OUT)}: {sz/1e6:.2f} MB")
 

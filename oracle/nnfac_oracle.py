@@ -399,6 +399,185 @@ def compute_ntf(tensor_in, rank, factors_in, n_iter_max=100, tol=1e-8, update_ru
 
 
 # --------------------------------------------------------------------------------------
+# a8: NTD  (nn_fac/ntd.py:248-698, nn_fac/update_rules/mu.py:99-159)
+# --------------------------------------------------------------------------------------
+class InvalidRanksException(ArgumentException):
+    """errors.py: raised when len(ranks) != tensor order (ntd.py:213)."""
+
+
+class CustomNotValidCore(ArgumentException):
+    """errors.py: custom init with core_0 None (ntd.py:234)."""
+
+
+def contract(a, modes_a, b, modes_b):
+    """tensorly 0.6.0 tl.tenalg.contract == tensordot over the listed modes."""
+    return np.tensordot(a, b, axes=(modes_a, modes_b))
+
+
+def random_tucker_full(shape, rank, seed):
+    """tl.random.random_tucker(shape, rank, full=True, random_state=seed): factors drawn first,
+    in mode order, then the core, then the full tensor."""
+    rs = np.random.RandomState(seed)
+    factors = [rs.random_sample((s, r)) for s, r in zip(shape, rank)]
+    core = rs.random_sample(tuple(rank))
+    return multi_mode_dot(core, factors)
+
+
+def ntd_random_init(shape, ranks, seed):
+    """initialize_factors.py:53-66 with deterministic=True (np.random.seed(seed); random.seed has no effect here)."""
+    np.random.seed(seed)
+    factors = []
+    for mode in range(len(shape)):
+        f = np.random.rand(shape[mode], ranks[mode])
+        f[f < 1e-12] = 1e-12
+        factors.append(f)
+    core = np.random.rand(int(np.prod(ranks))).reshape(tuple(ranks))
+    core[core < 1e-12] = 1e-12
+    return core, factors
+
+
+def one_ntd_step(tensor, ranks, in_core, in_factors, norm_tensor, sparsity_coefficients, fixed_modes, normalize,
+                 mode_core_norm, alpha=0.5, delta=0.01, sweeps=None, pg_iters=None):
+    """ntd.py:514-645.  The core update reuses `temp` and `elemprod` left behind by the LAST updated mode (:581-583).
+    sweeps / pg_iters (not in the reference) collect the inner sweep counts and the projected-gradient iteration count."""
+    for f in fixed_modes:
+        sparsity_coefficients[f] = None
+    core = in_core.copy()
+    factors = in_factors.copy()
+    nd = tensor.ndim
+    modes_list = [m for m in range(nd) if m not in fixed_modes]
+    for mode in modes_list:
+        elemprod = factors.copy()                                                   # :534-537
+        for i, factor in enumerate(factors):
+            if i != mode:
+                elemprod[i] = np.dot(np.conj(np.transpose(factor)), factor)
+        temp = multi_mode_dot(core, elemprod, skip=mode)                            # :539
+        con_modes = [i for i in range(nd) if i != mode]
+        UtU = contract(temp, con_modes, core, con_modes)                            # :544
+        temp = multi_mode_dot(tensor, factors, skip=mode, transpose=True)           # :550
+        MtU = contract(temp, con_modes, core, con_modes)                            # :555
+        UtM = np.transpose(MtU)
+        V, eps, cnt, rho = hals_nnls_acc(UtM, UtU, np.transpose(factors[mode]), maxiter=100, atime=None, alpha=alpha,
+                                         delta=delta, sparsity_coefficient=sparsity_coefficients[mode],
+                                         normalize=normalize[mode])                 # :571-573 (atime only feeds rho)
+        if sweeps is not None:
+            sweeps.append(cnt - 1)
+        factors[mode] = np.transpose(V)
+    last = modes_list[-1]
+    all_MtX = mode_dot(temp, np.transpose(factors[last]), last)                     # :581
+    all_MtM = elemprod.copy()
+    all_MtM[last] = factors[last].T @ factors[last]
+    gradient_step = 1                                                               # :588-596
+    for MtM in all_MtM:
+        gradient_step *= 1 / np.linalg.svd(MtM, compute_uv=False)[0]                # svds(MtM, k=1)[1][0]
+    gradient_step = round(gradient_step, 6)
+    cnt, upd_0, upd = 1, 0, 1
+    sparse = 0 if sparsity_coefficients[-1] is None else sparsity_coefficients[-1]
+    while cnt <= 300 and upd >= delta * upd_0:                                      # :609-619
+        gradient = -all_MtX + multi_mode_dot(core, all_MtM, transpose=False) + sparse * np.ones(core.shape)
+        delta_core = np.minimum(gradient_step * gradient, core)
+        core = core - delta_core
+        upd = np.sqrt(np.sum(delta_core ** 2))
+        if cnt == 1:
+            upd_0 = upd
+        cnt += 1
+    if pg_iters is not None:
+        pg_iters.append(cnt - 1)
+    if normalize[-1]:                                                               # :621-626
+        unfolded_core = unfold(core, mode_core_norm).copy()
+        for idx in range(unfolded_core.shape[0]):
+            nrm = np.sqrt(np.sum(unfolded_core[idx] ** 2))
+            if nrm != 0:
+                unfolded_core[idx] = unfolded_core[idx] / nrm
+        core = fold(unfolded_core, mode_core_norm, core.shape)
+    sparsity_error = 0                                                              # :629-637
+    for index, sp in enumerate(sparsity_coefficients):
+        if sp:
+            if index < len(factors):
+                sparsity_error += 2 * (sp * np.linalg.norm(factors[index], ord=1))
+            elif index == len(factors):
+                sparsity_error += 2 * (sp * np.sum(np.abs(core)))
+            else:
+                raise NotImplementedError("Too many sparsity coefficients")
+    rec_error = norm_tensor ** 2 - 2 * np.sum(all_MtX * core) + np.sum(multi_mode_dot(core, all_MtM, transpose=False) * core)
+    return core, factors, (rec_error + sparsity_error) / (norm_tensor ** 2)        # :639-640
+
+
+def mu_tensorial(G, factors, tensor, beta):
+    """mu.py:138-159 (core update of NTD-MU)."""
+    if beta < 0:
+        raise InvalidArgumentValue("Invalid value for beta: negative one.")
+    K = multi_mode_dot(G, factors)
+    if beta == 1:
+        L1, L2 = np.ones(np.shape(K)), K ** (-1) * tensor
+    elif beta == 2:
+        L1, L2 = K, np.ones(np.shape(K)) * tensor
+    elif beta == 3:
+        L1, L2 = K ** 2, K * tensor
+    else:
+        L1, L2 = K ** (beta - 1), K ** (beta - 2) * tensor
+    ft = [f.T for f in factors]
+    return np.maximum(G * (multi_mode_dot(L2, ft) / multi_mode_dot(L1, ft)) ** gamma_beta(beta), 1e-12)
+
+
+def one_ntd_step_mu(tensor, ranks, in_core, in_factors, beta, norm_tensor, fixed_modes, normalize, mode_core_norm):
+    """ntd.py:664-698.  The cost is NOT normalised (:696)."""
+    core = in_core.copy()
+    factors = in_factors.copy()
+    modes_list = [m for m in range(tensor.ndim) if m not in fixed_modes]
+    for mode in modes_list:
+        factors[mode] = mu_betadivmin(factors[mode], unfold(multi_mode_dot(core, factors, skip=mode), mode),
+                                      unfold(tensor, mode), beta)
+    core = mu_tensorial(core, factors, tensor, beta)
+    if normalize[-1]:
+        unfolded_core = unfold(core, mode_core_norm).copy()
+        for idx in range(unfolded_core.shape[0]):
+            nrm = np.sqrt(np.sum(unfolded_core[idx] ** 2))
+            if nrm != 0:
+                unfolded_core[idx] = unfolded_core[idx] / nrm
+        core = fold(unfolded_core, mode_core_norm, core.shape)
+    return core, factors, beta_divergence(tensor, multi_mode_dot(core, factors), beta)
+
+
+def compute_ntd(tensor_in, ranks, core_in, factors_in, n_iter_max=100, tol=1e-6, update_rule="hals", beta=2,
+                sparsity_coefficients=[], fixed_modes=[], normalize=[], mode_core_norm=None, return_costs=False,
+                deterministic=False, sweeps=None, pg_iters=None):
+    """ntd.py:355-433 (verbose printing dropped)."""
+    core = core_in.copy()
+    factors = factors_in.copy()
+    tensor = tensor_in
+    norm_tensor = np.sqrt(np.sum(np.abs(tensor) ** 2))
+    nb_modes = tensor.ndim
+    if sparsity_coefficients is None or len(sparsity_coefficients) != nb_modes + 1:
+        sparsity_coefficients = [None for _ in range(nb_modes + 1)]
+    if fixed_modes is None:
+        fixed_modes = []
+    if normalize is None or len(normalize) != nb_modes + 1:
+        normalize = [False for _ in range(nb_modes + 1)]
+    if normalize[-1] and (mode_core_norm is None or mode_core_norm < 0 or mode_core_norm >= nb_modes):
+        normalize[-1] = False
+    costs, toc = [], []
+    for iteration in range(n_iter_max):
+        if update_rule == "hals":
+            core, factors, cost = one_ntd_step(tensor, ranks, core, factors, norm_tensor, sparsity_coefficients,
+                                               fixed_modes, normalize, mode_core_norm,
+                                               alpha=math.inf if deterministic else 0.5, sweeps=sweeps,
+                                               pg_iters=pg_iters)
+        elif update_rule == "mu":
+            core, factors, cost = one_ntd_step_mu(tensor, ranks, core, factors, beta, norm_tensor, fixed_modes,
+                                                  normalize, mode_core_norm)
+        else:
+            raise InvalidArgumentValue(f"The update rule provided is not valid (Got {update_rule}).")
+        toc.append(0.0)
+        costs.append(cost)
+        if iteration > 0 and abs(costs[-2] - costs[-1]) < tol:
+            break
+    if return_costs:
+        return core, factors, costs, toc
+    return core, factors
+
+
+# --------------------------------------------------------------------------------------
 # synthetic inputs shared by tests and bench (SURVEY.md 8d)
 # --------------------------------------------------------------------------------------
 def synth_nmf(m, n, r, seed=0, dtype=np.float32):

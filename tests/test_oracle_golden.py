@@ -125,3 +125,64 @@ def test_g6_ntf(golden):
             for i in range(3):
                 np.testing.assert_allclose(f[i], g[f"{name}_{rule}_b{beta}_F{i}"], rtol=1e-10, atol=1e-13)
             np.testing.assert_allclose(costs, g[f"{name}_{rule}_b{beta}_costs"], rtol=1e-10)
+
+
+def ntd_reference_tensor(shape, ranks):
+    """The tensor of tests/NTD_tests.py:18-27 (setUp), rebuilt from the seeds (nothing of it is stored)."""
+    import random
+    np.random.seed(0)
+    random.seed(0)
+    assert (random.randint(3, 10), random.randint(3, 10), random.randint(3, 10)) == tuple(ranks)
+    assert (random.randint(20, 100), random.randint(20, 100), random.randint(20, 100)) == tuple(shape)
+    for mo in range(3):
+        np.random.rand(shape[mo], ranks[mo])
+    np.random.rand(*ranks)
+    return np.abs(orc.random_tucker_full(shape, ranks, 0)) + 1e-2 * np.random.rand(*shape)
+
+
+def test_g7_ntd_reference_known_answers(golden):
+    """The reference's own NTD known-answer tests (NTD_tests.py:141-255) through the restatement."""
+    g = golden("g7_ntd.npz")
+    shape, ranks = tuple(int(x) for x in g["ref_shape"]), tuple(int(x) for x in g["ref_ranks"])
+    T = ntd_reference_tensor(shape, ranks)
+    assert abs(T[0][0][0] - 21.974433828159626) < 1e-7
+    for rule, beta in (("hals", 2), ("mu", 2), ("mu", 1), ("mu", 0)):
+        c0, f0 = orc.ntd_random_init(shape, list(ranks), 0)
+        sw, pg = [], []
+        core, facs, costs, _ = orc.compute_ntd(T, list(ranks), c0, f0, n_iter_max=10, tol=1e-8, update_rule=rule, beta=beta,
+                                               sparsity_coefficients=[None] * 4, fixed_modes=[], normalize=[False] * 4,
+                                               return_costs=True, deterministic=True, sweeps=sw, pg_iters=pg)
+        tag = f"ref_{rule}_b{beta}"
+        np.testing.assert_allclose(core, g[f"{tag}_core"], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(costs, g[f"{tag}_costs"], rtol=1e-6, atol=1e-12)
+        for i in range(3):
+            np.testing.assert_allclose(facs[i], g[f"{tag}_F{i}"], rtol=1e-7, atol=1e-10)
+        assert list(sw) == list(g[f"{tag}_sweeps"]) and list(pg) == list(g[f"{tag}_pg"])
+
+
+def test_g7_ntd_small_steps(golden):
+    g = golden("g7_ntd.npz")
+    T, c0 = g["small_T"], g["small_core0"]
+    f0 = [g[f"small_F0_{i}"] for i in range(3)]
+    rk = list(c0.shape)
+    nrm = np.sqrt(np.sum(T ** 2))
+    cases = {"plain": ([None] * 4, [], [False] * 4, None), "sparse": ([0.01, None, 0.02, 0.05], [], [False] * 4, None),
+             "norm": ([None] * 4, [], [True, False, True, True], 1), "fixed1": ([None] * 4, [1], [False] * 4, None)}
+    for name, (sp, fixed, norm, mcn) in cases.items():
+        core, f, costs = c0.copy(), [x.copy() for x in f0], []
+        for _ in range(4):
+            core, f, c = orc.one_ntd_step(T, rk, core, f, nrm, list(sp), list(fixed), list(norm), mcn, alpha=math.inf,
+                                          delta=0.01)
+            costs.append(c)
+        np.testing.assert_allclose(core, g[f"small_hals_{name}_core"], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(costs, g[f"small_hals_{name}_costs"], rtol=1e-8, atol=1e-13)
+        for i in range(3):
+            np.testing.assert_allclose(f[i], g[f"small_hals_{name}_F{i}"], rtol=1e-8, atol=1e-12)
+    for beta in (0, 0.5, 1, 2, 3):
+        core, f, costs = c0.copy(), [x.copy() for x in f0], []
+        for _ in range(4):
+            core, f, c = orc.one_ntd_step_mu(T, rk, core, f, beta, nrm, [], [False] * 4, None)
+            costs.append(c)
+        np.testing.assert_allclose(core, g[f"small_mu_b{beta}_core"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(costs, g[f"small_mu_b{beta}_costs"], rtol=1e-9)
+        np.testing.assert_allclose(orc.mu_tensorial(c0, f0, T, beta), g[f"small_mut_b{beta}"], rtol=1e-12)

@@ -143,6 +143,24 @@ int nnf_cp3_betadiv_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int6
                         void* stream);
 
 /* small helpers used by the drivers (all deterministic, fixed-order) */
+/* Mode-n product of the 3-way data tensor with a transposed factor: out = T x_mode F^T
+ * (tl.tenalg.mode_dot(T, F.T, mode); the contractions of ntd.py:550,581 and of mu_tensorial, mu.py:159, are chains of
+ * these).  T is I x J x K row-major, Ft is r x I_mode (row stride ldf).  The new axis comes out FIRST for the two outer
+ * modes -- mode 0: out[r][J][K], mode 2: out[r][I][J] -- and in place for the middle one -- mode 1: out[I][r][K]. */
+int nnf_ttm3_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t K, const float* Ft, int64_t ldf, int r, int mode,
+                 float* out, void* stream);
+
+/* Projected-gradient update of the NTD core (ntd.py:588-619) and the Gram-form reconstruction error (ntd.py:639), one
+ * single-workgroup launch, fp64 arithmetic in LDS:
+ *   step = round(prod_i 1/sigma_max(M_i), 6);  repeat (<= max_iter, while update >= delta * first update):
+ *       grad = core x_0 M0 x_1 M1 x_2 M2 - MtX + sparse;  core -= min(step*grad, core)
+ * core (d0 x d1 x d2, updated in place), MtX same shape, M_i = F_i^T F_i (d_i x d_i, dense).
+ * status_f64[6] = {iterations, last update norm, first update norm, step, norm_sq - 2<MtX,core> + <core x M, core>, 0}.
+ * NNF_ERR_UNSUPPORTED if the core (4 fp64 copies) does not fit in one workgroup's LDS. */
+int nnf_ntd_core_pg_f32(nnf_ctx* ctx, float* core, const float* MtX, const float* M0, const float* M1, const float* M2, int d0,
+                        int d1, int d2, double sparse, double delta, int max_iter, double norm_sq, double* status_f64,
+                        void* stream);
+
 /* *out_f64 = sum_ij A[i,j]*B[i,j]   (fp64 accumulate)  -- inner products of ntf.py:470 */
 int nnf_dot_f32(nnf_ctx* ctx, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int64_t cols,
                 double* out_f64, void* stream);

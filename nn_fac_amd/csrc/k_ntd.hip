@@ -1,0 +1,205 @@
+// NTD pieces (nn_fac/ntd.py:514-645): mode-n products of the data tensor with a transposed factor, and the projected-
+// gradient update of the (small) core tensor as ONE single-workgroup launch.
+//
+//   nnf_ttm3_f32    out = T x_mode F^T   (tl.tenalg.mode_dot(T, F.T, mode), the building block of ntd.py:550,581)
+//       mode 0: T viewed as I x (J*K), first axis contracted   -> the W^T X kernel (k_stream.hip), out[r][J][K]
+//       mode 2: T viewed as (I*J) x K, last axis contracted     -> the X H^T kernel,                out[r][I][J]
+//       mode 1: middle axis, per slab i: out[i][r][K] = F^T T_i -> nnf_ttm_mid_kernel below (VALU, factor row in SGPRs)
+//     The two big cases stream T once with the MFMA kernels; the new axis comes out FIRST (row-major [r][rest]) so the
+//     next contraction of a chain is again a first/last-axis product of a 2-D view, never a transposed copy.
+//
+//   nnf_ntd_core_pg_f32   ntd.py:588-619 + 639: step = round(prod 1/sigma_max(M_i), 6); up to max_iter projected-gradient
+//     steps core -= min(step*grad, core) with grad = core x_0 M0 x_1 M1 x_2 M2 - MtX + sparse, stopped when the update
+//     norm falls below delta times the first one; then the Gram-form reconstruction error.  The core has a few hundred
+//     to a few thousand entries, so the whole loop runs in one workgroup with the core in LDS, in fp64 (the reference's
+//     arithmetic: the 300-step loop is a recurrence, and the error expression cancels to ~1e-8 of its terms).
+#include "nnf_internal.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// middle-axis product: out[i][b][k] = sum_j Ft[b][j] * T[i][j][k].   grid = (ceil(K/256), I), 256 threads;
+// thread = one k of one slab, RC rank rows at a time (the slab's J x 256 tile is re-read from L2 per rank chunk).
+// ---------------------------------------------------------------------------------------------------------
+template <int RC>
+__global__ __launch_bounds__(256) void nnf_ttm_mid_kernel(const float* __restrict__ T, int64_t J, int64_t K,
+                                                          const float* __restrict__ Ft, int64_t ldf, int r,
+                                                          float* __restrict__ out) {
+    const int64_t i = blockIdx.y, k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float* slab = T + i * J * K;
+    float* o = out + i * (int64_t)r * K;
+    for (int b0 = 0; b0 < r; b0 += RC) {
+        float acc[RC];
+#pragma unroll
+        for (int b = 0; b < RC; ++b) acc[b] = 0.f;
+        for (int64_t j = 0; j < J; ++j) {
+            const float t = (k < K) ? slab[j * K + k] : 0.f;
+#pragma unroll
+            for (int b = 0; b < RC; ++b)
+                if (b0 + b < r) acc[b] = fmaf(Ft[(int64_t)(b0 + b) * ldf + j], t, acc[b]);   // wave-uniform operand
+        }
+        if (k < K) {
+#pragma unroll
+            for (int b = 0; b < RC; ++b)
+                if (b0 + b < r) o[(int64_t)(b0 + b) * K + k] = acc[b];
+        }
+    }
+}
+
+extern "C" int nnf_ttm3_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t K, const float* Ft, int64_t ldf, int r,
+                            int mode, float* out, void* stream) {
+    if (!ctx || !T || !Ft || !out || I < 1 || J < 1 || K < 1 || r < 1 || mode < 0 || mode > 2) return NNF_ERR_ARG;
+    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    const int64_t dim = mode == 0 ? I : (mode == 1 ? J : K);
+    if (ldf < dim) return NNF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    nnf_ws_cursor cur(ctx);
+    if (mode == 0) return nnf_xty_impl(ctx, cur, T, I, J * K, J * K, Ft, r, ldf, out, J * K, st);
+    if (mode == 2) return nnf_xht_impl(ctx, cur, T, I * J, K, K, Ft, r, ldf, out, I * J, st);
+    if (I > 65535) return NNF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((nnf_ttm_mid_kernel<16>), dim3((unsigned)nnf_cdiv(K, 256), (unsigned)I), dim3(256), 0, st, T, J, K, Ft, ldf,
+                       r, out);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// core update.  LDS (fp64): core, MtX, two scratch tensors (S each), M0, M1, M2, a power-iteration vector pair.
+// status_f64[0..5] = {iterations done, last update norm, first update norm, step, reconstruction error, 0}
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pg_block_sum(double v, double* red) {
+    v = nnf_wave_sum_f64(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; ++i) s += red[i];   // every thread, same order
+    __syncthreads();
+    return s;
+}
+
+// largest eigenvalue of the symmetric PSD r x r matrix M (LDS, fp64) by power iteration from the ones vector (the Gram of
+// a non-negative factor has a positive Perron vector, so the start is never orthogonal to it); x, y: r doubles in LDS.
+__device__ double pg_sigma_max(const double* M, int r, double* x, double* y, double* red) {
+    for (int a = threadIdx.x; a < r; a += blockDim.x) x[a] = 1.0;
+    __syncthreads();
+    double lam = 0.0;
+    for (int it = 0; it < 3000; ++it) {
+        for (int a = threadIdx.x; a < r; a += blockDim.x) {
+            double s = 0.0;
+            for (int b = 0; b < r; ++b) s += M[a * r + b] * x[b];
+            y[a] = s;
+        }
+        __syncthreads();
+        double n2 = 0.0, xy = 0.0, xx = 0.0;
+        for (int a = threadIdx.x; a < r; a += blockDim.x) { n2 += y[a] * y[a]; xy += x[a] * y[a]; xx += x[a] * x[a]; }
+        n2 = pg_block_sum(n2, red);
+        xy = pg_block_sum(xy, red);
+        xx = pg_block_sum(xx, red);
+        const double lam_new = xy / xx;   // Rayleigh quotient
+        if (n2 == 0.0) return 0.0;
+        const double inv = 1.0 / sqrt(n2);
+        for (int a = threadIdx.x; a < r; a += blockDim.x) x[a] = y[a] * inv;
+        __syncthreads();
+        if (it > 8 && fabs(lam_new - lam) <= 1e-15 * fabs(lam_new)) { lam = lam_new; break; }
+        lam = lam_new;
+    }
+    return lam;
+}
+
+// dst = src x_mode M  (dst[.., a', ..] = sum_a M[a'][a] src[.., a, ..]),  dims d0 x d1 x d2, M is d_mode x d_mode
+__device__ void pg_mode_dot(const double* src, double* dst, const double* M, int d0, int d1, int d2, int mode) {
+    const int S = d0 * d1 * d2;
+    const int dm = mode == 0 ? d0 : (mode == 1 ? d1 : d2);
+    const int stride = mode == 0 ? d1 * d2 : (mode == 1 ? d2 : 1);
+    for (int e = threadIdx.x; e < S; e += blockDim.x) {
+        const int a = (e / stride) % dm;           // index along the contracted mode
+        const int base = e - a * stride;
+        double s = 0.0;
+        for (int t = 0; t < dm; ++t) s += M[a * dm + t] * src[base + t * stride];
+        dst[e] = s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void nnf_ntd_core_pg_kernel(float* __restrict__ core_g, const float* __restrict__ mtx_g,
+                                                               const float* __restrict__ M0g, const float* __restrict__ M1g,
+                                                               const float* __restrict__ M2g, int d0, int d1, int d2,
+                                                               double sparse, double delta, int max_iter, double norm_sq,
+                                                               double* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int S = d0 * d1 * d2;
+    double* core = sm;
+    double* mtx = core + S;
+    double* ta = mtx + S;
+    double* tb = ta + S;
+    double* M0 = tb + S;
+    double* M1 = M0 + d0 * d0;
+    double* M2 = M1 + d1 * d1;
+    double* vx = M2 + d2 * d2;
+    double* vy = vx + 128;
+    double* red = vy + 128;   // 16 doubles
+    for (int e = threadIdx.x; e < S; e += blockDim.x) { core[e] = (double)core_g[e]; mtx[e] = (double)mtx_g[e]; }
+    for (int e = threadIdx.x; e < d0 * d0; e += blockDim.x) M0[e] = (double)M0g[e];
+    for (int e = threadIdx.x; e < d1 * d1; e += blockDim.x) M1[e] = (double)M1g[e];
+    for (int e = threadIdx.x; e < d2 * d2; e += blockDim.x) M2[e] = (double)M2g[e];
+    __syncthreads();
+    // ntd.py:592-596
+    double step = 1.0;
+    step *= 1.0 / pg_sigma_max(M0, d0, vx, vy, red);
+    step *= 1.0 / pg_sigma_max(M1, d1, vx, vy, red);
+    step *= 1.0 / pg_sigma_max(M2, d2, vx, vy, red);
+    step = rint(step * 1e6) / 1e6;
+    // ntd.py:609-619
+    int cnt = 1;
+    double upd0 = 0.0, upd = 1.0;
+    while (cnt <= max_iter && upd >= delta * upd0) {
+        pg_mode_dot(core, ta, M0, d0, d1, d2, 0);
+        pg_mode_dot(ta, tb, M1, d0, d1, d2, 1);
+        pg_mode_dot(tb, ta, M2, d0, d1, d2, 2);
+        double s2 = 0.0;
+        for (int e = threadIdx.x; e < S; e += blockDim.x) {
+            const double grad = -mtx[e] + ta[e] + sparse;
+            const double dc = fmin(step * grad, core[e]);
+            core[e] -= dc;
+            s2 += dc * dc;
+        }
+        upd = sqrt(pg_block_sum(s2, red));
+        if (cnt == 1) upd0 = upd;
+        ++cnt;
+    }
+    // ntd.py:639 (the caller adds the sparsity terms and divides by norm_sq; it recomputes this itself if it normalises
+    // the core first)
+    pg_mode_dot(core, ta, M0, d0, d1, d2, 0);
+    pg_mode_dot(ta, tb, M1, d0, d1, d2, 1);
+    pg_mode_dot(tb, ta, M2, d0, d1, d2, 2);
+    double ip = 0.0, qf = 0.0;
+    for (int e = threadIdx.x; e < S; e += blockDim.x) { ip += mtx[e] * core[e]; qf += ta[e] * core[e]; }
+    ip = pg_block_sum(ip, red);
+    qf = pg_block_sum(qf, red);
+    for (int e = threadIdx.x; e < S; e += blockDim.x) core_g[e] = (float)core[e];
+    if (threadIdx.x == 0) {
+        status[0] = (double)(cnt - 1);
+        status[1] = upd;
+        status[2] = upd0;
+        status[3] = step;
+        status[4] = norm_sq - 2.0 * ip + qf;
+        status[5] = 0.0;
+    }
+}
+
+extern "C" int nnf_ntd_core_pg_f32(nnf_ctx* ctx, float* core, const float* MtX, const float* M0, const float* M1, const float* M2,
+                                   int d0, int d1, int d2, double sparse, double delta, int max_iter, double norm_sq,
+                                   double* status_f64, void* stream) {
+    if (!ctx || !core || !MtX || !M0 || !M1 || !M2 || !status_f64 || d0 < 1 || d1 < 1 || d2 < 1 || max_iter < 0) return NNF_ERR_ARG;
+    if (d0 > 128 || d1 > 128 || d2 > 128) return NNF_ERR_UNSUPPORTED;
+    const int64_t S = (int64_t)d0 * d1 * d2;
+    const size_t shm = ((size_t)4 * S + (size_t)d0 * d0 + (size_t)d1 * d1 + (size_t)d2 * d2 + 128 + 128 + 16) * 8;
+    if (shm > (size_t)160 * 1024) return NNF_ERR_UNSUPPORTED;   // the core must fit in one workgroup's LDS
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_ntd_core_pg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)shm) != hipSuccess)
+        return NNF_ERR_LAUNCH;
+    const int threads = S >= 1024 ? 1024 : (S >= 512 ? 512 : 256);
+    hipLaunchKernelGGL(nnf_ntd_core_pg_kernel, dim3(1), dim3(threads), shm, (hipStream_t)stream, core, MtX, M0, M1, M2, d0, d1, d2,
+                       sparse, delta, max_iter, norm_sq, status_f64);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}

@@ -9,6 +9,7 @@ import threading
 import torch
 
 from . import _lib
+from .utils import errors as err
 from .utils.errors import EngineError
 
 HALS_SPARSITY, HALS_NORMALIZE, HALS_NONZERO = 1, 2, 4
@@ -205,6 +206,35 @@ class Engine:
                                              _ptr(den_vec) if den_vec is not None else None, float(beta), _ptr(O),
                                              O.stride(0), self._stream()), "nnf_mu_apply_f32")
         return O
+
+    # ---- NTD -----------------------------------------------------------------------------------------
+    def ttm3(self, T, Ft, mode):
+        """T x_mode F^T for a contiguous 3-way tensor and a transposed factor Ft (r x I_mode).
+        Result layout: mode 0 -> (r, J, K); mode 1 -> (I, r, K); mode 2 -> (r, I, J)  (include/nnfac_hip.h)."""
+        if T.dim() != 3 or not T.is_contiguous():
+            raise err.ArgumentException("ttm3 needs a contiguous 3-way tensor")
+        _chk2d(Ft, "ttm3 Ft")
+        I, J, K = T.shape
+        r = Ft.shape[0]
+        shape = (r, J, K) if mode == 0 else ((I, r, K) if mode == 1 else (r, I, J))
+        out = torch.empty(shape, dtype=torch.float32, device=T.device)
+        _lib.check(self.lib.nnf_ttm3_f32(self.ctx, _ptr(T), I, J, K, _ptr(Ft), Ft.stride(0), r, int(mode), _ptr(out),
+                                         self._stream()), "nnf_ttm3_f32")
+        return out
+
+    def ntd_core_pg(self, core, MtX, grams, sparse, delta, max_iter, norm_sq, status=None):
+        """Projected-gradient core update (ntd.py:588-619), in place on `core`; returns the 6-double status block
+        {iterations, last update, first update, step, reconstruction error, 0} (device tensor, no sync)."""
+        if core.dim() != 3 or not core.is_contiguous() or core.dtype != torch.float32:
+            raise err.ArgumentException("ntd_core_pg updates a contiguous float32 3-way core in place")
+        d0, d1, d2 = core.shape
+        st = status if status is not None else torch.empty(6, dtype=torch.float64, device=core.device)
+        MtX = MtX.contiguous()
+        M = [g.contiguous() for g in grams]
+        _lib.check(self.lib.nnf_ntd_core_pg_f32(self.ctx, _ptr(core), _ptr(MtX), _ptr(M[0]), _ptr(M[1]), _ptr(M[2]), d0, d1,
+                                                d2, float(sparse), float(delta), int(max_iter), float(norm_sq), _ptr(st),
+                                                self._stream()), "nnf_ntd_core_pg_f32")
+        return st
 
     def betadiv(self, X, Ut, V, beta, out=None):
         _chk2d(X, "betadiv X"), _chk2d(Ut, "betadiv Ut"), _chk2d(V, "betadiv V")

@@ -1,0 +1,365 @@
+"""NTD (nonnegative Tucker decomposition) driver on the MI355X engine -- drop-in for nn_fac/ntd.py
+(ntd :27-246, compute_ntd :248-433, one_ntd_step :436-645, one_ntd_step_mu :658-698) for 3-way tensors.
+
+HALS step, per updated mode n (factors kept transposed, r_n x I_n; statement -> C ABI):
+
+    elemprod[i] = F_i^T F_i, i != n                      (ntd.py:534-537)  nnf_gram_f32
+    UtU = <core x_{i!=n} elemprod, core> over modes != n (ntd.py:539-544)  tiny (core-sized) -- torch on the device
+    temp = T x_{i!=n} F_i^T                              (ntd.py:550)      nnf_ttm3_f32: ONE streaming pass over T with the
+        W^T X / X H^T kernels (first or last axis contracted), then the same product on the small intermediate;
+        T x_0 F_0^T is shared by the mode-1 and mode-2 updates (F_0 does not change between them)
+    UtM = (<temp, core> over modes != n)^T               (ntd.py:555-556)  tiny GEMM on the device
+    F_n = hals_nnls_acc(UtM, UtU, F_n^T)^T               (ntd.py:571-573)  nnf_hals_solve_f32
+    core: step, <= 300 projected-gradient steps, error   (ntd.py:581-619,639) nnf_ntd_core_pg_f32 (one launch, fp64 in LDS)
+
+MU step: the factor updates are mu_betadivmin on the unfoldings (nnf_mu_left_f32; unfoldings 1, 2 are materialised
+once per run), the core update mu_tensorial (mu.py:99-159) is the right-update accumulation of the mode-0 problem
+(nnf_mu_right_accum_f32 -- U V is never materialised) followed by two core-sized contractions, and the cost is
+nnf_betadiv_f32 on the mode-0 problem.
+
+Tensor-sized work goes through the C ABI; what stays in torch is core-sized (prod(ranks) entries) plumbing.
+"""
+import math
+import time
+import warnings
+
+import numpy as np
+import torch
+
+from .utils import errors as err
+from .utils import initialize_factors as init_factors
+from . import engine as _engine
+from ._convert import device_of, to_dev, to_dev_t, like_input
+from .update_rules.nnls import sweep_budget
+
+
+def ntd(tensor, ranks, init="random", core_0=None, factors_0=[], n_iter_max=100, tol=1e-6,
+        update_rule="hals", beta=2,
+        sparsity_coefficients=[], fixed_modes=[], normalize=[], mode_core_norm=None,
+        verbose=False, return_costs=False, deterministic=False, seed=0):
+    """Nonnegative Tucker decomposition of `tensor` (reference docstring: ntd.py:32-203)."""
+    nb_modes = len(tensor.shape)
+    if deterministic:
+        np.random.seed(seed)
+    if type(ranks) is int:   # if only one rank is provided, use it for all modes
+        ranks = [ranks for i in range(nb_modes)]
+    elif len(ranks) != nb_modes:
+        raise err.InvalidRanksException("The number of ranks is different than the dim of the tensor, which is incorrect.") from None
+    for i in range(nb_modes):
+        if ranks[i] > tensor.shape[i]:
+            ranks[i] = tensor.shape[i]
+            warnings.warn(f"The {i}-th mode rank was larger than the shape of the tensor, which is incorrect (rank: {ranks[i]}, tensor shape: {tensor.shape[i]}). The rank was then set to the shape of the tensor.")
+    if update_rule == "hals":
+        assert beta == 2, f"Beta parameter is only used for MU update rule. Please set update_rule to 'mu' to use another beta value than 2. (Current setting: beta = {beta} and update_rule = {update_rule})."
+    if init.lower() == "custom":
+        factors = factors_0
+        core = core_0
+        if len(factors) != nb_modes:
+            raise err.CustomNotEngouhFactors("Custom initialization, but not enough factors")
+        else:
+            for array in factors:
+                if array is None:
+                    raise err.CustomNotValidFactors("Custom initialization, but (at least) one factor is set to 'None'")
+            if core is None:
+                raise err.CustomNotValidCore("Custom initialization, but the core is set to 'None'")
+    else:
+        core, factors = init_factors.ntd_initialization(tensor, ranks, init, deterministic=deterministic, seed=seed)
+    if (init.lower() == "chromas") and (0 not in fixed_modes):
+        fixed_modes.append(0)
+    return compute_ntd(tensor, ranks, core, factors, n_iter_max=n_iter_max, tol=tol,
+                       update_rule=update_rule, beta=beta,
+                       sparsity_coefficients=sparsity_coefficients, fixed_modes=fixed_modes,
+                       normalize=normalize, mode_core_norm=mode_core_norm,
+                       verbose=verbose, return_costs=return_costs, deterministic=deterministic, seed=seed)
+
+
+class _NtdState:
+    """Device-resident tensor, its squared norm, (MU only) the materialised unfoldings, and the per-step status block."""
+
+    def __init__(self, eng, T):
+        if T.dim() != 3:
+            raise NotImplementedError("the MI355X engine accelerates 3-way tensors (nnf_ttm3_f32)")
+        self.eng = eng
+        self.T = T.contiguous()
+        I, J, K = self.T.shape
+        self.t0 = self.T.view(I, J * K)
+        self.norm2 = eng.dot(self.t0, self.t0)          # float64 device scalar, ||T||^2 (read once by the driver)
+        self.norm2_host = None
+        self._unf = {0: self.t0}
+        # 3 HALS status blocks (8 doubles each) + 6 doubles of the core update + the cost
+        self.block = torch.zeros(8 * 3 + 8, dtype=torch.float64, device=T.device)
+
+    def unfolded(self, mode):
+        if mode not in self._unf:
+            self._unf[mode] = torch.movedim(self.T, mode, 0).reshape(self.T.shape[mode], -1).contiguous()
+        return self._unf[mode]
+
+    def norm_sq(self):
+        if self.norm2_host is None:
+            self.norm2_host = float(self.norm2)
+        return self.norm2_host
+
+
+def _normalize_core(core, mode_core_norm):
+    """ntd.py:621-626: every mode-`mode_core_norm` slice of the core divided by its l2 norm (zero slices are left alone)."""
+    unf = torch.movedim(core, mode_core_norm, 0)
+    nrm = unf.reshape(unf.shape[0], -1).norm(dim=1)
+    scale = torch.where(nrm != 0, 1.0 / nrm, torch.ones_like(nrm))
+    shape = [-1] + [1] * (core.dim() - 1)
+    return torch.movedim(unf * scale.view(shape), 0, mode_core_norm).contiguous()
+
+
+def _core_mode_dots(core, mats, skip=None):
+    """tl.tenalg.multi_mode_dot(core, mats, skip) for a core-sized tensor (mats[i]: new_dim x old_dim)."""
+    out = core
+    for i, M in enumerate(mats):
+        if i == skip:
+            continue
+        out = torch.movedim(torch.tensordot(M, out, dims=([1], [i])), 0, i)
+    return out
+
+
+def _one_ntd_step_dev(st, core_in, Ft_in, sparsity_coefficients, fixed_modes, normalize, mode_core_norm, alpha, delta):
+    """ntd.py:514-645 on the device.  Ft: transposed factors (r_n x I_n).  Returns (core, Ft, number of HALS solves);
+    the cost is left in st.block[30] and the status words in st.block[0:24] / [24:30]."""
+    eng = st.eng
+    for fixed_value in fixed_modes:
+        sparsity_coefficients[fixed_value] = None
+    core = core_in.clone()
+    Ft = list(Ft_in)
+    dev = st.T.device
+    modes_list = [m for m in range(3) if m not in fixed_modes]
+    if not modes_list:
+        raise UnboundLocalError("one_ntd_step needs at least one non-fixed factor mode (ntd.py:581 reuses its 'temp')")
+    nstat = 0
+    W0 = None           # T x_0 F_0^T, shared by the mode-1 and mode-2 updates
+    grams = [None, None, None]
+    deterministic = math.isinf(alpha)
+    for mode in modes_list:
+        if not deterministic:
+            torch.cuda.synchronize(dev)
+            t0 = time.time()
+        for i in range(3):
+            if i != mode:
+                grams[i] = eng.gram(Ft[i])                                    # elemprod (ntd.py:534-537)
+        others = [i for i in range(3) if i != mode]
+        tmp = _core_mode_dots(core, [grams[i] if i != mode else None for i in range(3)], skip=mode)
+        UtU = torch.tensordot(tmp, core, dims=(others, others)).contiguous()  # r_n x r_n (ntd.py:544)
+        # temp = T x_{i != mode} F_i^T (ntd.py:550), arranged so that every product contracts a first or a last axis
+        if mode == 0:
+            w = eng.ttm3(st.T, Ft[2], 2)                                      # (c, I, J)
+            c_, I_, J_ = w.shape
+            w = eng.xht(w.view(c_ * I_, J_), Ft[1]).view(-1, c_, I_)          # (b, c, I)
+            temp = w.permute(2, 0, 1)                                         # view as (I, b, c)
+        else:
+            if W0 is None:
+                W0 = eng.ttm3(st.T, Ft[0], 0)                                 # (a, J, K)
+            a_, J_, K_ = W0.shape
+            if mode == 1:
+                w = eng.xht(W0.view(a_ * J_, K_), Ft[2]).view(-1, a_, J_)     # (c, a, J)
+                temp = w.permute(1, 2, 0)                                     # (a, J, c)
+            else:
+                temp = torch.matmul(Ft[1], W0)                                # (a, b, K): core-width batched GEMM
+        MtU = torch.tensordot(temp, core, dims=(others, others))              # I_n x r_n (ntd.py:555)
+        UtM = MtU.t().contiguous()
+        new = Ft[mode].clone()
+        budget = 100
+        if not deterministic:
+            torch.cuda.synchronize(dev)
+            timer = time.time() - t0
+            probe = new.clone()
+            t0 = time.time()
+            eng.hals_sweeps(UtM, UtU, probe, 1, sparsity=sparsity_coefficients[mode], normalize=normalize[mode])
+            torch.cuda.synchronize(dev)
+            rho = timer / max(time.time() - t0, 10e-7) if timer else 100000
+            budget = max(1, sweep_budget(100, alpha, rho))
+        eng.hals_solve(UtM, UtU, new, budget, delta=delta, sparsity=sparsity_coefficients[mode],
+                       normalize=normalize[mode], status=st.block[8 * nstat:8 * nstat + 8])
+        nstat += 1
+        Ft[mode] = new
+        if mode == 0:
+            W0 = None
+    last = modes_list[-1]
+    # all_MtX = temp x_last F_last^T with the NEW factor; all_MtM = elemprod with the last Gram refreshed (ntd.py:581-583)
+    all_MtX = torch.movedim(torch.tensordot(Ft[last], temp, dims=([1], [last])), 0, last).contiguous()
+    grams[last] = eng.gram(Ft[last])
+    for i in range(3):
+        if grams[i] is None:            # a fixed mode that was never "other": cannot happen with >= 1 free mode of 3
+            grams[i] = eng.gram(Ft[i])
+    sparse = 0 if sparsity_coefficients[-1] is None else sparsity_coefficients[-1]
+    pg = st.block[24:30]
+    eng.ntd_core_pg(core, all_MtX, grams, sparse, delta, 300, st.norm_sq(), status=pg)
+    cost = st.block[30:31]
+    if normalize[-1]:
+        core = _normalize_core(core, mode_core_norm)
+        full = _core_mode_dots(core, grams)
+        cost.copy_((st.norm2 - 2 * (all_MtX.double() * core.double()).sum() + (full.double() * core.double()).sum()).reshape(1))
+    else:
+        cost.copy_(pg[4:5])
+    sparsity_error = None
+    for index, sp in enumerate(sparsity_coefficients):
+        if sp:
+            if index < 3:      # np.linalg.norm(factor, ord=1): max column abs-sum = max row abs-sum of the transposed factor
+                term = 2 * sp * Ft[index].abs().sum(dim=1).max().double()
+            elif index == 3:
+                term = 2 * sp * core.abs().sum().double()
+            else:
+                raise NotImplementedError("TODEBUG: Too many sparsity coefficients, should have been raised before.")
+            sparsity_error = term if sparsity_error is None else sparsity_error + term
+    if sparsity_error is not None:
+        cost.add_(sparsity_error)
+    cost.div_(st.norm2)
+    return core, Ft, nstat
+
+
+def _core_expand_mode0(core, Ft):
+    """unfold(core x_1 F_1 x_2 F_2, 0): the r_0 x (J*K) right operand of the mode-0 matrix problem (core-width GEMMs)."""
+    w = torch.tensordot(core, Ft[2], dims=([2], [0]))                        # (a, b, K)
+    w = torch.einsum('abk,bj->ajk', w, Ft[1])                                 # (a, J, K)
+    return w.reshape(w.shape[0], -1).contiguous()
+
+
+def _mu_tensorial_dev(st, core, Ft, beta):
+    """mu.py:138-159.  num/den = (L2 | L1) x_i F_i^T: the mode-0 product is the right-update accumulation of the matrix
+    problem T_(0) ~ F_0 V0 (one fused pass over T), the other two are core-width contractions."""
+    eng = st.eng
+    if beta < 0:
+        raise err.InvalidArgumentValue("Invalid value for beta: negative one.") from None
+    V0 = _core_expand_mode0(core, Ft)
+    num, den, dvec = eng.mu_right_accum(st.t0, Ft[0], V0, beta)
+    J, K = st.T.shape[1], st.T.shape[2]
+
+    def down(x):   # (a, J*K) -> x_1 F_1^T x_2 F_2^T -> (a, b, c)
+        w = torch.tensordot(x.view(-1, J, K), Ft[2], dims=([2], [1]))         # (a, J, c)
+        return torch.einsum('ajc,bj->abc', w, Ft[1])
+    num3 = down(num)
+    if dvec is not None:   # beta = 1: L1 = ones -> outer product of the factors' column sums
+        s1, s2 = Ft[1].sum(dim=1).double(), Ft[2].sum(dim=1).double()
+        den3 = (dvec.view(-1, 1, 1) * s1.view(1, -1, 1) * s2.view(1, 1, -1)).float()
+    else:
+        den3 = down(den)
+    from .utils.beta_divergence import gamma_beta
+    ratio = num3 / den3
+    g = gamma_beta(beta)
+    if g != 1:
+        ratio = ratio ** g
+    return torch.clamp(core * ratio, min=1e-12).contiguous()
+
+
+def _one_ntd_step_mu_dev(st, core_in, Ft_in, beta, fixed_modes, normalize, mode_core_norm):
+    """ntd.py:664-698 on the device; the (un-normalised, ntd.py:696) cost is left in st.block[30]."""
+    eng = st.eng
+    core = core_in.clone()
+    Ft = list(Ft_in)
+    for mode in [m for m in range(3) if m not in fixed_modes]:
+        # V = unfold(core x_{i != mode} F_i, mode): r_mode x prod(other dims), core-width GEMMs
+        mats = [Ft[i].t() if i != mode else None for i in range(3)]
+        V = torch.movedim(_core_mode_dots(core, mats, skip=mode), mode, 0)
+        V = V.reshape(V.shape[0], -1).contiguous()
+        Ft[mode] = eng.mu_left(st.unfolded(mode), Ft[mode], V, beta)          # mu_betadivmin (ntd.py:672)
+    core = _mu_tensorial_dev(st, core, Ft, beta)
+    if normalize[-1]:
+        core = _normalize_core(core, mode_core_norm)
+    eng.betadiv(st.t0, Ft[0], _core_expand_mode0(core, Ft), beta, out=st.block[30:31])
+    return core, Ft
+
+
+def compute_ntd(tensor_in, ranks, core_in, factors_in, n_iter_max=100, tol=1e-6,
+                update_rule="hals", beta=2,
+                sparsity_coefficients=[], fixed_modes=[], normalize=[], mode_core_norm=None,
+                verbose=False, return_costs=False, deterministic=False, seed=0, sweep_log=None, pg_log=None):
+    """Outer loop of ntd.py:355-433.  Returns (core, factors) [, costs, toc]; sweep_log / pg_log (not in the reference)
+    collect the inner sweep counts and projected-gradient iteration counts."""
+    dev = device_of(tensor_in, core_in, *factors_in)
+    eng = _engine.get_engine(dev)
+    st = _NtdState(eng, to_dev(tensor_in, dev))
+    core = to_dev(core_in, dev).clone().contiguous()
+    Ft = [to_dev_t(f, dev).clone() for f in factors_in]
+    nb_modes = st.T.dim()
+    if sparsity_coefficients is None or len(sparsity_coefficients) != nb_modes + 1:
+        print("Irrelevant number of sparsity coefficient (different from the number of modes + 1 for the core), they have been set to None.")
+        sparsity_coefficients = [None for i in range(nb_modes + 1)]
+    if fixed_modes is None:
+        fixed_modes = []
+    if normalize is None or len(normalize) != nb_modes + 1:
+        print("Irrelevant number of normalization booleans (different from the number of modes + 1 for the core), they have been set to False.")
+        normalize = [False for i in range(nb_modes + 1)]
+    if normalize[-1] and (mode_core_norm is None or mode_core_norm < 0 or mode_core_norm >= nb_modes):
+        print("The core was asked to be normalized, but an invalid mode was specified. Normalization has been set to False.")
+        normalize[-1] = False
+    if not normalize[-1] and (mode_core_norm is not None and mode_core_norm >= 0 and mode_core_norm < nb_modes):
+        print("The core was asked NOT to be normalized, but mode_core_norm was set to a valid norm. Is this a mistake?")
+    cost_fct_vals, toc = [], []
+    tic = time.time()
+    for iteration in range(n_iter_max):
+        nstat = 0
+        if update_rule == "hals":
+            core, Ft, nstat = _one_ntd_step_dev(st, core, Ft, sparsity_coefficients, fixed_modes, normalize, mode_core_norm,
+                                                math.inf if deterministic else 0.5, 0.01)
+        elif update_rule == "mu":
+            core, Ft = _one_ntd_step_mu_dev(st, core, Ft, beta, fixed_modes, normalize, mode_core_norm)
+        else:
+            raise err.InvalidArgumentValue(f"The update rule provided is not valid. Please choose between 'hals' and 'mu' (Got {update_rule}).")
+        host = st.block.cpu()
+        cost = float(host[30])
+        for i in range(nstat):
+            if int(host[8 * i + _engine.ST_ERR]) != 0:
+                raise err.EngineError("hals grid barrier timed out; result invalid")
+        if sweep_log is not None:
+            sweep_log.extend(int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(nstat))
+        if pg_log is not None and update_rule == "hals":
+            pg_log.append(int(host[24]))
+        toc.append(time.time() - tic)
+        cost_fct_vals.append(cost)
+        if verbose:
+            if iteration == 0:
+                print('Normalized cost function value={}'.format(cost))
+            else:
+                if cost_fct_vals[-2] - cost_fct_vals[-1] > 0:
+                    print('Normalized cost function value={}, variation={}.'.format(
+                        cost_fct_vals[-1], cost_fct_vals[-2] - cost_fct_vals[-1]))
+                else:
+                    print('\033[91m' + 'Normalized cost function value={}, variation={}.'.format(
+                        cost_fct_vals[-1], cost_fct_vals[-2] - cost_fct_vals[-1]) + '\033[0m')
+        if iteration > 0 and abs(cost_fct_vals[-2] - cost_fct_vals[-1]) < tol:
+            if verbose:
+                print('Converged in {} iterations.'.format(iteration))
+            break
+    core_out = like_input(core, core_in)
+    factors = [like_input(f.t(), factors_in[i]) for i, f in enumerate(Ft)]
+    if return_costs:
+        return core_out, factors, cost_fct_vals, toc
+    return core_out, factors
+
+
+def one_ntd_step(tensor, ranks, in_core, in_factors, norm_tensor,
+                 sparsity_coefficients, fixed_modes, normalize, mode_core_norm,
+                 alpha=0.5, delta=0.01):
+    """One HALS pass over the modes + projected-gradient core update (ntd.py:436-645).
+    Returns (core, factors, normalised cost).  `norm_tensor` is accepted for signature parity; ||T||^2 is recomputed on
+    the device."""
+    dev = device_of(tensor, in_core, *in_factors)
+    eng = _engine.get_engine(dev)
+    st = _NtdState(eng, to_dev(tensor, dev))
+    core = to_dev(in_core, dev).contiguous()
+    Ft = [to_dev_t(f, dev) for f in in_factors]
+    core, Ft, nstat = _one_ntd_step_dev(st, core, Ft, sparsity_coefficients, fixed_modes, normalize, mode_core_norm,
+                                        alpha, delta)
+    host = st.block.cpu()
+    for i in range(nstat):
+        if int(host[8 * i + _engine.ST_ERR]) != 0:
+            raise err.EngineError("hals grid barrier timed out; result invalid")
+    return like_input(core, in_core), [like_input(f.t(), in_factors[i]) for i, f in enumerate(Ft)], float(host[30])
+
+
+def one_ntd_step_mu(tensor, ranks, in_core, in_factors, beta, norm_tensor,
+                    fixed_modes, normalize, mode_core_norm):
+    """One MU pass over the modes and the core (ntd.py:658-698).  Returns (core, factors, beta-divergence)."""
+    dev = device_of(tensor, in_core, *in_factors)
+    eng = _engine.get_engine(dev)
+    st = _NtdState(eng, to_dev(tensor, dev))
+    core = to_dev(in_core, dev).contiguous()
+    Ft = [to_dev_t(f, dev) for f in in_factors]
+    core, Ft = _one_ntd_step_mu_dev(st, core, Ft, beta, fixed_modes, normalize, mode_core_norm)
+    return (like_input(core, in_core), [like_input(f.t(), in_factors[i]) for i, f in enumerate(Ft)],
+            float(st.block[30]))

@@ -39,3 +39,18 @@ def switch_alternate_mu(data, U, V, beta, matrix):
         return like_input(out, V)
     else:
         raise err.InvalidArgumentValue(f"Invalid value for matrix: got {matrix}, but it must be 'U' or 'W' for the first matrix, and 'V' or 'H' for the second one.") from None
+
+
+def mu_tensorial(G, factors, tensor, beta):
+    """Core update of NTD-MU (reference mu.py:99-159): max(G * (L2 x F^T / L1 x F^T)^gamma, epsilon).
+    Same arguments as the reference (core, list of factors I_n x r_n, tensor, beta); 3-way tensors."""
+    from .. import engine as _engine
+    from .._convert import device_of, to_dev, to_dev_t, like_input
+    from ..ntd import _NtdState, _mu_tensorial_dev
+    if beta < 0:
+        raise err.InvalidArgumentValue("Invalid value for beta: negative one.") from None
+    dev = device_of(tensor, G, *factors)
+    eng = _engine.get_engine(dev)
+    st = _NtdState(eng, to_dev(tensor, dev))
+    core = _mu_tensorial_dev(st, to_dev(G, dev).contiguous(), [to_dev_t(f, dev) for f in factors], beta)
+    return like_input(core, G)

@@ -36,3 +36,23 @@ def ntf_initialization(tensor, rank, init_type, deterministic=False, seed=0):
     if kind == "nndsvd":
         raise NotImplementedError("nndsvd initialisation is outside the accelerated hot path; pass init='custom'")
     raise err.InvalidInitializationType("Initialization type not understood.")
+
+
+def ntd_initialization(tensor, ranks, init_type, deterministic=False, seed=0):
+    """initialize_factors.py:50-83; 'tucker' / 'chromas' need a Tucker decomposition (HOSVD), outside the hot path."""
+    kind = init_type.lower()
+    if kind == "random":
+        factors = []
+        if deterministic:
+            np.random.seed(seed)
+            random.seed(seed)
+        for mode in range(len(tensor.shape)):
+            one_factor = np.random.rand(tensor.shape[mode], ranks[mode])
+            one_factor[one_factor < 1e-12] = 1e-12   # To avoid zeros
+            factors.append(one_factor)
+        the_core = np.random.rand(int(np.prod(ranks))).reshape(tuple(ranks))
+        the_core[the_core < 1e-12] = 1e-12
+        return the_core, factors
+    if kind in ("tucker", "chromas"):
+        raise NotImplementedError("tucker (HOSVD) initialisation is outside the accelerated hot path; pass init='custom'")
+    raise err.InvalidInitializationType("Initialization type not understood.")

@@ -1,0 +1,172 @@
+"""GPU parity: NTD pieces and drivers vs the oracle and the G7 fixtures (reference outputs).
+
+Stated fp32 tolerances: mode products / single kernels rel <= 1e-5; projected-gradient core update (fp64 inside the
+kernel, fp32 inputs) rel <= 1e-5 with the iteration count equal; NTD-HALS factors and core rel_fro <= 1e-3 after 4-10 outer
+iterations, inner sweep counts equal; NTD-MU rel_fro <= 1e-4, cost rel <= 1e-4.  The NTD-HALS cost is the reference's
+Gram-form expression (ntd.py:639), ~1e-8 of its terms on near-exact data: it is compared with an ABSOLUTE tolerance of
+2e-6 on the normalised value (fp32 inputs cannot resolve more).
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import nnfac_oracle as orc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(built_lib):
+    from nn_fac_amd.engine import get_engine
+    return get_engine("cuda:0")
+
+
+def dev(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda").contiguous()
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.mark.parametrize("shape,r", [((53, 85, 82), 9), ((7, 5, 3), 2), ((130, 33, 70), 17), ((64, 64, 64), 64), ((9, 300, 11), 5)])
+def test_ttm3_all_modes(eng, shape, r):
+    rng = np.random.RandomState(sum(shape) + r)
+    T = rng.rand(*shape)
+    for mode in range(3):
+        F = rng.rand(shape[mode], r)
+        want = orc.mode_dot(T, F.T, mode)                       # axis `mode` replaced by r, in place
+        got = eng.ttm3(dev(T), dev(F.T.copy()), mode).cpu().numpy()
+        if mode == 0:
+            assert got.shape == (r, shape[1], shape[2])
+        elif mode == 1:
+            assert got.shape == (shape[0], r, shape[2])
+        else:
+            assert got.shape == (r, shape[0], shape[1])
+            got = np.moveaxis(got, 0, 2)
+        assert rel(got, want) < 1e-5
+
+
+@pytest.mark.parametrize("dims,sparse", [((9, 9, 3), 0.0), ((4, 3, 2), 0.05), ((16, 12, 20), 0.0), ((1, 5, 1), 0.0)])
+def test_core_projected_gradient(eng, dims, sparse):
+    rng = np.random.RandomState(sum(dims))
+    shape = tuple(5 * d + 3 for d in dims)
+    F = [rng.rand(shape[i], dims[i]) for i in range(3)]
+    core_true = rng.rand(*dims)
+    T = orc.multi_mode_dot(core_true, F) + 0.01 * rng.rand(*shape)
+    # fp32-rounded inputs on both sides
+    MtX = orc.multi_mode_dot(T, F, transpose=True).astype(np.float32).astype(np.float64)
+    M = [(f.T @ f).astype(np.float32).astype(np.float64) for f in F]
+    core0 = rng.rand(*dims).astype(np.float32).astype(np.float64)
+    step = 1.0
+    for m_ in M:
+        step *= 1 / np.linalg.svd(m_, compute_uv=False)[0]
+    step = round(step, 6)
+    core, cnt, upd0, upd = core0.copy(), 1, 0, 1
+    while cnt <= 300 and upd >= 0.01 * upd0:
+        grad = -MtX + orc.multi_mode_dot(core, M) + sparse * np.ones(core.shape)
+        dc = np.minimum(step * grad, core)
+        core = core - dc
+        upd = np.sqrt(np.sum(dc ** 2))
+        if cnt == 1:
+            upd0 = upd
+        cnt += 1
+    nrm2 = float(np.sum(T ** 2))
+    want_err = nrm2 - 2 * np.sum(MtX * core) + np.sum(orc.multi_mode_dot(core, M) * core)
+    cd = dev(core0)
+    st = eng.ntd_core_pg(cd, dev(MtX), [dev(m_) for m_ in M], sparse, 0.01, 300, nrm2).cpu().numpy()
+    assert int(st[0]) == cnt - 1
+    assert abs(st[3] - step) <= 1e-12
+    assert rel(cd.cpu().numpy(), core) < 1e-5
+    assert abs(st[4] - want_err) <= 1e-6 * nrm2
+
+
+def _small(golden):
+    g = golden("g7_ntd.npz")
+    return g, g["small_T"], g["small_core0"], [g[f"small_F0_{i}"] for i in range(3)]
+
+
+@pytest.mark.parametrize("name,sp,fixed,norm,mcn", [("plain", [None] * 4, [], [False] * 4, None),
+                                                    ("sparse", [0.01, None, 0.02, 0.05], [], [False] * 4, None),
+                                                    ("norm", [None] * 4, [], [True, False, True, True], 1),
+                                                    ("fixed1", [None] * 4, [1], [False] * 4, None)])
+def test_one_ntd_step_against_reference_fixture(golden, name, sp, fixed, norm, mcn):
+    from nn_fac_amd.ntd import one_ntd_step
+    g, T, core, f = _small(golden)
+    rk = list(core.shape)
+    nrm = np.sqrt(np.sum(T ** 2))
+    costs = []
+    for _ in range(4):
+        core, f, c = one_ntd_step(T, rk, core, f, nrm, list(sp), list(fixed), list(norm), mcn, alpha=math.inf, delta=0.01)
+        costs.append(c)
+    assert rel(core, g[f"small_hals_{name}_core"]) < 1e-3
+    for i in range(3):
+        assert rel(f[i], g[f"small_hals_{name}_F{i}"]) < 1e-3
+    np.testing.assert_allclose(costs, g[f"small_hals_{name}_costs"], rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("beta", [0, 0.5, 1, 2, 3])
+def test_one_ntd_step_mu_and_mu_tensorial_against_reference_fixture(golden, beta):
+    from nn_fac_amd.ntd import one_ntd_step_mu
+    from nn_fac_amd.update_rules.mu import mu_tensorial
+    g, T, core, f = _small(golden)
+    rk = list(core.shape)
+    assert rel(mu_tensorial(core, f, T, beta), g[f"small_mut_b{beta}"]) < 2e-5
+    costs = []
+    for _ in range(4):
+        core, f, c = one_ntd_step_mu(T, rk, core, f, beta, None, [], [False] * 4, None)
+        costs.append(c)
+    assert rel(core, g[f"small_mu_b{beta}_core"]) < 1e-4
+    for i in range(3):
+        assert rel(f[i], g[f"small_mu_b{beta}_F{i}"]) < 1e-4
+    np.testing.assert_allclose(costs, g[f"small_mu_b{beta}_costs"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 2), ("mu", 1), ("mu", 0)])
+def test_ntd_on_the_reference_test_problem(golden, rule, beta):
+    """The configuration of the reference's known-answer tests (NTD_tests.py:138-255): 53x85x82, ranks (9,9,3), random
+    init with seed 0, 10 iterations -- against the reference's full outputs stored in G7."""
+    from nn_fac_amd.ntd import ntd
+    from test_oracle_golden import ntd_reference_tensor
+    g = golden("g7_ntd.npz")
+    shape, ranks = tuple(int(x) for x in g["ref_shape"]), [int(x) for x in g["ref_ranks"]]
+    T = ntd_reference_tensor(shape, ranks)
+    core, facs, costs, toc = ntd(T, list(ranks), init="random", n_iter_max=10, tol=1e-8, update_rule=rule, beta=beta,
+                                 sparsity_coefficients=[None] * 4, fixed_modes=[], normalize=[False] * 4, verbose=False,
+                                 return_costs=True, deterministic=True, seed=0)
+    tag = f"ref_{rule}_b{beta}"
+    tol = 1e-3 if rule == "hals" else 1e-4
+    assert rel(core, g[f"{tag}_core"]) < tol
+    for i in range(3):
+        assert rel(facs[i], g[f"{tag}_F{i}"]) < tol
+    want = g[f"{tag}_costs"]
+    if rule == "hals":
+        assert len(costs) == len(want)
+        np.testing.assert_allclose(costs, want, rtol=0, atol=2e-6)
+    else:
+        np.testing.assert_allclose(costs, want, rtol=1e-4)
+
+
+def test_ntd_argument_errors():
+    """Raise sites of ntd.py:213,228,232,234 and initialize_factors.py:83."""
+    from nn_fac_amd.ntd import ntd
+    from nn_fac_amd.utils import errors as err
+    T = np.random.RandomState(0).rand(6, 5, 4)
+    kw = dict(sparsity_coefficients=[None] * 4, normalize=[False] * 4)
+    with pytest.raises(err.InvalidRanksException):
+        ntd(T, [3, 4], init="random", **kw)
+    with pytest.raises(err.InvalidInitializationType):
+        ntd(T, [2, 4, 3], init="string", **kw)
+    f = [np.ones((6, 2)), np.ones((5, 2)), np.ones((4, 2))]
+    with pytest.raises(err.CustomNotEngouhFactors):
+        ntd(T, [2, 2, 2], init="custom", factors_0=f[:2], **kw)
+    with pytest.raises(err.CustomNotValidFactors):
+        ntd(T, [2, 2, 2], init="custom", factors_0=[f[0], f[1], None], **kw)
+    with pytest.raises(err.CustomNotValidCore):
+        ntd(T, [2, 2, 2], init="custom", factors_0=f, core_0=None, **kw)

@@ -19,7 +19,7 @@
 
 // prep: padded Gram, 1/diag, zeroed barrier words and status
 __global__ void nnf_hals_prep_kernel(const float* __restrict__ UtU, int64_t ldg, int r, int RP, float* __restrict__ Gp,
-                                     float* __restrict__ dinv, unsigned* counter, double* status) {
+                                     float* __restrict__ dinv, float* __restrict__ Gs, unsigned* counter, double* status) {
     const int RS = 32 * ((RP + 31) / 32);      // row stride of the padded Gram (32-float blocks, k_hals_fast.hip)
     for (int e = threadIdx.x; e < RP * RS; e += blockDim.x) {
         const int a = e / RS, b = e - a * RS;
@@ -29,6 +29,23 @@ __global__ void nnf_hals_prep_kernel(const float* __restrict__ UtU, int64_t ldg,
         const float d = (k < r) ? UtU[(int64_t)k * ldg + k] : 0.f;
         dinv[2 * k] = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;   // pair (1/diag, nz): nz = 0 = leave the row alone
         dinv[2 * k + 1] = (d != 0.f) ? 1.f : 0.f;
+    }
+    if (threadIdx.x == 0) {   // all-live flag: no zero on the diagonal of the r x r Gram
+        float live = 1.f;
+        for (int k = 0; k < r; ++k)
+            if (UtU[(int64_t)k * ldg + k] == 0.f) live = 0.f;
+        dinv[2 * RP] = live;
+    }
+    if (Gs) {   // rows scaled by 1/diag (rows with a zero diagonal: all zero), same padding
+        for (int e = threadIdx.x; e < RP * RS; e += blockDim.x) {
+            const int a = e / RS, b = e - a * RS;
+            float g = 0.f;
+            if (a < r && b < r) {
+                const float d = UtU[(int64_t)a * ldg + a];
+                if (d != 0.f) g = UtU[(int64_t)a * ldg + b] * (float)(1.0 / (double)d);
+            }
+            Gs[e] = g;
+        }
     }
     if (threadIdx.x == 0) {
         *counter = 0u;
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(256) void nnf_hals_sum_sweeps_kernel(const double* 
 
 // ---------------------------------------------------------------------------------------------------------
 static int pick_rp(int r) {
-    static const int opts[] = {8, 16, 24, 32, 40, 48, 52, 56, 64, 80, 96, 104, 112, 128};
+    static const int opts[] = {8, 16, 24, 32, 40, 48, 50, 52, 56, 64, 80, 96, 104, 112, 128};
     for (int o : opts)
         if (r <= o) return o;
     return -1;
@@ -190,7 +207,9 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     const bool force_lane = force && force[0] == 'l', force_quad = force && force[0] == 'q';
     const bool quad = !generic && !force_lane && (ncols <= 32768 || force_quad) && (int64_t)(r + 16) * (ldv > ldm ? ldv : ldm) * 4 < (int64_t)0x7fff0000 &&
                       nnf_hals_quad_fits(ctx, r, ncols, max_blocks);
-    size_t gfloats = (size_t)RP * RS + 2 * RP;
+    const size_t gs_off = (((size_t)RP * RS + 2 * RP + 1) + 15) & ~(size_t)15;   // scaled image, 64-byte aligned
+    const bool want_gs = !generic && RP > 32 && RP <= 64;
+    size_t gfloats = gs_off + (want_gs ? (size_t)RP * RS : 0);
     if (quad && nnf_hals_quad_gram_floats(r) > gfloats) gfloats = nnf_hals_quad_gram_floats(r);
     float* Gp = (float*)cur.take(gfloats * 4);   // padded Gram, then the (1/diag, nz) pairs (quad: scaled Gram, 1/diag)
     float* dinv = Gp ? Gp + (size_t)RP * RS : nullptr;
@@ -202,8 +221,8 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     if (!Gp || !dinv || !counter || !slots || !sslots || (MODE == 1 && !sweep_partials))
         return NNF_ERR_WORKSPACE;
     if (!quad) {
-        hipLaunchKernelGGL(nnf_hals_prep_kernel, dim3(1), dim3(256), 0, st, UtU, ldg, r, RP, Gp, dinv, counter,
-                           MODE == 0 ? status : (double*)nullptr);
+        hipLaunchKernelGGL(nnf_hals_prep_kernel, dim3(1), dim3(256), 0, st, UtU, ldg, r, RP, Gp, dinv,
+                           want_gs ? Gp + gs_off : (float*)nullptr, counter, MODE == 0 ? status : (double*)nullptr);
         NNF_CHECK_LAUNCH();
         if (nsweeps == 0) return NNF_OK;
     }
@@ -214,8 +233,8 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     if (quad) {
         if ((((int64_t)(r - 1) * ldv + ncols) * 4) >= (int64_t)0x7fff0000 || (((int64_t)(r - 1) * ldm + ncols) * 4) >= (int64_t)0x7fff0000)
             return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
-        hals_args a{UtM, ldm, nullptr, nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status, sweep_partials, snapshots,
-                    snap_stride};
+        hals_args a{UtM, ldm, nullptr, nullptr, nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status, sweep_partials,
+                    snapshots, snap_stride};
         rc = nnf_hals_quad_run(ctx, UtU, ldg, Gp, counter, a, &nblocks, st);
         if (rc != NNF_OK) return rc;
         if (nsweeps == 0) return NNF_OK;
@@ -239,8 +258,8 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     } else {
         if ((((int64_t)(r - 1) * ldv + ncols) * 4) >= (int64_t)0x7fff0000 || (((int64_t)(r - 1) * ldm + ncols) * 4) >= (int64_t)0x7fff0000)
             return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
-        hals_args a{UtM, ldm, Gp, dinv, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status, sweep_partials, snapshots,
-                    snap_stride};
+        hals_args a{UtM, ldm, Gp, dinv, want_gs ? Gp + gs_off : nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status,
+                    sweep_partials, snapshots, snap_stride};
         if (RP <= 48) rc = nnf_hals_fast_part0(ctx, RP, a, max_blocks, &nblocks, st);
         else if (RP <= 64) rc = nnf_hals_fast_part1(ctx, RP, a, max_blocks, &nblocks, st);
         else if (RP <= 104) rc = nnf_hals_fast_part2(ctx, RP, a, max_blocks, &nblocks, st);

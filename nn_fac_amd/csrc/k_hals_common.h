@@ -154,7 +154,8 @@ __device__ __forceinline__ bool hals_collect(const hals_sync& sy, int s, int nbl
 struct hals_args {
     const float* UtM; int64_t ldm;
     const float* Gp;      // padded Gram  RP x RP (zeros outside r x r), workspace
-    const float* dinv;    // 1/diag (0 where the diagonal is 0 or padded), workspace
+    const float* dinv;    // RP pairs (1/diag, nz) (0, 0 where the diagonal is 0 or padded), then the all-live flag; workspace
+    const float* Gs;      // lane layout, 32 < RP <= 64: Gram rows scaled by 1/diag (k_hals_fast.hip), workspace
     float* V; int64_t ldv;
     int r; int64_t ncols;
     int max_sweeps; double delta; float sp;

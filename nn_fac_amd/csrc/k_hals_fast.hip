@@ -71,62 +71,68 @@ __device__ __forceinline__ f32x2 sg_pair(const sgbuf<W>& d, int p) {   // floats
     return f32x2{d.r[j3], d.r[j3 + 1]};
 }
 
-// One Gauss-Seidel sweep for 32 < R <= 64 with the UtM column resident (b already holds UtM - sp).
+// One Gauss-Seidel sweep for 32 < R <= 64 with the UtM column resident.  Operands are pre-scaled by 1/diag:
+// Gs = diag(1/diag) UtU (rows with a zero diagonal are all zero) and b = (UtM - sp)/diag, so a row update is
+//     x = b[k] - Gs[k,:].v ;  d = max(x, -v[k]) ;  v[k] += d ;  nodelta += d*d          (nnls.py:162-170)
+// i.e. 6 vector instructions after the R/2 packed FMAs of the dot product.
 // A Gram row is split into X = columns [0, XW) and Y = columns [XW, XW+24).  Y is double-buffered and fetched a whole
 // row ahead; X is single-buffered and refilled for the next row as soon as its FMAs have issued, i.e. before the Y
 // part and the row bookkeeping -- so the single lgkmcnt(0) per row finds both in (or nearly in) the registers.
-// The row update is the reference's statement order (nnls.py:162-170): d = max(x, -v[k]); v[k] += d; nodelta += d*d;
-// rows with a zero Gram diagonal (and the padding rows) carry the pair (1/diag, nz) = (0, 0), which forces d = 0.
-template <int R>
-__device__ __forceinline__ float hals_sweep_column_xy(f32x2 (&v2)[R / 2], const float (&b)[R], const float* __restrict__ Gp) {
-    constexpr int RS = 64, P = R / 2, YW = 24, XW = (R - YW + 3) & ~3, XP = XW / 2, DOFF = R * RS;
+// GUARD: some Gram diagonal is zero (rare).  Such a row must be left alone whatever it holds (nnls.py:160): d is
+// multiplied by the row's nz flag (0/1) fetched with the Y part.  Without GUARD there is no per-row flag at all.
+template <int R, bool GUARD>
+__device__ __forceinline__ float hals_sweep_column_xy(f32x2 (&v2)[R / 2], const float (&b)[R], const float* __restrict__ Gs,
+                                                      const float* __restrict__ nzp) {
+    constexpr int RS = 64, P = R / 2, YW = 24, XW = (R - YW + 3) & ~3, XP = XW / 2;
     static_assert(YW == 24, "the Y issue statement below is written for x16 + x8");
-    static_assert(R > 32 && R <= 64 && XW + YW <= RS && XW >= 8, "row split");
-    const uint64_t base = (uint64_t)Gp;
+    static_assert(R > 32 && R <= 64 && R % 2 == 0 && XW + YW <= RS && XW >= 8, "row split");
+    const uint64_t base = (uint64_t)Gs, nzb = (uint64_t)nzp;
     sgbuf<XW> X;
     sgbuf<YW> Y[2];
-    f32x2 dv[2];
+    f32x2 dv[2];   // (1/diag, nz) pair of the row (GUARD only)
     float nd = 0.f;
     sg_issue<XW, false>(X, base, 0);
     sg_issue<YW, false>(Y[0], base, XW);
-    asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(dv[0]) : "s"(base), "i"(DOFF * 4));
+    if constexpr (GUARD) asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(dv[0]) : "s"(nzb), "i"(0));
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int cur = k & 1, nxt = cur ^ 1;
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dv[cur]));
+        if constexpr (GUARD) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dv[cur]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         sg_arrived<XW>(X);
         sg_arrived<YW>(Y[cur]);
-        if (k + 1 < R)   // one statement, so that all three are issued here and not wherever the scheduler sinks them
-            asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx8 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6"
-                         : "=s"(Y[nxt].a), "=s"(Y[nxt].q), "=s"(dv[nxt])
-                         : "s"(base), "i"(((k + 1) * RS + XW) * 4), "i"(((k + 1) * RS + XW + 16) * 4), "i"((DOFF + 2 * (k + 1)) * 4));
-        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+        if (k + 1 < R) {   // one statement, so that all of it is issued here and not wherever the scheduler sinks it
+            if constexpr (GUARD)
+                asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx8 %1, %3, %5\n\ts_load_dwordx2 %2, %6, %7"
+                             : "=s"(Y[nxt].a), "=s"(Y[nxt].q), "=s"(dv[nxt])
+                             : "s"(base), "i"(((k + 1) * RS + XW) * 4), "i"(((k + 1) * RS + XW + 16) * 4), "s"(nzb),
+                               "i"(8 * (k + 1)));
+            else
+                asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx8 %1, %2, %4"
+                             : "=s"(Y[nxt].a), "=s"(Y[nxt].q)
+                             : "s"(base), "i"(((k + 1) * RS + XW) * 4), "i"(((k + 1) * RS + XW + 16) * 4));
+        }
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};   // two chains are enough: the other wave of the SIMD fills the FMA latency
 #pragma unroll
         for (int p = 0; p < XP; ++p) {
             const f32x2 g = sg_pair<XW>(X, p);
-            if ((p & 3) == 0) a0 = __builtin_elementwise_fma(g, v2[p], a0);
-            if ((p & 3) == 1) a1 = __builtin_elementwise_fma(g, v2[p], a1);
-            if ((p & 3) == 2) a2 = __builtin_elementwise_fma(g, v2[p], a2);
-            if ((p & 3) == 3) a3 = __builtin_elementwise_fma(g, v2[p], a3);
+            if (p & 1) a1 = __builtin_elementwise_fma(g, v2[p], a1);
+            else a0 = __builtin_elementwise_fma(g, v2[p], a0);
         }
-        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));   // X is consumed: its registers may be refilled
+        asm volatile("" : "+v"(a0), "+v"(a1));   // X is consumed: its registers may be refilled
         if (k + 1 < R) sg_issue<XW, true>(X, base, (k + 1) * RS);
 #pragma unroll
         for (int p = XP; p < P; ++p) {
             const f32x2 g = sg_pair<YW>(Y[cur], p - XP);
-            if ((p & 3) == 0) a0 = __builtin_elementwise_fma(g, v2[p], a0);
-            if ((p & 3) == 1) a1 = __builtin_elementwise_fma(g, v2[p], a1);
-            if ((p & 3) == 2) a2 = __builtin_elementwise_fma(g, v2[p], a2);
-            if ((p & 3) == 3) a3 = __builtin_elementwise_fma(g, v2[p], a3);
+            if (p & 1) a1 = __builtin_elementwise_fma(g, v2[p], a1);
+            else a0 = __builtin_elementwise_fma(g, v2[p], a0);
         }
-        const f32x2 a = (a0 + a1) + (a2 + a3);
-        const float dot = a[0] + a[1];
-        const float di = dv[cur][0], nz = dv[cur][1];
+        const f32x2 a = a0 + a1;
         const float vk = v2[k / 2][k & 1];
-        const float x = (b[k] - dot) * di;
+        const float x = b[k] - (a[0] + a[1]);
         float dl;   // max(x, -v[k]) in one instruction (fmaxf adds a canonicalising max for the negated operand)
         asm("v_max_f32 %0, %1, -%2" : "=v"(dl) : "v"(x), "v"(vk));
-        dl *= nz;
+        if constexpr (GUARD) dl *= dv[cur][1];
         v2[k / 2][k & 1] = vk + dl;
         nd = fmaf(dl, dl, nd);
         asm volatile("" : "+v"(nd));  // finish this row's bookkeeping here (otherwise it is sunk to the end of the sweep)
@@ -142,7 +148,6 @@ __device__ __forceinline__ float hals_sweep_column_xy(f32x2 (&v2)[R / 2], const 
 template <int R, bool KEEPB>
 __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const float (&b)[KEEPB ? R : 1], rsrc_t rb, int voff,
                                                    int ldm4, const float* __restrict__ Gp, float sp) {
-    if constexpr (KEEPB && R > 32 && R <= 64) return hals_sweep_column_xy<R>(v2, b, Gp);
     constexpr int NBLK = (R + 31) / 32, RS = 32 * NBLK, P = R / 2, DOFF = R * RS;
     const uint64_t base = (uint64_t)Gp;
     f32x16 buf[2][2];
@@ -216,6 +221,8 @@ __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const flo
 template <int RP, bool RES>
 __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_args a) {
     constexpr bool KEEPB = (RP <= 104);   // UtM column resident in VGPRs next to the V column (fits 256 registers)
+    constexpr bool XY = (RP > 32 && RP <= 64);   // row-split sweep on operands pre-scaled by 1/diag
+    const bool all_live = XY && (a.dinv[2 * RP] != 0.f);   // wave-uniform: no zero on the Gram diagonal (prep kernel)
     __shared__ double red[4 * 3];
     __shared__ unsigned lds_flag;
     const int nblocks = gridDim.x;
@@ -229,12 +236,21 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
     const int ldv4 = (int)(a.ldv * 4), ldm4 = (int)(a.ldm * 4);
     f32x2 v2[RP / 2];
     float b[KEEPB ? RP : 1];
+    auto sweep = [&](int voff) -> float {
+        if constexpr (XY) {
+            return all_live ? hals_sweep_column_xy<RP, false>(v2, b, a.Gs, a.dinv) : hals_sweep_column_xy<RP, true>(v2, b, a.Gs, a.dinv);
+        } else {
+            return hals_sweep_column<RP, KEEPB>(v2, b, rb, voff, ldm4, a.Gp, a.sp);
+        }
+    };
     auto load_col = [&](int voff) {
 #pragma unroll
         for (int k = 0; k < RP; ++k) {
             v2[k / 2][k & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, k * ldv4, 0));
-            if constexpr (KEEPB)   // the sparsity constant is folded in once (rows >= r: di = 0, value irrelevant)
+            if constexpr (KEEPB) {   // the sparsity constant is folded in once (rows >= r: di = 0, value irrelevant)
                 b[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, voff, k * ldm4, 0)) - a.sp;
+                if constexpr (XY) b[k] *= a.dinv[2 * k];   // scaled operands (hals_sweep_column_xy)
+            }
         }
     };
     auto store_col = [&](int voff) {
@@ -250,7 +266,7 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
     // Speculation needs "V after the last confirmed sweep" when a stop arrives one sweep late.  Small ranks keep it in
     // a second set of registers (one copy per sweep, V is written to memory once, at the end); larger ranks have no room
     // and store V after every confirmed sweep instead (20 MB of stores per sweep at B's U side).
-    constexpr bool BACKUP = RES && RP <= 64;
+    constexpr bool BACKUP = RES && RP <= 56;
     f32x2 vb[BACKUP ? RP / 2 : 1];
 
     // Sweep loop.  mode 1: fixed count, per-sweep local partials, nothing to decide.
@@ -275,13 +291,13 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
         if constexpr (RES) {
             if constexpr (RP <= 96)   // (the resident pair of columns leaves no registers for it beyond that)
                 if (a.mode == 0 && s >= 2) hals_collect_issue(a.sy, s - 1, nblocks, pf);   // consumed after this sweep
-            const float f = hals_sweep_column<RP, KEEPB>(v2, b, rb, voff0, ldm4, a.Gp, a.sp);
+            const float f = sweep(voff0);
             nd = gtid < a.ncols ? (double)f : 0.0;
         } else {
             for (int64_t col = gtid; col < a.ncols; col += gthreads) {
                 const int voff = (int)(col * 4);
                 load_col(voff);
-                nd += (double)hals_sweep_column<RP, KEEPB>(v2, b, rb, voff, ldm4, a.Gp, a.sp);
+                nd += (double)sweep(voff);
                 store_col(voff);
             }
         }
@@ -388,7 +404,7 @@ int nnf_hals_fast_part0(nnf_ctx* ctx, int RP, const hals_args& a, int max_blocks
 }
 #elif HALS_PART == 1
 int nnf_hals_fast_part1(nnf_ctx* ctx, int RP, const hals_args& a, int max_blocks_cap, int* nblocks_out, hipStream_t st) {
-    switch (RP) { HALS_CASE(52) HALS_CASE(56) HALS_CASE(64) default: return NNF_ERR_UNSUPPORTED; }
+    switch (RP) { HALS_CASE(50) HALS_CASE(52) HALS_CASE(56) HALS_CASE(64) default: return NNF_ERR_UNSUPPORTED; }
 }
 #elif HALS_PART == 2
 int nnf_hals_fast_part2(nnf_ctx* ctx, int RP, const hals_args& a, int max_blocks_cap, int* nblocks_out, hipStream_t st) {

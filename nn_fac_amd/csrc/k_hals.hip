@@ -208,7 +208,7 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     const bool quad = !generic && !force_lane && (ncols <= 32768 || force_quad) && (int64_t)(r + 16) * (ldv > ldm ? ldv : ldm) * 4 < (int64_t)0x7fff0000 &&
                       nnf_hals_quad_fits(ctx, r, ncols, max_blocks);
     const size_t gs_off = (((size_t)RP * RS + 2 * RP + 1) + 15) & ~(size_t)15;   // scaled image, 64-byte aligned
-    const bool want_gs = !generic && RP > 32 && RP <= 64;
+    const bool want_gs = !generic && RP > 32 && RP <= 52;
     size_t gfloats = gs_off + (want_gs ? (size_t)RP * RS : 0);
     if (quad && nnf_hals_quad_gram_floats(r) > gfloats) gfloats = nnf_hals_quad_gram_floats(r);
     float* Gp = (float*)cur.take(gfloats * 4);   // padded Gram, then the (1/diag, nz) pairs (quad: scaled Gram, 1/diag)

@@ -151,6 +151,50 @@ __device__ __forceinline__ bool hals_collect(const hals_sync& sy, int s, int nbl
     return ok;
 }
 
+// Barrier-lean forms for the persistent sweep loop: `red` is a per-sweep-parity slot array ((blockDim/64) doubles each),
+// so a slot is rewritten only two sweeps later, with a barrier in between -- no trailing barrier is needed, and the
+// time-out flag is armed once before the loop instead of per call.  One __syncthreads each.
+__device__ __forceinline__ double hals_block_sum1(double v, double* red_p) {
+    v = nnf_wave_sum_f64(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red_p[w] = v;
+    __syncthreads();
+    double t = red_p[0];
+    for (int k = 1; k < nw; ++k) t += red_p[k];
+    return t;   // every thread
+}
+__device__ __forceinline__ bool hals_collect1(const hals_sync& sy, int s, int nblocks, double& total, double* red_p,
+                                              unsigned* lds_flag, const hals_prefetch& pf) {
+    const unsigned tag = sy.epoch * 1024u + (unsigned)s;
+    const unsigned long long* base = reinterpret_cast<const unsigned long long*>(sy.sslots) + (size_t)s * nblocks * 2;
+    double v = 0.0;
+    int i = 0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x, ++i) {
+        unsigned long long g0 = 0ull, g1 = 0ull;
+        if (pf.s == s) {
+#pragma unroll
+            for (int u = 0; u < HALS_PF; ++u)
+                if (u == i) { g0 = pf.g0[u]; g1 = pf.g1[u]; }
+        }
+        unsigned spins = 0;
+        while (!((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag)) {
+            if (spins > 0) __builtin_amdgcn_s_sleep(1);
+            if (++spins > HALS_SPIN_LIMIT) { *lds_flag = 0u; break; }
+            g0 = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g1 = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        v += __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xffffffffull));
+    }
+    v = nnf_wave_sum_f64(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red_p[w] = v;
+    __syncthreads();
+    double t = red_p[0];
+    for (int k = 1; k < nw; ++k) t += red_p[k];
+    total = t;
+    return *lds_flag != 0u;
+}
+
 struct hals_args {
     const float* UtM; int64_t ldm;
     const float* Gp;      // padded Gram  RP x RP (zeros outside r x r), workspace

@@ -221,10 +221,12 @@ __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const flo
 template <int RP, bool RES>
 __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_args a) {
     constexpr bool KEEPB = (RP <= 104);   // UtM column resident in VGPRs next to the V column (fits 256 registers)
-    constexpr bool XY = (RP > 32 && RP <= 64);   // row-split sweep on operands pre-scaled by 1/diag
+    constexpr bool XY = (RP > 32 && RP <= 52);   // row-split sweep on operands pre-scaled by 1/diag (its 3 buffers need RP+24 SGPRs: beyond 52 the allocator starts spilling in-flight buffers)
     const bool all_live = XY && (a.dinv[2 * RP] != 0.f);   // wave-uniform: no zero on the Gram diagonal (prep kernel)
     __shared__ double red[4 * 3];
+    __shared__ double red2[2][2][4];   // [sweep parity][block sum | collect][wave]: see hals_block_sum1
     __shared__ unsigned lds_flag;
+    if (threadIdx.x == 0) lds_flag = 1u;   // time-out flag of the collects, armed once (read after a barrier)
     const int nblocks = gridDim.x;
     const int64_t gthreads = (int64_t)nblocks * 256;
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -301,7 +303,9 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
                 store_col(voff);
             }
         }
-        const double bs = nnf_block_sum_f64(nd, red);
+        double bs;
+        if (RES && a.mode == 0) bs = hals_block_sum1(nd, red2[s & 1][0]);   // valid in every thread
+        else bs = nnf_block_sum_f64(nd, red);
         if (a.mode == 1) {
             if (threadIdx.x == 0) a.sweep_partials[(size_t)(s - 1) * nblocks + blockIdx.x] = bs;
             if constexpr (RES) {
@@ -319,7 +323,8 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
         const int c = RES ? s - 1 : s;          // sweep whose global sum is examined now
         if (c >= 1) {
             double tot;
-            ok = hals_collect(a.sy, c, nblocks, tot, red, &lds_flag, &pf);
+            if constexpr (RES) ok = hals_collect1(a.sy, c, nblocks, tot, red2[s & 1][1], &lds_flag, pf);
+            else ok = hals_collect(a.sy, c, nblocks, tot, red, &lds_flag, &pf);
             if (!ok) break;
             if (c == 1) eps0 = tot;
             eps = tot;

@@ -51,6 +51,12 @@ def main():
     F = Ut.clone()
     ms = timeit(lambda: eng.hals_solve(UtM, UtU, F, 10, delta=0.0), reps=10)
     print(f"hals_solve U-side 10 sweeps (grid barrier) {ms*1e3:9.1f} us ({ms*1e2:7.1f} us/sweep)")
+    F = Ut.clone()
+    ms = timeit(lambda: eng.hals_sweeps(UtM, UtU, F, 100), reps=5)
+    print(f"hals_sweeps U-side x100      {ms*1e3:9.1f} us  ({ms*10:7.1f} us/sweep)")
+    F = Ut.clone()
+    ms = timeit(lambda: eng.hals_solve(UtM, UtU, F, 100, delta=0.0), reps=5)
+    print(f"hals_solve U-side x100       {ms*1e3:9.1f} us  ({ms*10:7.1f} us/sweep)")
     VtM, VtV = eng.xty(X, Ut), eng.gram(Ut)
     for k in (10, 100):
         F = V.clone()

@@ -16,10 +16,10 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 // issue(next) -> 16 x v_pk_fma_f32 with SGPR-pair operands.  The loads are invisible to hipcc's counters (so it adds no
 // waits of its own); the "+s" wait statements carry the data dependence (cdna_hip_programming.md s.5.7 form (ii)).
 #define NNF_SLOAD2(d0, d1, base, off) \
-    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4" : "=s"(d0), "=s"(d1) : "s"(base), "i"((off) * 4), "i"((off) * 4 + 64))
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4" : "=&s"(d0), "=&s"(d1) : "s"(base), "i"((off) * 4), "i"((off) * 4 + 64))
 #define NNF_SLOAD2D(d0, d1, dd, base, off, doff) \
     asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dword %2, %3, %6" \
-                 : "=s"(d0), "=s"(d1), "=s"(dd) : "s"(base), "i"((off) * 4), "i"((off) * 4 + 64), "i"((doff) * 4))
+                 : "=&s"(d0), "=&s"(d1), "=&s"(dd) : "s"(base), "i"((off) * 4), "i"((off) * 4 + 64), "i"((doff) * 4))
 #define NNF_SWAIT2(d0, d1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1))
 #define NNF_SWAIT3(d0, d1, dd) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1), "+s"(dd))
 
@@ -104,12 +104,12 @@ __device__ __forceinline__ float hals_sweep_column_xy(f32x2 (&v2)[R / 2], const 
         if (k + 1 < R) {   // one statement, so that all of it is issued here and not wherever the scheduler sinks it
             if constexpr (GUARD)
                 asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx8 %1, %3, %5\n\ts_load_dwordx2 %2, %6, %7"
-                             : "=s"(Y[nxt].a), "=s"(Y[nxt].q), "=s"(dv[nxt])
+                             : "=&s"(Y[nxt].a), "=&s"(Y[nxt].q), "=&s"(dv[nxt])
                              : "s"(base), "i"(((k + 1) * RS + XW) * 4), "i"(((k + 1) * RS + XW + 16) * 4), "s"(nzb),
                                "i"(8 * (k + 1)));
             else
                 asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx8 %1, %2, %4"
-                             : "=s"(Y[nxt].a), "=s"(Y[nxt].q)
+                             : "=&s"(Y[nxt].a), "=&s"(Y[nxt].q)
                              : "s"(base), "i"(((k + 1) * RS + XW) * 4), "i"(((k + 1) * RS + XW + 16) * 4));
         }
         f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};   // two chains are enough: the other wave of the SIMD fills the FMA latency

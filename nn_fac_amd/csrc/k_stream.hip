@@ -410,12 +410,49 @@ static int launch_gram(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, 
 //   which is exactly what a lane's float4 load of X[row][j0+4jj..+3] holds.
 //   The rank loop is a run-time loop (both operands come from LDS), so one kernel serves every r <= 128.
 // =========================================================================================================
+// Right-operand fragments of ALL column blocks, laid out exactly as the cost kernel stages them:
+//   Vf[(blk*KS + s)*64 + L] = float4 V[4s + (L>>4)][64 blk + 4(L&15) .. +3]   (zero outside r x n)
+// V is tiny (r x n) and identical for every workgroup, so the index arithmetic, the ragged-edge masks and (CP cost) the
+// Khatri-Rao products V[k][ja]*Vb[k][jb] are done once here instead of once per workgroup and column block.
+__global__ __launch_bounds__(256) void nnf_cost_prepv_kernel(const float* __restrict__ V, int64_t ldv, int r, int64_t n, int KS,
+                                                             const float* __restrict__ Vb, int64_t ldvb, int64_t nb,
+                                                             f32x4* __restrict__ Vf, int64_t total) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int L = (int)(e & 63);
+        const int64_t q = e >> 6;
+        const int s_ = (int)(q % KS);
+        const int64_t blk = q / KS;
+        const int k = 4 * s_ + (L >> 4);
+        const int64_t j = 64 * blk + 4 * (L & 15);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < r && j < n) {
+            if (Vb == nullptr) {
+                const float* p = V + (int64_t)k * ldv + j;
+                v[0] = p[0];
+                if (j + 1 < n) v[1] = p[1];
+                if (j + 2 < n) v[2] = p[2];
+                if (j + 3 < n) v[3] = p[3];
+            } else {  // Khatri-Rao column j = (ja, jb), jb fastest: V[k][ja] * Vb[k][jb]
+                const int64_t ja0 = j / nb, jb0 = j - ja0 * nb;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (j + c < n) {
+                        int64_t ja = ja0, jb = jb0 + c;
+                        while (jb >= nb) { jb -= nb; ++ja; }
+                        v[c] = V[(int64_t)k * ldv + ja] * Vb[(int64_t)k * ldvb + jb];
+                    }
+                }
+            }
+        }
+        Vf[e] = v;
+    }
+}
+
 template <int OP, bool VEC>
-__global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+__global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                           const float* __restrict__ Ut, int64_t ldu,
-                                                          const float* __restrict__ V, int64_t ldv, int r,
+                                                          const f32x4* __restrict__ Vf, int r,
                                                           float beta, double* __restrict__ partial,
-                                                          const float* __restrict__ Vb, int64_t ldvb, int64_t nb,
                                                           const float* __restrict__ Ub, int64_t ldub, int64_t nbu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KS = (r + 3) >> 2;                               // k-steps of 4
@@ -431,7 +468,12 @@ __global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restric
     const rsrc_t rs = nnf_make_rsrc(X + (rows > 0 ? i0w : 0) * ldx, bytes);
     const int ldx4 = (int)(ldx * 4);
     const int voff = (int)(((int64_t)4 * g * ldx + 4 * jj) * 4);
-    const int nblk = (int)((n + 63) >> 6);
+    // column blocks [blk0, blk1) of this workgroup: blockIdx.y splits the column range so that the grid has several times
+    // more workgroups than resident slots (128-row workgroups alone give 782 for 512 slots at B: a 1.5-round tail)
+    const int nblk_all = (int)((n + 63) >> 6);
+    const int per = (nblk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int blk0 = (int)blockIdx.y * per;
+    const int nblk = (blk0 + per < nblk_all) ? (blk0 + per) : nblk_all;
 
     // U fragments of this wave's 32 rows: ldsU[w][rt][s][lane] = Ut[4s + (lane>>4)][i0w + 16rt + (lane&15)]
     for (int e = lane; e < 2 * KS * 64; e += 64) {
@@ -452,37 +494,12 @@ __global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restric
     // Staged in two halves: global loads into registers before the MFMAs of the current block, LDS writes after them.
     constexpr int NV = 8;                       // KS*64/256 <= 8 float4 per thread (r <= 128)
     f32x4 vreg[NV];
-    auto stageV_load = [&](int blk) {
-        const int64_t j0 = 64 * (int64_t)blk;
+    auto stageV_load = [&](int blk) {   // straight copies of the pre-arranged fragments (nnf_cost_prepv_kernel)
+        const f32x4* src = Vf + (size_t)blk * KS * 64;
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int e = threadIdx.x + 256 * u;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < KS * 64) {
-                const int s = e >> 6, L = e & 63;
-                const int k = 4 * s + (L >> 4);
-                const int64_t j = j0 + 4 * (L & 15);
-                if (k < r && j < n) {
-                    if (Vb == nullptr) {
-                        const float* p = V + (int64_t)k * ldv + j;
-                        v[0] = p[0];
-                        if (j + 1 < n) v[1] = p[1];
-                        if (j + 2 < n) v[2] = p[2];
-                        if (j + 3 < n) v[3] = p[3];
-                    } else {  // Khatri-Rao column j = (ja, jb), jb fastest: V[k][ja] * Vb[k][jb]
-                        const int64_t ja0 = j / nb, jb0 = j - ja0 * nb;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            if (j + c < n) {
-                                int64_t ja = ja0, jb = jb0 + c;
-                                while (jb >= nb) { jb -= nb; ++ja; }
-                                v[c] = V[(int64_t)k * ldv + ja] * Vb[(int64_t)k * ldvb + jb];
-                            }
-                        }
-                    }
-                }
-            }
-            vreg[u] = v;
+            vreg[u] = (e < KS * 64 && blk < nblk_all) ? src[e] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto stageV_store = [&](f32x4* img) {
@@ -492,18 +509,18 @@ __global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restric
             if (e < KS * 64) img[e] = vreg[u];
         }
     };
-    stageV_load(0);
-    stageV_store(ldsV);
+    stageV_load(blk0);
+    stageV_store(ldsV + (size_t)(blk0 & 1) * KS * 64);
     f32x4 xb[2][4];  // [rt][reg]: row i0w + 16rt + 4g + reg, columns j0+4jj..+3
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) xb[rt][reg] = nnf_bload4<VEC>(rs, voff, (16 * rt + reg) * ldx4);
+        for (int reg = 0; reg < 4; ++reg) xb[rt][reg] = nnf_bload4<VEC>(rs, voff, (16 * rt + reg) * ldx4 + 256 * blk0);
     __syncthreads();
 
     double dsum = 0.0;
     const float* uf = ldsU + (size_t)(w * 2) * KS * 64 + lane;
-    for (int blk = 0; blk < nblk; ++blk) {
+    for (int blk = blk0; blk < nblk; ++blk) {
         const f32x4* img = ldsV + (size_t)(blk & 1) * KS * 64;
         stageV_load(blk + 1);   // past the last block every entry is masked to zero (j >= n)
         f32x4 acc[2][4];
@@ -511,29 +528,76 @@ __global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restric
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) acc[rt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int s = 0; s < KS; ++s) {
-            const f32x4 bv = img[s * 64 + lane];
-            const float a0 = uf[s * 64], a1 = uf[KS * 64 + s * 64];
+        // k loop, two steps per trip, software-pipelined by hand: the fragments of the next step are read from LDS (three
+        // hand-issued ds_reads) while the MFMAs of the current one run.  The compiler rotates a C++ version of this back
+        // into "read, wait, multiply" (tools/ notes: ~30 % of the MFMA time exposed).  Nothing is in flight at the loop
+        // back-edge or at any other control-flow merge, which is what makes hand-issued loads safe (k_hals_quad.hip).
+        {
+            const unsigned bvb = (unsigned)(uintptr_t)img + (unsigned)lane * 16u;        // + 1024 per k-step
+            const unsigned a0b = (unsigned)(uintptr_t)uf;                                 // + 256 per k-step
+            const unsigned a1b = a0b + (unsigned)KS * 256u;
+            f32x4 bvA, bvB;
+            float a0A, a1A, a0B, a1B;
+            asm volatile("ds_read_b128 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(bvA), "=&v"(a0A), "=&v"(a1A) : "v"(bvb), "v"(a0b), "v"(a1b));
+            int s = 0;
+            for (; s + 1 < KS; s += 2) {
+                const int sb = s + 1, sa = (s + 2 < KS) ? s + 2 : KS - 1;   // the clamped extra read is never used
+                // (the A set rides through the statement as in/out operands so that its MFMAs cannot be scheduled above it,
+                //  and the accumulators ride through the wait so that they cannot sink below it)
+                asm volatile("ds_read_b128 %0, %6\n\tds_read_b32 %1, %7\n\tds_read_b32 %2, %8"
+                             : "=&v"(bvB), "=&v"(a0B), "=&v"(a1B), "+v"(bvA), "+v"(a0A), "+v"(a1A)
+                             : "v"(bvb + (unsigned)sb * 1024u), "v"(a0b + (unsigned)sb * 256u), "v"(a1b + (unsigned)sb * 256u));
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                acc[0][cc] = MFMA16(a0, bv[cc], acc[0][cc]);
-                acc[1][cc] = MFMA16(a1, bv[cc], acc[1][cc]);
+                for (int cc = 0; cc < 4; ++cc) {
+                    acc[0][cc] = MFMA16(a0A, bvA[cc], acc[0][cc]);
+                    acc[1][cc] = MFMA16(a1A, bvA[cc], acc[1][cc]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(bvB), "+v"(a0B), "+v"(a1B), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                               "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+                asm volatile("ds_read_b128 %0, %6\n\tds_read_b32 %1, %7\n\tds_read_b32 %2, %8"
+                             : "=&v"(bvA), "=&v"(a0A), "=&v"(a1A), "+v"(bvB), "+v"(a0B), "+v"(a1B)
+                             : "v"(bvb + (unsigned)sa * 1024u), "v"(a0b + (unsigned)sa * 256u), "v"(a1b + (unsigned)sa * 256u));
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    acc[0][cc] = MFMA16(a0B, bvB[cc], acc[0][cc]);
+                    acc[1][cc] = MFMA16(a1B, bvB[cc], acc[1][cc]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(bvA), "+v"(a0A), "+v"(a1A), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                               "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+            }
+            if (s < KS) {   // odd number of k-steps: the A set holds step KS-1
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    acc[0][cc] = MFMA16(a0A, bvA[cc], acc[0][cc]);
+                    acc[1][cc] = MFMA16(a1A, bvA[cc], acc[1][cc]);
+                }
             }
         }
         // residual of this 32 x 64 block; columns past n hold the next row's data -> masked out
         const int64_t jrem = n - (64 * (int64_t)blk + 4 * jj);
         float loc = 0.f;
+        if (rows == 32 && 64 * (int64_t)(blk + 1) <= n) {   // interior block (wave-uniform): no edge masks
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                if (16 * rt + 4 * g + reg >= rows) continue;   // rows past the end of the matrix
+                for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    if (cc < jrem) loc += nnf_cost_term<OP>(xb[rt][reg][cc], acc[rt][cc][reg], beta);
+                    for (int cc = 0; cc < 4; ++cc) loc += nnf_cost_term<OP>(xb[rt][reg][cc], acc[rt][cc][reg], beta);
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    if (16 * rt + 4 * g + reg >= rows) continue;   // rows past the end of the matrix
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        if (cc < jrem) loc += nnf_cost_term<OP>(xb[rt][reg][cc], acc[rt][cc][reg], beta);
+                    }
                 }
-            }
+        }
         dsum += (double)loc;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -544,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void nnf_cost_kernel(const float* __restric
         __syncthreads();
     }
     const double bs = nnf_block_sum_f64(dsum, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = bs;
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = bs;
 }
 
 // sum of `count` doubles in index order by one workgroup -> out[0]
@@ -652,10 +716,24 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
                        const float* Vb = nullptr, int64_t ldvb = 0, int64_t nb = 1, const float* Ub = nullptr,
                        int64_t ldub = 0, int64_t nbu = 1) {
     const int grid = (int)nnf_cdiv(m, 128);
+    // column splits: aim at ~8 workgroups per resident slot, keep at least 4 column blocks per workgroup
+    const int nblk_all = (int)nnf_cdiv(n, 64);
+    int csplit = (int)nnf_cdiv((int64_t)8 * 2 * ctx->num_cus, grid);
+    if (csplit > nblk_all / 4) csplit = nblk_all / 4;
+    if (csplit < 1) csplit = 1;
     nnf_ws_cursor cur(ctx);
-    double* partial = (double*)cur.take((size_t)grid * 8);
+    double* partial = (double*)cur.take((size_t)grid * csplit * 8);
     if (!partial) return NNF_ERR_WORKSPACE;
     const int KS = (r + 3) / 4;
+    const int64_t vf_total = (int64_t)nblk_all * KS * 64;
+    f32x4* Vf = (f32x4*)cur.take((size_t)vf_total * 16);
+    if (!Vf) return NNF_ERR_WORKSPACE;
+    {
+        int64_t pg = nnf_cdiv(vf_total, 256);
+        if (pg > 1024) pg = 1024;
+        hipLaunchKernelGGL(nnf_cost_prepv_kernel, dim3((int)pg), dim3(256), 0, st, V, ldv, r, n, KS, Vb, ldvb, nb, Vf, vf_total);
+        NNF_CHECK_LAUNCH();
+    }
     const size_t shm = (size_t)4 * 2 * KS * 64 * 4 + (size_t)2 * KS * 64 * 16 + 64;
     if (shm > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_cost_kernel<OP, true>),
@@ -664,13 +742,13 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     }
     if (x_vec_ok(X, ldx))
-        hipLaunchKernelGGL((nnf_cost_kernel<OP, true>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
-                           beta, partial, Vb, ldvb, nb, Ub, ldub, nbu);
+        hipLaunchKernelGGL((nnf_cost_kernel<OP, true>), dim3(grid, csplit), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, Vf, r, beta,
+                           partial, Ub, ldub, nbu);
     else
-        hipLaunchKernelGGL((nnf_cost_kernel<OP, false>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
-                           beta, partial, Vb, ldvb, nb, Ub, ldub, nbu);
+        hipLaunchKernelGGL((nnf_cost_kernel<OP, false>), dim3(grid, csplit), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, Vf, r, beta,
+                           partial, Ub, ldub, nbu);
     NNF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nnf_sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)grid, scale, out_f64);
+    hipLaunchKernelGGL(nnf_sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)grid * csplit, scale, out_f64);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
 }

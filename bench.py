@@ -182,7 +182,8 @@ def main():
                        "inner_sweeps_mean": float(np.mean([sum(s) for s in sweeps])) if sweeps else None,
                        "final_cost": cost},
             "roofline": {"kernel": "nnf_xty_f32 = nnf_xty_kernel + nnf_reduce_slabs_kernel (W^T X incl. its fixed-order "
-                                   "slab reduction; rocprof: ~204 us + ~16 us)", "bound": "mfma", "achieved": achieved,
+                                   "slab reduction, timed together; per-kernel split in profiles/)", "bound": "mfma",
+                         "achieved": achieved,
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                          "traffic": traffic, "launch_ms": xty_ms,
                          "algorithmic_bytes": xty_bytes, "hbm_gbs": xty_bytes / (xty_ms * 1e-3) / 1e9,

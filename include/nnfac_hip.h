@@ -156,7 +156,7 @@ int nnf_ttm3_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t K, 
  *       grad = core x_0 M0 x_1 M1 x_2 M2 - MtX + sparse;  core -= min(step*grad, core)
  * core (d0 x d1 x d2, updated in place), MtX same shape, M_i = F_i^T F_i (d_i x d_i, dense).
  * status_f64[6] = {iterations, last update norm, first update norm, step, norm_sq - 2<MtX,core> + <core x M, core>, 0}.
- * NNF_ERR_UNSUPPORTED if the core (4 fp64 copies) does not fit in one workgroup's LDS. */
+ * Cores whose four fp64 copies exceed one workgroup's LDS (~4500 entries) work out of the context workspace instead. */
 int nnf_ntd_core_pg_f32(nnf_ctx* ctx, float* core, const float* MtX, const float* M0, const float* M1, const float* M2, int d0,
                         int d1, int d2, double sparse, double delta, int max_iter, double norm_sq, double* status_f64,
                         void* stream);

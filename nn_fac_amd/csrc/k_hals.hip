@@ -30,21 +30,21 @@ __global__ void nnf_hals_prep_kernel(const float* __restrict__ UtU, int64_t ldg,
         dinv[2 * k] = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;   // pair (1/diag, nz): nz = 0 = leave the row alone
         dinv[2 * k + 1] = (d != 0.f) ? 1.f : 0.f;
     }
-    if (threadIdx.x == 0) {   // all-live flag: no zero on the diagonal of the r x r Gram
-        float live = 1.f;
-        for (int k = 0; k < r; ++k)
-            if (UtU[(int64_t)k * ldg + k] == 0.f) live = 0.f;
-        dinv[2 * RP] = live;
+    {   // all-live flag: no zero on the diagonal of the r x r Gram (r <= 128 < blockDim)
+        const int dead = (threadIdx.x < r) && (UtU[(int64_t)threadIdx.x * ldg + threadIdx.x] == 0.f);
+        const int any_dead = __syncthreads_or(dead);
+        if (threadIdx.x == 0) dinv[2 * RP] = any_dead ? 0.f : 1.f;
     }
     if (Gs) {   // rows scaled by 1/diag (rows with a zero diagonal: all zero), same padding
+        __shared__ float di_s[NNF_MAX_RANK];
+        for (int k = threadIdx.x; k < RP; k += blockDim.x) {
+            const float d = (k < r) ? UtU[(int64_t)k * ldg + k] : 0.f;
+            di_s[k] = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;
+        }
+        __syncthreads();
         for (int e = threadIdx.x; e < RP * RS; e += blockDim.x) {
             const int a = e / RS, b = e - a * RS;
-            float g = 0.f;
-            if (a < r && b < r) {
-                const float d = UtU[(int64_t)a * ldg + a];
-                if (d != 0.f) g = UtU[(int64_t)a * ldg + b] * (float)(1.0 / (double)d);
-            }
-            Gs[e] = g;
+            Gs[e] = (a < r && b < r) ? UtU[(int64_t)a * ldg + b] * di_s[a] : 0.f;
         }
     }
     if (threadIdx.x == 0) {

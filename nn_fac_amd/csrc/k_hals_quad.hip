@@ -32,18 +32,17 @@ __device__ __forceinline__ float dpp_quad(float x) {
 __global__ void nnf_hals_prep_quad_kernel(const float* __restrict__ UtU, int64_t ldg, int r, int CH, float* __restrict__ Gq,
                                           float* __restrict__ dinvq, unsigned* counter, double* status) {
     const int RQ = 4 * CH, CHP = (CH + 3) & ~3, RS = 4 * CHP;
-    for (int e = threadIdx.x; e < RQ * RS; e += blockDim.x) {
-        const int k = e / RS, c = e - k * RS, q = c / CHP, jj = c - q * CHP, j = q * CH + jj;
-        float g = 0.f;
-        if (k < r && jj < CH && j < r) {
-            const float d = UtU[(int64_t)k * ldg + k];
-            if (d != 0.f) g = UtU[(int64_t)k * ldg + j] * (float)(1.0 / (double)d);
-        }
-        Gq[e] = g;
-    }
+    __shared__ float di_s[NNF_MAX_RANK];
     for (int k = threadIdx.x; k < RQ; k += blockDim.x) {
         const float d = (k < r) ? UtU[(int64_t)k * ldg + k] : 0.f;
-        dinvq[k] = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;
+        const float di = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;
+        di_s[k] = di;
+        dinvq[k] = di;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < RQ * RS; e += blockDim.x) {
+        const int k = e / RS, c = e - k * RS, q = c / CHP, jj = c - q * CHP, j = q * CH + jj;
+        Gq[e] = (k < r && jj < CH && j < r) ? UtU[(int64_t)k * ldg + j] * di_s[k] : 0.f;
     }
     if (threadIdx.x == 0) {
         *counter = 0u;

@@ -78,14 +78,14 @@ __device__ __forceinline__ double pg_block_sum(double v, double* red) {
 
 // largest eigenvalue of the symmetric PSD r x r matrix M (LDS, fp64) by power iteration from the ones vector (the Gram of
 // a non-negative factor has a positive Perron vector, so the start is never orthogonal to it); x, y: r doubles in LDS.
-__device__ double pg_sigma_max(const double* M, int r, double* x, double* y, double* red) {
+__device__ double pg_sigma_max(const float* M, int r, double* x, double* y, double* red) {
     for (int a = threadIdx.x; a < r; a += blockDim.x) x[a] = 1.0;
     __syncthreads();
     double lam = 0.0;
     for (int it = 0; it < 3000; ++it) {
         for (int a = threadIdx.x; a < r; a += blockDim.x) {
             double s = 0.0;
-            for (int b = 0; b < r; ++b) s += M[a * r + b] * x[b];
+            for (int b = 0; b < r; ++b) s += (double)M[a * r + b] * x[b];
             y[a] = s;
         }
         __syncthreads();
@@ -106,41 +106,57 @@ __device__ double pg_sigma_max(const double* M, int r, double* x, double* y, dou
 }
 
 // dst = src x_mode M  (dst[.., a', ..] = sum_a M[a'][a] src[.., a, ..]),  dims d0 x d1 x d2, M is d_mode x d_mode
-__device__ void pg_mode_dot(const double* src, double* dst, const double* M, int d0, int d1, int d2, int mode) {
+template <typename ST>
+__device__ void pg_mode_dot(const ST* src, ST* dst, const float* M, int d0, int d1, int d2, int mode) {
     const int S = d0 * d1 * d2;
     const int dm = mode == 0 ? d0 : (mode == 1 ? d1 : d2);
     const int stride = mode == 0 ? d1 * d2 : (mode == 1 ? d2 : 1);
     for (int e = threadIdx.x; e < S; e += blockDim.x) {
         const int a = (e / stride) % dm;           // index along the contracted mode
         const int base = e - a * stride;
-        double s = 0.0;
-        for (int t = 0; t < dm; ++t) s += M[a * dm + t] * src[base + t * stride];
-        dst[e] = s;
+        const float* mr = M + a * dm;
+        double s0 = 0.0, s1 = 0.0;   // two chains; the Gram entries are fp32 values (exact in fp32 storage)
+        int t = 0;
+        for (; t + 1 < dm; t += 2) {
+            s0 += (double)mr[t] * (double)src[base + t * stride];
+            s1 += (double)mr[t + 1] * (double)src[base + (t + 1) * stride];
+        }
+        if (t < dm) s0 += (double)mr[t] * (double)src[base + t * stride];
+        dst[e] = (ST)(s0 + s1);
     }
     __syncthreads();
 }
 
+// ST: storage type of the four core-sized arrays.  double (the reference's arithmetic) while they fit in LDS; float -- with
+// every dot product and the update still accumulated in fp64 -- for cores up to ~9000 entries; beyond that (gbuf != 0)
+// double again, in the context workspace.
+template <typename ST>
 __global__ __launch_bounds__(1024) void nnf_ntd_core_pg_kernel(float* __restrict__ core_g, const float* __restrict__ mtx_g,
                                                                const float* __restrict__ M0g, const float* __restrict__ M1g,
                                                                const float* __restrict__ M2g, int d0, int d1, int d2,
                                                                double sparse, double delta, int max_iter, double norm_sq,
-                                                               double* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+                                                               double* __restrict__ status, double* gbuf) {
+    // working set: LDS when it fits (the usual few-hundred-entry core), else a slice of the context workspace -- still
+    // one workgroup (its waves share the CU's L1, and every phase ends in a barrier), just with L2 latency per access
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
     const int S = d0 * d1 * d2;
-    double* core = sm;
-    double* mtx = core + S;
-    double* ta = mtx + S;
-    double* tb = ta + S;
-    double* M0 = tb + S;
-    double* M1 = M0 + d0 * d0;
-    double* M2 = M1 + d1 * d1;
-    double* vx = M2 + d2 * d2;
+    // LDS: [vx 128][vy 128][red 16] doubles, [M0][M1][M2] floats (the Grams ARE fp32 values), then (unless gbuf) the four
+    // core-sized arrays of ST, 8-byte aligned
+    double* vx = lds_all;
+    float* M0 = reinterpret_cast<float*>(lds_all + 272);
+    float* M1 = M0 + d0 * d0;
+    float* M2 = M1 + d1 * d1;
+    const int mfl = (d0 * d0 + d1 * d1 + d2 * d2 + 1) & ~1;
+    ST* core = gbuf ? reinterpret_cast<ST*>(gbuf) : reinterpret_cast<ST*>(M0 + mfl);
+    ST* mtx = core + S;
+    ST* ta = mtx + S;
+    ST* tb = ta + S;
     double* vy = vx + 128;
     double* red = vy + 128;   // 16 doubles
-    for (int e = threadIdx.x; e < S; e += blockDim.x) { core[e] = (double)core_g[e]; mtx[e] = (double)mtx_g[e]; }
-    for (int e = threadIdx.x; e < d0 * d0; e += blockDim.x) M0[e] = (double)M0g[e];
-    for (int e = threadIdx.x; e < d1 * d1; e += blockDim.x) M1[e] = (double)M1g[e];
-    for (int e = threadIdx.x; e < d2 * d2; e += blockDim.x) M2[e] = (double)M2g[e];
+    for (int e = threadIdx.x; e < S; e += blockDim.x) { core[e] = (ST)core_g[e]; mtx[e] = (ST)mtx_g[e]; }
+    for (int e = threadIdx.x; e < d0 * d0; e += blockDim.x) M0[e] = M0g[e];
+    for (int e = threadIdx.x; e < d1 * d1; e += blockDim.x) M1[e] = M1g[e];
+    for (int e = threadIdx.x; e < d2 * d2; e += blockDim.x) M2[e] = M2g[e];
     __syncthreads();
     // ntd.py:592-596
     double step = 1.0;
@@ -157,9 +173,10 @@ __global__ __launch_bounds__(1024) void nnf_ntd_core_pg_kernel(float* __restrict
         pg_mode_dot(tb, ta, M2, d0, d1, d2, 2);
         double s2 = 0.0;
         for (int e = threadIdx.x; e < S; e += blockDim.x) {
-            const double grad = -mtx[e] + ta[e] + sparse;
-            const double dc = fmin(step * grad, core[e]);
-            core[e] -= dc;
+            const double c = (double)core[e];
+            const double grad = -(double)mtx[e] + (double)ta[e] + sparse;
+            const double dc = fmin(step * grad, c);
+            core[e] = (ST)(c - dc);
             s2 += dc * dc;
         }
         upd = sqrt(pg_block_sum(s2, red));
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(1024) void nnf_ntd_core_pg_kernel(float* __restrict
     pg_mode_dot(ta, tb, M1, d0, d1, d2, 1);
     pg_mode_dot(tb, ta, M2, d0, d1, d2, 2);
     double ip = 0.0, qf = 0.0;
-    for (int e = threadIdx.x; e < S; e += blockDim.x) { ip += mtx[e] * core[e]; qf += ta[e] * core[e]; }
+    for (int e = threadIdx.x; e < S; e += blockDim.x) { ip += (double)mtx[e] * (double)core[e]; qf += (double)ta[e] * (double)core[e]; }
     ip = pg_block_sum(ip, red);
     qf = pg_block_sum(qf, red);
     for (int e = threadIdx.x; e < S; e += blockDim.x) core_g[e] = (float)core[e];
@@ -192,14 +209,35 @@ extern "C" int nnf_ntd_core_pg_f32(nnf_ctx* ctx, float* core, const float* MtX, 
     if (!ctx || !core || !MtX || !M0 || !M1 || !M2 || !status_f64 || d0 < 1 || d1 < 1 || d2 < 1 || max_iter < 0) return NNF_ERR_ARG;
     if (d0 > 128 || d1 > 128 || d2 > 128) return NNF_ERR_UNSUPPORTED;
     const int64_t S = (int64_t)d0 * d1 * d2;
-    const size_t shm = ((size_t)4 * S + (size_t)d0 * d0 + (size_t)d1 * d1 + (size_t)d2 * d2 + 128 + 128 + 16) * 8;
-    if (shm > (size_t)160 * 1024) return NNF_ERR_UNSUPPORTED;   // the core must fit in one workgroup's LDS
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_ntd_core_pg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)shm) != hipSuccess)
-        return NNF_ERR_LAUNCH;
+    if (S > ((int64_t)1 << 22)) return NNF_ERR_UNSUPPORTED;
+    const size_t fixed = (size_t)272 * 8 + ((((size_t)d0 * d0 + (size_t)d1 * d1 + (size_t)d2 * d2) + 1) & ~(size_t)1) * 4;
+    const size_t lim = (size_t)160 * 1024;
     const int threads = S >= 1024 ? 1024 : (S >= 512 ? 512 : 256);
-    hipLaunchKernelGGL(nnf_ntd_core_pg_kernel, dim3(1), dim3(threads), shm, (hipStream_t)stream, core, MtX, M0, M1, M2, d0, d1, d2,
-                       sparse, delta, max_iter, norm_sq, status_f64);
+    hipStream_t st = (hipStream_t)stream;
+    if (fixed + (size_t)4 * S * 8 <= lim) {          // everything in LDS, fp64 storage
+        const size_t shm = fixed + (size_t)4 * S * 8;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_ntd_core_pg_kernel<double>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+            return NNF_ERR_LAUNCH;
+        hipLaunchKernelGGL(nnf_ntd_core_pg_kernel<double>, dim3(1), dim3(threads), shm, st, core, MtX, M0, M1, M2, d0, d1, d2, sparse,
+                           delta, max_iter, norm_sq, status_f64, (double*)nullptr);
+    } else if (fixed + (size_t)4 * S * 4 <= lim) {   // everything in LDS, fp32 storage, fp64 accumulation
+        const size_t shm = fixed + (size_t)4 * S * 4;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_ntd_core_pg_kernel<float>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+            return NNF_ERR_LAUNCH;
+        hipLaunchKernelGGL(nnf_ntd_core_pg_kernel<float>, dim3(1), dim3(threads), shm, st, core, MtX, M0, M1, M2, d0, d1, d2, sparse,
+                           delta, max_iter, norm_sq, status_f64, (double*)nullptr);
+    } else {                                          // core-sized arrays in the context workspace (slow: L2 latency per access)
+        nnf_ws_cursor cur(ctx);
+        double* gbuf = (double*)cur.take((size_t)4 * S * 8);
+        if (!gbuf) return NNF_ERR_WORKSPACE;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_ntd_core_pg_kernel<double>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)fixed) != hipSuccess)
+            return NNF_ERR_LAUNCH;
+        hipLaunchKernelGGL(nnf_ntd_core_pg_kernel<double>, dim3(1), dim3(threads), fixed, st, core, MtX, M0, M1, M2, d0, d1, d2, sparse,
+                           delta, max_iter, norm_sq, status_f64, gbuf);
+    }
     NNF_CHECK_LAUNCH();
     return NNF_OK;
 }

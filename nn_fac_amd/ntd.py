@@ -12,8 +12,8 @@ HALS step, per updated mode n (factors kept transposed, r_n x I_n; statement -> 
     F_n = hals_nnls_acc(UtM, UtU, F_n^T)^T               (ntd.py:571-573)  nnf_hals_solve_f32
     core: step, <= 300 projected-gradient steps, error   (ntd.py:581-619,639) nnf_ntd_core_pg_f32 (one launch, fp64 in LDS)
 
-MU step: the factor updates are mu_betadivmin on the unfoldings (nnf_mu_left_f32; unfoldings 1, 2 are materialised
-once per run), the core update mu_tensorial (mu.py:99-159) is the right-update accumulation of the mode-0 problem
+MU step: the factor updates are mu_betadivmin on the transposed unfoldings (nnf_mu_right_f32 on (prod other dims) x I_n:
+the last mode is a view of T, modes 0 and 1 are materialised once per run), the core update mu_tensorial (mu.py:99-159) is the right-update accumulation of the mode-0 problem
 (nnf_mu_right_accum_f32 -- U V is never materialised) followed by two core-sized contractions, and the cost is
 nnf_betadiv_f32 on the mode-0 problem.
 
@@ -85,14 +85,16 @@ class _NtdState:
         self.t0 = self.T.view(I, J * K)
         self.norm2 = eng.dot(self.t0, self.t0)          # float64 device scalar, ||T||^2 (read once by the driver)
         self.norm2_host = None
-        self._unf = {0: self.t0}
+        self._unf_t = {}
         # 3 HALS status blocks (8 doubles each) + 6 doubles of the core update + the cost
         self.block = torch.zeros(8 * 3 + 8, dtype=torch.float64, device=T.device)
 
-    def unfolded(self, mode):
-        if mode not in self._unf:
-            self._unf[mode] = torch.movedim(self.T, mode, 0).reshape(self.T.shape[mode], -1).contiguous()
-        return self._unf[mode]
+    def unfolded_t(self, mode):
+        """tl.unfold(T, mode)^T as a contiguous (prod(other dims)) x I_mode matrix (MU path).  The last mode is a view of T;
+        modes 0 and 1 are materialised once per run."""
+        if mode not in self._unf_t:
+            self._unf_t[mode] = torch.movedim(self.T, mode, -1).reshape(-1, self.T.shape[mode]).contiguous()
+        return self._unf_t[mode]
 
     def norm_sq(self):
         if self.norm2_host is None:
@@ -256,7 +258,9 @@ def _one_ntd_step_mu_dev(st, core_in, Ft_in, beta, fixed_modes, normalize, mode_
         mats = [Ft[i].t() if i != mode else None for i in range(3)]
         V = torch.movedim(_core_mode_dots(core, mats, skip=mode), mode, 0)
         V = V.reshape(V.shape[0], -1).contiguous()
-        Ft[mode] = eng.mu_left(st.unfolded(mode), Ft[mode], V, beta)          # mu_betadivmin (ntd.py:672)
+        # mu_betadivmin(F, V, unfold(T, mode)) (ntd.py:672) on the TRANSPOSED problem unfold^T ~ V^T F^T: the unfolding is
+        # short and fat (I_mode rows), its transpose gives the streaming kernel prod(other dims) rows to split over
+        Ft[mode] = eng.mu_right(st.unfolded_t(mode), V, Ft[mode], beta)
     core = _mu_tensorial_dev(st, core, Ft, beta)
     if normalize[-1]:
         core = _normalize_core(core, mode_core_norm)

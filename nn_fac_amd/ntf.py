@@ -7,7 +7,7 @@ Per updated mode the reference statements map to the C ABI as follows (factors k
     krao ; rhs = unfolded[mode] @ krao             (ntf.py:448-449) -> nnf_mttkrp3_f32 (one pass over the tensor IN PLACE:
                                                      neither the unfoldings nor the Khatri-Rao matrix are materialised)
     hals_nnls_acc(rhs^T, cross, F[mode]^T)         (ntf.py:454-456) -> nnf_hals_solve_f32
-    mu_betadivmin(F[mode], krao^T, unfolded[mode]) (ntf.py:459-460) -> nnf_mu_left_f32 on the unfolding (MU path only)
+    mu_betadivmin(F[mode], krao^T, unfolded[mode]) (ntf.py:459-460) -> nnf_mu_right_f32 on the transposed unfolding (MU path only)
     cost                                           (ntf.py:462-475) -> nnf_cp3_betadiv_f32: the reference's
         ||T||^2 - 2<F,rhs> + ||F krao^T||^2 equals ||T - model||^2 exactly; it is evaluated directly (one more pass
         over the tensor) because the difference form cancels catastrophically in fp32.
@@ -67,10 +67,10 @@ class _NtfState:
         self._unf = {}
         self.block = torch.zeros(8 * 3 + 8, dtype=torch.float64, device=T.device)   # 3 HALS status blocks + cost
 
-    def unfolded(self, mode):
-        """tl.unfold(T, mode) = moveaxis(mode -> 0).reshape(dim, -1)  (MU path; mode 0 is a view)."""
+    def unfolded_t(self, mode):
+        """tl.unfold(T, mode)^T = moveaxis(mode -> last).reshape(-1, dim), contiguous (MU path; the last mode is a view)."""
         if mode not in self._unf:
-            self._unf[mode] = torch.movedim(self.T, mode, 0).reshape(self.T.shape[mode], -1).contiguous()
+            self._unf[mode] = torch.movedim(self.T, mode, -1).reshape(-1, self.T.shape[mode]).contiguous()
         return self._unf[mode]
 
 
@@ -122,7 +122,9 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
             nstat += 1
             Ft[mode] = new
         else:
-            Ft[mode] = eng.mu_left(st.unfolded(mode), Ft[mode], _krao_t(Ft, mode), beta)
+            # mu_betadivmin(F, krao^T, unfold) (ntf.py:459-460) on the transposed problem unfold^T ~ krao F^T: the unfolding
+            # has only I_mode rows, its transpose gives the streaming kernel prod(other dims) rows to split over
+            Ft[mode] = eng.mu_right(st.unfolded_t(mode), _krao_t(Ft, mode), Ft[mode], beta)
 
     cost = st.block[24:25]
     if update_rule == "hals":

@@ -53,11 +53,14 @@ def test_ttm3_all_modes(eng, shape, r):
         assert rel(got, want) < 1e-5
 
 
-@pytest.mark.parametrize("dims,sparse", [((9, 9, 3), 0.0), ((4, 3, 2), 0.05), ((16, 12, 20), 0.0), ((1, 5, 1), 0.0)])
-def test_core_projected_gradient(eng, dims, sparse):
+@pytest.mark.parametrize("dims,sparse,scale", [((9, 9, 3), 0.0, 1.0), ((4, 3, 2), 0.05, 1.0), ((16, 12, 20), 0.0, 0.1),
+                                               ((1, 5, 1), 0.0, 1.0),
+                                               ((20, 20, 20), 0.0, 0.1),    # fp32 storage in LDS, fp64 accumulation
+                                               ((24, 24, 24), 0.0, 0.1)])   # does not fit in LDS: workspace path
+def test_core_projected_gradient(eng, dims, sparse, scale):
     rng = np.random.RandomState(sum(dims))
     shape = tuple(5 * d + 3 for d in dims)
-    F = [rng.rand(shape[i], dims[i]) for i in range(3)]
+    F = [scale * rng.rand(shape[i], dims[i]) for i in range(3)]   # scale keeps the 6-decimal step away from 0
     core_true = rng.rand(*dims)
     T = orc.multi_mode_dot(core_true, F) + 0.01 * rng.rand(*shape)
     # fp32-rounded inputs on both sides
@@ -81,9 +84,10 @@ def test_core_projected_gradient(eng, dims, sparse):
     want_err = nrm2 - 2 * np.sum(MtX * core) + np.sum(orc.multi_mode_dot(core, M) * core)
     cd = dev(core0)
     st = eng.ntd_core_pg(cd, dev(MtX), [dev(m_) for m_ in M], sparse, 0.01, 300, nrm2).cpu().numpy()
-    assert int(st[0]) == cnt - 1
+    fp32_store = 4500 < core.size < 9500
+    assert abs(int(st[0]) - (cnt - 1)) <= (3 if fp32_store else 0)      # the stop test compares fp32-rounded updates there
     assert abs(st[3] - step) <= 1e-12
-    assert rel(cd.cpu().numpy(), core) < 1e-5
+    assert rel(cd.cpu().numpy(), core) < (1e-4 if fp32_store else 1e-5)
     assert abs(st[4] - want_err) <= 1e-6 * nrm2
 
 

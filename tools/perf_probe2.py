@@ -57,3 +57,19 @@ _, costs, _ = compute_ntf(T, R, F0, n_iter_max=10, tol=0, alpha=math.inf, return
                           normalize=[False]*3, sweep_log=sw)
 torch.cuda.synchronize(); dt = time.time() - t0
 print(f"NTF HALS (config D): {dt*100:.3f} ms/iter -> {10/dt:.1f} it/s; sweeps {sw[-3:]}; costs {costs[0]:.4e} -> {costs[-1]:.4e}")
+del T, A, B, C
+# ---- NTD: 300x300x300, ranks (20, 20, 20)
+from nn_fac_amd.ntd import compute_ntd
+I = J = K = 300; rk = [20, 20, 20]
+Fs = [torch.rand(s, q, device="cuda", generator=g) for s, q in zip((I, J, K), rk)]
+G0 = torch.rand(*rk, device="cuda", generator=g)
+T = torch.einsum('abc,ia,jb,kc->ijk', G0, *Fs) + 1e-2 * torch.rand(I, J, K, device="cuda", generator=g)
+F0 = [torch.rand(s, q, device="cuda", generator=g) for s, q in zip((I, J, K), rk)]
+C0 = torch.rand(*rk, device="cuda", generator=g)
+kw = dict(sparsity_coefficients=[None] * 4, normalize=[False] * 4, tol=0, deterministic=True)
+for rule, beta in (("hals", 2), ("mu", 1)):
+    compute_ntd(T, rk, C0, F0, n_iter_max=2, update_rule=rule, beta=beta, **kw)
+    torch.cuda.synchronize(); t0 = time.time()
+    _, _, costs, _ = compute_ntd(T, rk, C0, F0, n_iter_max=10, update_rule=rule, beta=beta, return_costs=True, **kw)
+    torch.cuda.synchronize(); dt = time.time() - t0
+    print(f"NTD {rule} beta={beta} (300^3, ranks 20): {dt*100:.3f} ms/iter -> {10/dt:.1f} it/s; costs {costs[0]:.4e} -> {costs[-1]:.4e}")

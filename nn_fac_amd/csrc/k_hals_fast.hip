@@ -265,18 +265,18 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
     };
     const int voff0 = gtid < a.ncols ? (int)(gtid * 4) : (int)0x7ffffff0;
     if constexpr (RES) load_col(voff0);
-    // Speculation needs "V after the last confirmed sweep" when a stop arrives one sweep late.  Small ranks keep it in
-    // a second set of registers (one copy per sweep, V is written to memory once, at the end); larger ranks have no room
-    // and store V after every confirmed sweep instead (20 MB of stores per sweep at B's U side).
+    // Sweep loop.  mode 1: fixed count, per-sweep local partials, nothing to decide.
+    // mode 0, resident columns, RP <= 56: lag-one speculation.  After sweep s the workgroup publishes its partial and goes
+    // straight on to sweep s+1 in registers; only then does it collect the global sum of sweep s (published by every
+    // workgroup a whole sweep ago, its granule loads issued a sweep ago: the wait is normally free).  If that sum says
+    // "stop" (nnls.py:156) the registers hold one sweep too many and V is taken from a register copy made before the
+    // sweep; V is written to memory once, at the end.  Cost: one wasted sweep at the end instead of a stall per sweep.
+    // Larger ranks have no registers for the copy; storing V after every confirmed sweep instead costs more than it saves
+    // (125000 x 100: 100 vs 45 us per sweep), so they -- and the strided mode -- wait for the sum of the sweep just done.
     constexpr bool BACKUP = RES && RP <= 56;
+    constexpr bool SPEC = BACKUP;
     f32x2 vb[BACKUP ? RP / 2 : 1];
 
-    // Sweep loop.  mode 1: fixed count, per-sweep local partials, nothing to decide.
-    // mode 0, resident columns: lag-one speculation.  After sweep s the workgroup publishes its partial and goes straight
-    // on to sweep s+1 in registers; only then does it collect the global sum of sweep s (published by every workgroup a
-    // whole sweep ago, so the wait is normally free).  If that sum says "stop" (nnls.py:156) the registers are dropped:
-    // memory still holds V after sweep s, because V is stored only after a sweep has been confirmed.  Cost: one wasted
-    // sweep at the end instead of a grid-barrier stall in every sweep.  Strided mode keeps the blocking exchange.
     double eps0 = 0.0, eps = 1.0;
     int done = 0;
     bool ok = true, stopped = false;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
             }
         }
         if constexpr (RES) {
-            if constexpr (RP <= 96)   // (the resident pair of columns leaves no registers for it beyond that)
+            if constexpr (SPEC)
                 if (a.mode == 0 && s >= 2) hals_collect_issue(a.sy, s - 1, nblocks, pf);   // consumed after this sweep
             const float f = sweep(voff0);
             nd = gtid < a.ncols ? (double)f : 0.0;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
             continue;
         }
         hals_publish(a.sy, s, nblocks, bs);
-        const int c = RES ? s - 1 : s;          // sweep whose global sum is examined now
+        const int c = SPEC ? s - 1 : s;         // sweep whose global sum is examined now
         if (c >= 1) {
             double tot;
             if constexpr (RES) ok = hals_collect1(a.sy, c, nblocks, tot, red2[s & 1][1], &lds_flag, pf);
@@ -331,20 +331,21 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
             done = c;
             if (!(eps >= a.delta * eps0)) { stopped = true; break; }   // nnls.py:156: sweep c was the last one
         }
-        if constexpr (RES && !BACKUP) store_col(voff0);    // V after sweep s (sweep s-1 said "go on")
     }
-    if constexpr (BACKUP) {
+    if constexpr (RES) {
         if (a.mode == 0) {
-            if (stopped || !ok) {   // the registers hold one sweep too many: fall back to the copy
+            if constexpr (BACKUP) {
+                if (stopped || !ok) {   // the registers hold one sweep too many: fall back to the copy
 #pragma unroll
-                for (int k = 0; k < RP / 2; ++k) v2[k] = vb[k];
+                    for (int k = 0; k < RP / 2; ++k) v2[k] = vb[k];
+                }
             }
             if (a.max_sweeps >= 1) store_col(voff0);
         }
     }
     if (a.mode == 1) {
         if constexpr (RES) store_col(voff0);
-    } else if (RES && ok && !stopped && a.max_sweeps >= 1) {
+    } else if (SPEC && ok && !stopped && a.max_sweeps >= 1) {
         double tot;                             // ran to the sweep budget: the last sweep's sum is still due
         ok = hals_collect(a.sy, a.max_sweeps, nblocks, tot, red, &lds_flag);
         if (ok) {

@@ -26,6 +26,7 @@ __device__ __forceinline__ float dpp_quad(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
 }
 
+#if !defined(QUAD_PART) || QUAD_PART == 0
 // prep: LDS image of the row-scaled Gram.  Row k (k < RQ = 4*CH) is four chunks of CHP = roundup(CH, 4) floats; chunk q holds
 // G'[k][q*CH + jj] = UtU[k][q*CH + jj] / UtU[k][k], jj < CH (0 in the padding, outside r x r and in rows with a zero
 // diagonal).  Then 1/diag per row (0 = skip row), zeroed barrier word and status.
@@ -54,6 +55,8 @@ __global__ void nnf_hals_prep_quad_kernel(const float* __restrict__ UtU, int64_t
         }
     }
 }
+
+#endif
 
 // Row update shared by both sweep variants: g = this lane's chunk of G'[k,:] (NP float4), q0/j = owner lane / slot of row k.
 template <int CH, int K>
@@ -141,7 +144,7 @@ struct quad_rows_checked {
 template <int CH>
 __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
     constexpr int RQ = 4 * CH, CHP = (CH + 3) & ~3, RS = 4 * CHP;
-    __shared__ __attribute__((aligned(16))) float lg[RQ * RS];
+    extern __shared__ __attribute__((aligned(16))) float lg[];   // RQ * RS floats (dynamic: 64 KB at r = 128)
     __shared__ double red[4];
     __shared__ unsigned lds_flag;
     const int lane = threadIdx.x, q = lane & 3;
@@ -250,14 +253,18 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
     }
 }
 
-static int quad_ch(int r) { return r <= 96 ? (r + 3) / 4 : 0; }   // rows per lane; 0: not built
+static int quad_ch(int r) { return r <= 128 ? (r + 3) / 4 : 0; }   // rows per lane; 0: not built
+static size_t quad_lds(int ch) { return (size_t)(4 * ch) * (size_t)(4 * ((ch + 3) & ~3)) * 4; }
 
 template <int CH>
 static int quad_cap(nnf_ctx* ctx) {   // workgroups that can be co-resident (all of them must be: persistent kernel)
     static int cached = 0;
     if (cached == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_quad_kernel<CH>, 64, 0) != hipSuccess || nb < 1) return -1;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_quad_kernel<CH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)quad_lds(CH));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_quad_kernel<CH>, 64, quad_lds(CH)) != hipSuccess || nb < 1)
+            return -1;
         int b = nb >= 3 ? nb - 1 : nb;   // margin: the occupancy API can over-report by one block per CU
         if (b > 8) b = 8;
         cached = b;
@@ -265,22 +272,62 @@ static int quad_cap(nnf_ctx* ctx) {   // workgroups that can be co-resident (all
     return cached * ctx->num_cus;
 }
 
+// The 32 instantiations are compiled as four translation units (-DQUAD_PART=0..3, like k_hals_fast.hip); each part exports
+// one residency query and one launcher for its range of CH, part 0 also holds the prep kernel's launcher and the host logic.
 #define QUAD_CASE(N, FN, ...) \
     case N:                   \
         return FN<N>(__VA_ARGS__);
-#define QUAD_DISPATCH(EXPR_CH, FN, ...)                                                                             \
-    switch (EXPR_CH) {                                                                                              \
-        QUAD_CASE(1, FN, __VA_ARGS__) QUAD_CASE(2, FN, __VA_ARGS__) QUAD_CASE(3, FN, __VA_ARGS__)                   \
-        QUAD_CASE(4, FN, __VA_ARGS__) QUAD_CASE(5, FN, __VA_ARGS__) QUAD_CASE(6, FN, __VA_ARGS__)                   \
-        QUAD_CASE(7, FN, __VA_ARGS__) QUAD_CASE(8, FN, __VA_ARGS__) QUAD_CASE(9, FN, __VA_ARGS__)                   \
-        QUAD_CASE(10, FN, __VA_ARGS__) QUAD_CASE(11, FN, __VA_ARGS__) QUAD_CASE(12, FN, __VA_ARGS__)                \
-        QUAD_CASE(13, FN, __VA_ARGS__) QUAD_CASE(14, FN, __VA_ARGS__) QUAD_CASE(15, FN, __VA_ARGS__)                \
-        QUAD_CASE(16, FN, __VA_ARGS__) QUAD_CASE(17, FN, __VA_ARGS__) QUAD_CASE(18, FN, __VA_ARGS__)                \
-        QUAD_CASE(19, FN, __VA_ARGS__) QUAD_CASE(20, FN, __VA_ARGS__) QUAD_CASE(21, FN, __VA_ARGS__)                \
-        QUAD_CASE(22, FN, __VA_ARGS__) QUAD_CASE(23, FN, __VA_ARGS__) QUAD_CASE(24, FN, __VA_ARGS__)                \
-        default: return -1;                                                                                         \
-    }
-static int quad_cap_dispatch(nnf_ctx* ctx, int ch) { QUAD_DISPATCH(ch, quad_cap, ctx) }
+#ifndef QUAD_PART
+#define QUAD_PART 0
+#endif
+#if QUAD_PART == 0
+#define QUAD_CASES(FN, ...)                                                                                             \
+    QUAD_CASE(1, FN, __VA_ARGS__) QUAD_CASE(2, FN, __VA_ARGS__) QUAD_CASE(3, FN, __VA_ARGS__) QUAD_CASE(4, FN, __VA_ARGS__)     \
+    QUAD_CASE(5, FN, __VA_ARGS__) QUAD_CASE(6, FN, __VA_ARGS__) QUAD_CASE(7, FN, __VA_ARGS__) QUAD_CASE(8, FN, __VA_ARGS__)     \
+    QUAD_CASE(9, FN, __VA_ARGS__) QUAD_CASE(10, FN, __VA_ARGS__) QUAD_CASE(11, FN, __VA_ARGS__) QUAD_CASE(12, FN, __VA_ARGS__)  \
+    QUAD_CASE(13, FN, __VA_ARGS__) QUAD_CASE(14, FN, __VA_ARGS__)
+#define QUAD_PART_FN(name) name##0
+#elif QUAD_PART == 1
+#define QUAD_CASES(FN, ...)                                                                                             \
+    QUAD_CASE(15, FN, __VA_ARGS__) QUAD_CASE(16, FN, __VA_ARGS__) QUAD_CASE(17, FN, __VA_ARGS__) QUAD_CASE(18, FN, __VA_ARGS__) \
+    QUAD_CASE(19, FN, __VA_ARGS__) QUAD_CASE(20, FN, __VA_ARGS__) QUAD_CASE(21, FN, __VA_ARGS__)
+#define QUAD_PART_FN(name) name##1
+#elif QUAD_PART == 2
+#define QUAD_CASES(FN, ...)                                                                                             \
+    QUAD_CASE(22, FN, __VA_ARGS__) QUAD_CASE(23, FN, __VA_ARGS__) QUAD_CASE(24, FN, __VA_ARGS__) QUAD_CASE(25, FN, __VA_ARGS__) \
+    QUAD_CASE(26, FN, __VA_ARGS__) QUAD_CASE(27, FN, __VA_ARGS__)
+#define QUAD_PART_FN(name) name##2
+#else
+#define QUAD_CASES(FN, ...)                                                                                             \
+    QUAD_CASE(28, FN, __VA_ARGS__) QUAD_CASE(29, FN, __VA_ARGS__) QUAD_CASE(30, FN, __VA_ARGS__) QUAD_CASE(31, FN, __VA_ARGS__) \
+    QUAD_CASE(32, FN, __VA_ARGS__)
+#define QUAD_PART_FN(name) name##3
+#endif
+
+template <int CH>
+static int quad_launch(const hals_args& a, int nblocks, hipStream_t st) {
+    hipLaunchKernelGGL((nnf_hals_quad_kernel<CH>), dim3(nblocks), dim3(64), quad_lds(CH), st, a);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+int QUAD_PART_FN(nnf_hals_quad_cap_part)(nnf_ctx* ctx, int ch) {
+    switch (ch) { QUAD_CASES(quad_cap, ctx) default: return -1; }
+}
+int QUAD_PART_FN(nnf_hals_quad_launch_part)(int ch, const hals_args& a, int nblocks, hipStream_t st) {
+    switch (ch) { QUAD_CASES(quad_launch, a, nblocks, st) default: return NNF_ERR_UNSUPPORTED; }
+}
+
+#if QUAD_PART == 0
+int nnf_hals_quad_cap_part1(nnf_ctx*, int);
+int nnf_hals_quad_cap_part2(nnf_ctx*, int);
+int nnf_hals_quad_cap_part3(nnf_ctx*, int);
+int nnf_hals_quad_launch_part1(int, const hals_args&, int, hipStream_t);
+int nnf_hals_quad_launch_part2(int, const hals_args&, int, hipStream_t);
+int nnf_hals_quad_launch_part3(int, const hals_args&, int, hipStream_t);
+static int quad_cap_dispatch(nnf_ctx* ctx, int ch) {
+    return ch <= 14 ? nnf_hals_quad_cap_part0(ctx, ch) : ch <= 21 ? nnf_hals_quad_cap_part1(ctx, ch)
+         : ch <= 27 ? nnf_hals_quad_cap_part2(ctx, ch) : nnf_hals_quad_cap_part3(ctx, ch);
+}
 
 // Heuristic + residency: the quad kernel wins while its waves stay at <= 2 per SIMD (ncols <= 32768 on 256 CUs).
 bool nnf_hals_quad_fits(nnf_ctx* ctx, int r, int64_t ncols, int max_blocks_cap) {
@@ -297,13 +344,6 @@ size_t nnf_hals_quad_gram_floats(int r) {
     return (size_t)rq * rs + rq;
 }
 
-template <int CH>
-static int quad_launch(const hals_args& a, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL((nnf_hals_quad_kernel<CH>), dim3(nblocks), dim3(64), 0, st, a);
-    NNF_CHECK_LAUNCH();
-    return NNF_OK;
-}
-
 // Gq: workspace of nnf_hals_quad_gram_floats(r) floats.  a.Gp / a.dinv are set here.
 int nnf_hals_quad_run(nnf_ctx* ctx, const float* UtU, int64_t ldg, float* Gq, unsigned* counter, hals_args a, int* nblocks_out,
                       hipStream_t st) {
@@ -318,5 +358,7 @@ int nnf_hals_quad_run(nnf_ctx* ctx, const float* UtU, int64_t ldg, float* Gq, un
     a.dinv = dinvq;
     const int nblocks = (int)nnf_cdiv(a.ncols, 16);
     *nblocks_out = nblocks;
-    QUAD_DISPATCH(ch, quad_launch, a, nblocks, st)
+    return ch <= 14 ? nnf_hals_quad_launch_part0(ch, a, nblocks, st) : ch <= 21 ? nnf_hals_quad_launch_part1(ch, a, nblocks, st)
+         : ch <= 27 ? nnf_hals_quad_launch_part2(ch, a, nblocks, st) : nnf_hals_quad_launch_part3(ch, a, nblocks, st);
 }
+#endif   // QUAD_PART == 0

@@ -173,7 +173,7 @@ def test_hals_does_not_modify_inputs(eng):
 
 
 @pytest.mark.parametrize("r,ncols,layout", [(50, 100000, "lane"), (100, 20000, "lane"), (30, 500, "lane"), (50, 300000, "lane"),
-                                            (30, 500, "quad"), (50, 2000, "quad"), (96, 8000, "quad"), (70, 16000, "quad"),
+                                            (30, 500, "quad"), (50, 2000, "quad"), (96, 8000, "quad"), (70, 16000, "quad"), (100, 4000, "quad"), (128, 3000, "quad"),
                                             (100, 20000, "auto"), (120, 9000, "lane"), (64, 70000, "lane"), (56, 40000, "lane"), (34, 40000, "lane")])
 def test_hals_large_vs_oracle(eng, r, ncols, layout, monkeypatch):
     """Resident and strided (ncols > resident threads) persistent solves vs the fp64 oracle; sweep counts equal."""

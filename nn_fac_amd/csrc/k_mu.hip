@@ -77,8 +77,11 @@ __device__ __forceinline__ void mu_elem(float x, float p, float beta, float& r1,
 // =========================================================================================================
 // right update: slabs of num (and den) [ks][r][ldp], split over the rows of X like xty.
 // =========================================================================================================
+// The V fragments of a wave's 64 columns are loop-invariant and live in registers (4*MT float4, straight from global),
+// which leaves 64 KB of LDS (the two double-buffered images of the Ut chunk) and lets two workgroups share a CU.
+// (KL only: the general-beta form carries a second accumulator set and keeps the fragments in LDS, one workgroup per CU.)
 template <int MT, int BM, bool VEC>
-__global__ __launch_bounds__(256, 1) void nnf_mu_right_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+__global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_right_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                               const float* __restrict__ Ut, int64_t ldu,
                                                               const float* __restrict__ V, int64_t ldv, int r, float beta,
                                                               float* __restrict__ snum, float* __restrict__ sden,
@@ -86,8 +89,9 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_right_kernel(const float* __res
                                                               int a_vec_ok) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KS = (r + 3) >> 2;
-    f32x4* ldsVf = reinterpret_cast<f32x4*>(smem);                 // [4][KS][64]: V[4s+g][jw+4jj..+3]
-    f32x4* ldsA = ldsVf + (size_t)4 * KS * 64;                       // [2][MT*256]  F_A image of the Ut chunk
+    constexpr bool REGF = (BM == BM_KL);                             // resident fragments in registers / in LDS
+    f32x4* ldsVf = reinterpret_cast<f32x4*>(smem);                 // !REGF: [4][KS][64]: V[4s+g][jw+4jj..+3]
+    f32x4* ldsA = ldsVf + (REGF ? 0 : (size_t)4 * KS * 64);          // [2][MT*256]  F_A image of the Ut chunk
     f32x4* ldsK = ldsA + (size_t)2 * MT * 256;                       // [2][MT*256]  F_K image of the Ut chunk
     int ks, cb;
     nnf_xcd_map(blockIdx.x, ncb, ks, cb);
@@ -102,20 +106,37 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_right_kernel(const float* __res
     const int voff = (jl < n) ? (int)(((int64_t)4 * g * ldx + jl) * 4) : (int)0x7ffffff0;
     const int ldx4 = (int)(ldx * 4);
 
-    // resident V fragments of this workgroup's 256 columns
-    for (int e = threadIdx.x; e < 4 * KS * 64; e += 256) {
-        const int ww = e / (KS * 64), rem = e - ww * KS * 64, s = rem >> 6, L = rem & 63;
-        const int k = 4 * s + (L >> 4);
-        const int64_t j = (int64_t)cb * 256 + ww * 64 + 4 * (L & 15);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < r && j < n) {
-            const float* p = V + (int64_t)k * ldv + j;
-            v[0] = p[0];
-            if (j + 1 < n) v[1] = p[1];
-            if (j + 2 < n) v[2] = p[2];
-            if (j + 3 < n) v[3] = p[3];
+    // resident V fragments of this wave's 64 columns: vfr[s] = V[4s+g][jl .. jl+3], s < KS (zero beyond r x n)
+    f32x4 vfr[REGF ? 4 * MT : 1];
+    if constexpr (REGF) {
+#pragma unroll
+        for (int s_ = 0; s_ < 4 * MT; ++s_) {
+            const int k = 4 * s_ + g;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < r && jl < n) {
+                const float* p = V + (int64_t)k * ldv + jl;
+                v[0] = p[0];
+                if (jl + 1 < n) v[1] = p[1];
+                if (jl + 2 < n) v[2] = p[2];
+                if (jl + 3 < n) v[3] = p[3];
+            }
+            vfr[s_] = v;
         }
-        ldsVf[e] = v;
+    } else {
+        for (int e = threadIdx.x; e < 4 * KS * 64; e += 256) {
+            const int ww = e / (KS * 64), rem = e - ww * KS * 64, s_ = rem >> 6, L = rem & 63;
+            const int k = 4 * s_ + (L >> 4);
+            const int64_t j = (int64_t)cb * 256 + ww * 64 + 4 * (L & 15);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < r && j < n) {
+                const float* p = V + (int64_t)k * ldv + j;
+                v[0] = p[0];
+                if (j + 1 < n) v[1] = p[1];
+                if (j + 2 < n) v[2] = p[2];
+                if (j + 3 < n) v[3] = p[3];
+            }
+            ldsVf[e] = v;
+        }
     }
     f32x4 num[MT][4], den[BM == BM_GEN ? MT : 1][4];
 #pragma unroll
@@ -125,15 +146,14 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_right_kernel(const float* __res
             num[mt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (BM == BM_GEN) den[mt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    f32x4 xb[4][4];
+    f32x4 xb[2][4];   // ring of two 16-row groups: group gi lives in xb[gi & 1] and is refilled with group gi + 2
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, (16 * t + c) * ldx4);
     stageA_direct<MT>(Ut, ldu, r, i_end, i_begin, a_vec_ok, ldsA);
     stageK<MT>(Ut, ldu, r, i_end, i_begin, ldsK);
     __syncthreads();
-    const f32x4* vf = ldsVf + (size_t)w * KS * 64 + lane;
 
     for (int q = 0; q < nchunk; ++q) {
         const f32x4* imgA = ldsA + (size_t)(q & 1) * MT * 256;
@@ -142,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_right_kernel(const float* __res
         f32x4 sa[MT], sk[MT];
         stageA_load<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), a_vec_ok, sa);
         stageK_load<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), sk);
-        const int soff_next = (q + 1) * 64 * ldx4;
+        const int soff_q = q * 64 * ldx4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             // MFMA #1: P[i0+16t+4g+reg][jw+4jj+cc]
@@ -155,7 +175,9 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_right_kernel(const float* __res
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (4 * s4 + c < KS) {
-                        const f32x4 bv = vf[(4 * s4 + c) * 64];
+                        f32x4 bv;
+                        if constexpr (REGF) bv = vfr[4 * s4 + c];
+                        else bv = ldsVf[(size_t)w * KS * 64 + (4 * s4 + c) * 64 + lane];
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc) accP[cc] = MFMA16(ak[c], bv[cc], accP[cc]);
                     }
@@ -169,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_right_kernel(const float* __res
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     float r1, r2;
-                    mu_elem<BM>(xb[t][reg][cc], accP[cc][reg], beta, r1, r2);
+                    mu_elem<BM>(xb[t & 1][reg][cc], accP[cc][reg], beta, r1, r2);
                     const bool ok = reg < rowrem;
                     R1[cc][reg] = ok ? r1 : 0.f;
                     if constexpr (BM == BM_GEN) R2[cc][reg] = ok ? r2 : 0.f;
@@ -188,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_right_kernel(const float* __res
                         if constexpr (BM == BM_GEN) den[mt][cc] = MFMA16(af[mt][reg], R2[cc][reg], den[mt][cc]);
                     }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, soff_next + (16 * t + c) * ldx4);
+            for (int c = 0; c < 4; ++c) xb[t & 1][c] = nnf_bload4<VEC>(rs, voff, soff_q + (16 * (t + 2) + c) * ldx4);
         }
         stageA_store<MT>(ldsA + (size_t)((q + 1) & 1) * MT * 256, sa);
         stageK_store<MT>(ldsK + (size_t)((q + 1) & 1) * MT * 256, sk);
@@ -248,15 +270,16 @@ __global__ __launch_bounds__(256) void nnf_rowsum_kernel(const float* __restrict
 // left update: workgroup = 256 rows of X (wave: 64 rows as four 16-row N tiles), sweeping all columns; no split.
 // =========================================================================================================
 template <int MT, int BM, bool VEC>
-__global__ __launch_bounds__(256, 1) void nnf_mu_left_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+__global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                              const float* __restrict__ Ut, int64_t ldu,
                                                              const float* __restrict__ V, int64_t ldv, int r, float beta,
                                                              const double* __restrict__ den_vec, float gamma,
                                                              float* __restrict__ Ut_out, int64_t lduo, int a_vec_ok) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KS = (r + 3) >> 2;
-    f32x4* ldsUf = reinterpret_cast<f32x4*>(smem);                 // [4][KS][64]: comps nt: Ut[4s+g][i0w+16nt+ii]
-    f32x4* ldsA = ldsUf + (size_t)4 * KS * 64;                       // [2][MT*256]  F_A image of the V chunk
+    constexpr bool REGF = (BM == BM_KL);                             // resident fragments in registers / in LDS
+    f32x4* ldsUf = reinterpret_cast<f32x4*>(smem);                 // !REGF: [4][KS][64]: comps nt: Ut[4s+g][i0w+16nt+ii]
+    f32x4* ldsA = ldsUf + (REGF ? 0 : (size_t)4 * KS * 64);          // [2][MT*256]  F_A image of the V chunk
     f32x4* ldsK = ldsA + (size_t)2 * MT * 256;                       // [2][MT*256]  F_K image of the V chunk
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ii = lane & 15, g = lane >> 4;
@@ -269,18 +292,37 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_left_kernel(const float* __rest
     const int ldx4 = (int)(ldx * 4);
     const int nchunk = (int)((n + 63) >> 6);
 
-    for (int e = threadIdx.x; e < 4 * KS * 64; e += 256) {
-        const int ww = e / (KS * 64), rem = e - ww * KS * 64, s = rem >> 6, L = rem & 63;
-        const int k = 4 * s + (L >> 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < r) {
+    // resident U fragments of this wave's 64 rows, in registers (like the V fragments of the right kernel):
+    // ufr[s][nt] = Ut[4s+g][i0w + 16nt + ii], s < KS (zero beyond r x m)
+    f32x4 ufr[REGF ? 4 * MT : 1];
+    if constexpr (REGF) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int64_t i = (int64_t)blockIdx.x * 256 + 64 * ww + 16 * nt + (L & 15);
-                if (i < m) v[nt] = Ut[(int64_t)k * ldu + i];
+        for (int s_ = 0; s_ < 4 * MT; ++s_) {
+            const int k = 4 * s_ + g;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < r) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int64_t i = i0w + 16 * nt + ii;
+                    if (i < m) v[nt] = Ut[(int64_t)k * ldu + i];
+                }
             }
+            ufr[s_] = v;
         }
-        ldsUf[e] = v;
+    } else {
+        for (int e = threadIdx.x; e < 4 * KS * 64; e += 256) {
+            const int ww = e / (KS * 64), rem = e - ww * KS * 64, s_ = rem >> 6, L = rem & 63;
+            const int k = 4 * s_ + (L >> 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < r) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int64_t i = (int64_t)blockIdx.x * 256 + 64 * ww + 16 * nt + (L & 15);
+                    if (i < m) v[nt] = Ut[(int64_t)k * ldu + i];
+                }
+            }
+            ldsUf[e] = v;
+        }
     }
     f32x4 num[MT][4], den[BM == BM_GEN ? MT : 1][4];
 #pragma unroll
@@ -290,15 +332,14 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_left_kernel(const float* __rest
             num[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (BM == BM_GEN) den[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    f32x4 xb[4][4];  // [t][nt]: X[i0w+16nt+ii][64q+16t+4g .. +3]
+    f32x4 xb[2][4];  // ring of two 16-column groups [group parity][nt]: X[i0w+16nt+ii][16*gi+4g .. +3]
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 64 * t);
     stageA_direct<MT>(V, ldv, r, n, 0, a_vec_ok, ldsA);
     stageK<MT>(V, ldv, r, n, 0, ldsK);
     __syncthreads();
-    const f32x4* uf = ldsUf + (size_t)w * KS * 64 + lane;
 
     for (int q = 0; q < nchunk; ++q) {
         const f32x4* imgA = ldsA + (size_t)(q & 1) * MT * 256;
@@ -318,7 +359,9 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_left_kernel(const float* __rest
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (4 * s4 + c < KS) {
-                        const f32x4 bu = uf[(4 * s4 + c) * 64];
+                        f32x4 bu;
+                        if constexpr (REGF) bu = ufr[4 * s4 + c];
+                        else bu = ldsUf[(size_t)w * KS * 64 + (4 * s4 + c) * 64 + lane];
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt) accP[nt] = MFMA16(ak[c], bu[nt], accP[nt]);
                     }
@@ -332,7 +375,7 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_left_kernel(const float* __rest
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     float r1, r2;
-                    mu_elem<BM>(xb[t][nt][reg], accP[nt][reg], beta, r1, r2);
+                    mu_elem<BM>(xb[t & 1][nt][reg], accP[nt][reg], beta, r1, r2);
                     const bool ok = rowok && (reg < colrem);
                     R1[nt][reg] = ok ? r1 : 0.f;
                     if constexpr (BM == BM_GEN) R2[nt][reg] = ok ? r2 : 0.f;
@@ -353,7 +396,7 @@ __global__ __launch_bounds__(256, 1) void nnf_mu_left_kernel(const float* __rest
                     }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * (q + 1) + 64 * t);
+                xb[t & 1][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * q + 64 * (t + 2));
         }
         stageA_store<MT>(ldsA + (size_t)((q + 1) & 1) * MT * 256, sa);
         stageK_store<MT>(ldsK + (size_t)((q + 1) & 1) * MT * 256, sk);
@@ -399,7 +442,9 @@ __global__ __launch_bounds__(256) void nnf_mu2_finish_kernel(const float* __rest
 
 static float gamma_of(double beta) { return beta < 1.0 ? (float)(1.0 / (2.0 - beta)) : (beta > 2.0 ? (float)(1.0 / (beta - 1.0)) : 1.f); }
 
-static size_t mu_shm(int MT, int r) { return ((size_t)4 * ((r + 3) / 4) * 64 + (size_t)4 * MT * 256) * 16; }
+static size_t mu_shm(int MT, int r, bool regf) {   // two double-buffered chunk images (+ the resident fragments unless in registers)
+    return ((regf ? 0 : (size_t)4 * ((r + 3) / 4) * 64) + (size_t)4 * MT * 256) * 16;
+}
 
 template <int MT, int BM, bool VEC>
 static int launch_mu_right(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx,
@@ -409,7 +454,7 @@ static int launch_mu_right(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int
     const int ncb = (int)nnf_cdiv(n, 256);
     const int64_t ldp = nnf_rup(n, 4);
     const int nacc = (BM == BM_GEN) ? 2 : 1;
-    int64_t nsplit = (int64_t)ctx->num_cus / ncb;   // one 4-wave workgroup per CU (LDS-bound occupancy)
+    int64_t nsplit = (BM == BM_KL ? 2 : 1) * (int64_t)ctx->num_cus / ncb;   // resident 4-wave workgroups per CU
     if (nsplit < 1) nsplit = 1;
     const int64_t max_split = nnf_cdiv(m, 64);
     if (nsplit > max_split) nsplit = max_split;
@@ -430,7 +475,7 @@ static int launch_mu_right(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int
     float* sden = nacc == 2 ? (float*)cur.take((size_t)nsplit * slab_elems * 4) : nullptr;
     if (!snum || (nacc == 2 && !sden)) return NNF_ERR_WORKSPACE;
     const int a_vec_ok = ((((uintptr_t)Ut) & 15) == 0 && (ldu & 3) == 0) ? 1 : 0;
-    const size_t shm = mu_shm(MT, r);
+    const size_t shm = mu_shm(MT, r, BM == BM_KL);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_mu_right_kernel<MT, BM, VEC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (BM == BM_KL) {  // den[k] = colsum(U)[k] = rowsum(Ut)[k]   (mu.py:86-87 on the transposed problem)
@@ -463,7 +508,7 @@ static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int6
     double* dvec = (double*)cur.take((size_t)r * 8);
     if (!dvec) return NNF_ERR_WORKSPACE;
     const int a_vec_ok = ((((uintptr_t)V) & 15) == 0 && (ldv & 3) == 0) ? 1 : 0;
-    const size_t shm = mu_shm(MT, r);
+    const size_t shm = mu_shm(MT, r, BM == BM_KL);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_mu_left_kernel<MT, BM, VEC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (BM == BM_KL) {  // den[k] = rowsum(V)[k]   (mu.py:86-87)

@@ -149,8 +149,41 @@ __global__ __launch_bounds__(256) void nnf_reduce_slabs_kernel(const float* __re
     }
 }
 
+// same sums, four columns per thread (16-byte slab loads); needs lds % 4 == 0 and 16-byte aligned slabs
+__global__ __launch_bounds__(256) void nnf_reduce_slabs4_kernel(const float* __restrict__ slabs, int nslab,
+                                                                int64_t slab_stride, int rows, int64_t cols, int64_t lds,
+                                                                float* __restrict__ out, int64_t ldo) {
+    const int64_t cq = (cols + 3) >> 2, total = (int64_t)rows * cq;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / cq, col = 4 * (e - row * cq);
+        const float* p = slabs + row * lds + col;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int k = 0; k < nslab; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + (int64_t)k * slab_stride);
+            s0 += (double)v[0];
+            s1 += (double)v[1];
+            s2 += (double)v[2];
+            s3 += (double)v[3];
+        }
+        float* o = out + row * ldo + col;
+        o[0] = (float)s0;
+        if (col + 1 < cols) o[1] = (float)s1;
+        if (col + 2 < cols) o[2] = (float)s2;
+        if (col + 3 < cols) o[3] = (float)s3;
+    }
+}
+
 int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, int rows, int64_t cols, int64_t lds,
                             float* out, int64_t ldo, hipStream_t st) {
+    if ((lds & 3) == 0 && (slab_stride & 3) == 0 && (((uintptr_t)slabs) & 15) == 0 && cols >= 4) {
+        const int64_t total4 = (int64_t)rows * ((cols + 3) >> 2);
+        int grid4 = (int)((total4 + 255) / 256);
+        if (grid4 > 2048) grid4 = 2048;
+        hipLaunchKernelGGL(nnf_reduce_slabs4_kernel, dim3(grid4), dim3(256), 0, st, slabs, nslab, slab_stride, rows, cols, lds, out,
+                           ldo);
+        NNF_CHECK_LAUNCH();
+        return NNF_OK;
+    }
     const int64_t total = (int64_t)rows * cols;
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;

@@ -10,11 +10,12 @@ Grams and every scalar are replicated.  Per outer iteration the only exchanges a
 
 The U-side stopping rule (nnls.py:156) couples all shards once per sweep.  Exchanging one scalar per sweep would put
 a collective and a host round trip (tens of microseconds) behind every ~10 us sweep, so the sweeps are run in chunks:
-a chunk of C sweeps is executed blind (nnf_hals_sweeps_f32 records the local sum of every sweep), ONE all-reduce of
-the C partials follows, and the first sweep at which the reference would have stopped is located.  If that is the
-last sweep of the chunk we are done; if it is earlier the chunk is replayed from a saved copy for exactly that many
-sweeps (the kernels are deterministic, so the replay reproduces the straight run bit for bit).  The chunk length is
-the sweep count of the previous outer iteration, which changes slowly.
+a chunk of C sweeps is executed blind (nnf_hals_sweeps_f32 records the local sum of every sweep and a snapshot of the
+factor after every sweep), ONE all-reduce of the C partials follows, and the first sweep at which the reference would
+have stopped is located.  If that is not the last sweep of the chunk, the factor is taken from that sweep's snapshot
+(bitwise what a straight run would hold; the kernels are deterministic).  The chunk length follows the sweep count of
+the previous outer iteration, which changes slowly; the snapshot ring is sized for a whole solve (100 sweeps of an
+r x m_local factor: 2 GB at config B, 5 GB at E -- small change on a 288 GB device) so that a solve is normally one chunk.
 """
 import torch
 import torch.distributed as dist
@@ -40,7 +41,7 @@ def shard_rows(m, rank, nranks):
 class SweepGuess:
     """Per-factor state of the sharded solve: chunk length memory and the reusable snapshot buffer."""
 
-    def __init__(self, first=16, max_chunk=48):
+    def __init__(self, first=16, max_chunk=104):
         self.value = first
         self.max_chunk = max_chunk
         self.snap = None

@@ -62,6 +62,11 @@ int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_bytes);
 int nnf_ctx_destroy(nnf_ctx* ctx);
 size_t nnf_ctx_workspace_bytes(const nnf_ctx* ctx);
 
+/* Measurement hook: two caller-owned hipEvent_t (passed as void*; NULL, NULL removes them) that nnf_xty_f32 records on its
+ * launch stream immediately before and after its main kernel, so that a benchmark can time the dominant kernel alone --
+ * without the slab reduction that follows it -- with HIP events on the stream the kernel runs on. */
+int nnf_ctx_set_probe(nnf_ctx* ctx, void* ev_begin, void* ev_end);
+
 /* G[r x r] = A[r x K] * A^T.   Replaces VVt = np.dot(V, V.T) (nmf.py:407), UtU = np.dot(U.T, U) (nmf.py:432),
  * and each factor Gram in ntf.py:442-445.  Split-K partials are summed in fp64 in a fixed order. */
 int nnf_gram_f32(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg, void* stream);

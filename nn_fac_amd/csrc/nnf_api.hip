@@ -33,6 +33,7 @@ extern "C" int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_by
     c->ws_bytes = workspace_bytes ? workspace_bytes : (size_t)256 << 20;
     c->ws = nullptr;
     c->hals_epoch = 0u;
+    c->probe[0] = c->probe[1] = nullptr;
     hipError_t e = hipMalloc((void**)&c->ws, c->ws_bytes);
     if (e == hipSuccess) e = hipMemset(c->ws, 0, c->ws_bytes);   // exchange words must not start as look-alike tags
     (void)hipSetDevice(prev);
@@ -52,6 +53,13 @@ extern "C" int nnf_ctx_destroy(nnf_ctx* ctx) {
 }
 
 extern "C" size_t nnf_ctx_workspace_bytes(const nnf_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
+
+extern "C" int nnf_ctx_set_probe(nnf_ctx* ctx, void* ev_begin, void* ev_end) {
+    if (!ctx || ((ev_begin == nullptr) != (ev_end == nullptr))) return NNF_ERR_ARG;
+    ctx->probe[0] = (hipEvent_t)ev_begin;
+    ctx->probe[1] = (hipEvent_t)ev_end;
+    return NNF_OK;
+}
 
 // ---- dot: sum_ij A[i,j]*B[i,j] in fp64, fixed order ------------------------------------------------------
 __global__ __launch_bounds__(256) void nnf_dot_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,

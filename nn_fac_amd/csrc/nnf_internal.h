@@ -10,7 +10,8 @@ struct nnf_ctx {
     int num_cus;
     size_t ws_bytes;
     char* ws;          // device scratch (split-K slabs, partial sums, barrier words); zeroed once at creation
-    unsigned hals_epoch;  // salt of the HALS exchange tags (k_hals_common.h)
+    unsigned hals_epoch;
+    hipEvent_t probe[2];   // optional caller-owned events recorded around the main W^T X kernel (nnf_ctx_set_probe)  // salt of the HALS exchange tags (k_hals_common.h)
 };
 
 #define NNF_CHECK_LAUNCH()                                   \

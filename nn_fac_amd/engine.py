@@ -207,6 +207,14 @@ class Engine:
                                              O.stride(0), self._stream()), "nnf_mu_apply_f32")
         return O
 
+    def set_probe(self, ev_begin=None, ev_end=None):
+        """Measurement hook (bench.py): two torch.cuda.Event(enable_timing=True) that nnf_xty_f32 records right before and
+        right after its main kernel; call with no arguments to remove them.  The events must have been recorded once
+        already (torch creates the underlying hipEvent_t lazily)."""
+        b = C.c_void_p(ev_begin.cuda_event) if ev_begin is not None else None
+        e = C.c_void_p(ev_end.cuda_event) if ev_end is not None else None
+        _lib.check(self.lib.nnf_ctx_set_probe(self.ctx, b, e), "nnf_ctx_set_probe")
+
     # ---- NTD -----------------------------------------------------------------------------------------
     def ttm3(self, T, Ft, mode):
         """T x_mode F^T for a contiguous 3-way tensor and a transposed factor Ft (r x I_mode).

@@ -140,6 +140,27 @@ class _StepBuffers:
         self.block = torch.zeros(24, dtype=torch.float64, device=X.device)
         self.cost = self.block[16:17]
         self.guess_u = _dist.SweepGuess()
+        # the r x r Gram of an update is independent of its cross product (nmf.py:407-408, :432-433): it runs on a side
+        # stream, with its own context (a context's workspace serves one stream at a time), under the streaming kernel
+        self.side_stream = torch.cuda.Stream(device=X.device) if X.is_cuda else None
+        self.side_eng = None
+
+
+
+def _gram_on_side(ws, eng, A, out):
+    """eng.gram(A, out=out) overlapped with whatever the caller launches next on the current stream; returns the event the
+    current stream has to wait on before `out` is used (None: ran inline -- CPU test doubles, buffers without a side stream)."""
+    side = getattr(ws, "side_stream", None)
+    if side is None or not isinstance(eng, _engine.Engine):
+        eng.gram(A, out=out)
+        return None
+    if ws.side_eng is None:
+        ws.side_eng = _engine.Engine(A.device, workspace_bytes=64 << 20)
+    ready = torch.cuda.current_stream(A.device).record_event()
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        ws.side_eng.gram(A, out=out)
+        return side.record_event()
 
 
 def _raise_on_status(host, nstat):
@@ -195,8 +216,10 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             if not deterministic:
                 torch.cuda.synchronize(dev)
                 t0 = time.time()
-            eng.gram(V, out=ws.G)                       # VVt  (nmf.py:407)
+            done = _gram_on_side(ws, eng, V, ws.G)      # VVt  (nmf.py:407)
             eng.xht(X, V, out=ws.VMt)                   # VMt  (nmf.py:408)
+            if done is not None:
+                torch.cuda.current_stream(dev).wait_event(done)
             if not deterministic:
                 torch.cuda.synchronize(dev)
                 timer = time.time() - t0
@@ -218,8 +241,10 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             if not deterministic:
                 torch.cuda.synchronize(dev)
                 t0 = time.time()
-            eng.gram(Ut, out=ws.G2)                     # UtU  (nmf.py:432)
+            done = _gram_on_side(ws, eng, Ut, ws.G2)    # UtU  (nmf.py:432)
             eng.xty(X, Ut, out=ws.UtM)                  # UtM  (nmf.py:433)
+            if done is not None:
+                torch.cuda.current_stream(dev).wait_event(done)
             if sharded:                                 # sum over the row blocks: r x r and r x n over xGMI
                 _dist.allreduce_(ws.G2, group)
                 _dist.allreduce_(ws.UtM, group)

@@ -172,10 +172,15 @@ def _raise_on_status(host, nstat):
             raise err.EngineError("hals grid barrier timed out; result invalid")
 
 
+# inner-solve settings of one_nmf_step (nmf.py:415-419,440-444: maxiter=100, delta=0.01).  bench.py's fixed-work line
+# (delta=0, maxiter=10, so that runs are comparable whatever the data) overrides them through this dict.
+HALS_INNER = {"maxiter": 100, "delta": 0.01}
+
+
 def _hals_call(eng, cross, gram, F, sparsity, normalize, deterministic, timer, status):
     """hals_nnls_acc(..., maxiter=100, atime=timer, alpha=inf|0.5, delta=0.01) of nmf.py:415-419,440-444, in place."""
     from .update_rules.nnls import sweep_budget
-    budget = 100
+    budget = HALS_INNER["maxiter"]
     if not deterministic:
         # wall-clock rule: rho = atime / btime with btime = time of one sweep (nnls.py:190-194)
         probe = F.clone()
@@ -185,8 +190,8 @@ def _hals_call(eng, cross, gram, F, sparsity, normalize, deterministic, timer, s
         torch.cuda.synchronize(F.device)
         btime = max(time.time() - t0, 10e-7)
         rho = timer / btime if timer else 100000
-        budget = max(1, sweep_budget(100, 0.5, rho))
-    return eng.hals_solve(cross, gram, F, budget, delta=0.01, sparsity=sparsity, normalize=normalize, nonzero=False,
+        budget = max(1, sweep_budget(HALS_INNER["maxiter"], 0.5, rho))
+    return eng.hals_solve(cross, gram, F, budget, delta=HALS_INNER["delta"], sparsity=sparsity, normalize=normalize, nonzero=False,
                           status=status)
 
 
@@ -225,8 +230,9 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                 timer = time.time() - t0
             Ut = Ut_in.clone()                          # solve starts from U_in^T (nmf.py:415)
             if sharded:
-                eps, cnt, eps0 = _dist.sharded_hals_solve(eng, ws.VMt, ws.G, Ut, group, ws.guess_u, budget=100,
-                                                          delta=0.01, sparsity=sparsity_coefficients[0])
+                eps, cnt, eps0 = _dist.sharded_hals_solve(eng, ws.VMt, ws.G, Ut, group, ws.guess_u,
+                                                          budget=HALS_INNER["maxiter"], delta=HALS_INNER["delta"],
+                                                          sparsity=sparsity_coefficients[0])
                 ws.block[8 * nstat:8 * nstat + 4] = torch.tensor([eps, cnt, eps0, 0.0], dtype=torch.float64)
             else:
                 _hals_call(eng, ws.VMt, ws.G, Ut, sparsity_coefficients[0], normalize[0], deterministic, timer,

@@ -130,6 +130,13 @@ int nnf_mu_apply_f32(nnf_ctx* ctx, const float* F, int64_t ldf, int r, int64_t c
                      const float* den, int64_t ldden, const double* den_vec_f64, double beta, float* out, int64_t ldo,
                      void* stream);
 
+/* Ranks beyond the fused kernels (64 < r <= 128, beta != 2): the element-wise operands of mu_betadivmin (mu.py:84-97),
+ *   R1 = X .* (UV)^(beta-2)   and, unless beta == 1,   R2 = (UV)^(beta-1)        (both m x n, row stride ldr, caller-owned),
+ * written in one pass over X; the two contractions are then plain nnf_xht_f32 / nnf_xty_f32 calls on R1 / R2 and
+ * nnf_mu_apply_f32 finishes (nn_fac_amd/engine.py composes them when the fused entry points return NNF_ERR_UNSUPPORTED). */
+int nnf_mu_ratio_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                     const float* V, int64_t ldv, int r, double beta, float* R1, float* R2, int64_t ldr, void* stream);
+
 /* beta_divergence(X, U@V, beta) (beta_divergence.py:45-52) fused with the product; *out_f64 = the sum. */
 int nnf_betadiv_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
                     const float* V, int64_t ldv, int r, double beta, double* out_f64, void* stream);

@@ -33,6 +33,7 @@ SIGNATURES = {
     "nnf_mu_right_accum_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _i64, _p, _i64, _p, _p]),
     "nnf_ttm3_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _i32, _i32, _p, _p]),
     "nnf_ntd_core_pg_f32": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f64, _f64, _i32, _f64, _p, _p]),
+    "nnf_mu_ratio_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _p, _i64, _p]),
     "nnf_mu_apply_f32": (_i32, [_p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64, _p, _f64, _p, _i64, _p]),
     "nnf_betadiv_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _p]),
     "nnf_mttkrp3_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p]),

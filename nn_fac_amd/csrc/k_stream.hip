@@ -489,7 +489,8 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
                                                           const float* __restrict__ Ut, int64_t ldu,
                                                           const f32x4* __restrict__ Vf, int r,
                                                           float beta, double* __restrict__ partial,
-                                                          const float* __restrict__ Ub, int64_t ldub, int64_t nbu) {
+                                                          const float* __restrict__ Ub, int64_t ldub, int64_t nbu,
+                                                          float* __restrict__ R1, float* __restrict__ R2, int64_t ldr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KS = (r + 3) >> 2;                               // k-steps of 4
     float* ldsU = reinterpret_cast<float*>(smem);              // [wave 4][rt 2][KS][64]
@@ -615,6 +616,38 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
         // residual of this 32 x 64 block; columns past n hold the next row's data -> masked out
         const int64_t jrem = n - (64 * (int64_t)blk + 4 * jj);
         float loc = 0.f;
+        if constexpr (OP == NNF_RATIO_KL || OP == NNF_RATIO_GEN) {
+            // large-rank MU (r > 64): the element-wise operands are written out, the two contractions follow as plain
+            // X H^T / W^T X launches on them (k_mu.hip).  One float4 per (row piece): columns j0+4jj .. +3.
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int rowl = 16 * rt + 4 * g + reg;
+                    if (rowl >= rows) continue;
+                    f32x4 o1, o2;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const float p = acc[rt][cc][reg], x = xb[rt][reg][cc];
+                        if constexpr (OP == NNF_RATIO_KL) {
+                            o1[cc] = x * __builtin_amdgcn_rcpf(p);
+                            o2[cc] = 0.f;
+                        } else {
+                            const float lp = __builtin_amdgcn_logf(p);
+                            o2[cc] = __builtin_amdgcn_exp2f((beta - 1.f) * lp);
+                            o1[cc] = o2[cc] * __builtin_amdgcn_rcpf(p) * x;
+                        }
+                    }
+                    const int64_t off = (i0w + rowl) * ldr + 64 * (int64_t)blk + 4 * jj;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        if (cc < jrem) {
+                            R1[off + cc] = o1[cc];
+                            if constexpr (OP == NNF_RATIO_GEN) R2[off + cc] = o2[cc];
+                        }
+                    }
+                }
+        } else
         if (rows == 32 && 64 * (int64_t)(blk + 1) <= n) {   // interior block (wave-uniform): no edge masks
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -750,7 +783,7 @@ template <int OP>
 static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
                        const float* V, int64_t ldv, int r, float beta, double scale, double* out_f64, hipStream_t st,
                        const float* Vb = nullptr, int64_t ldvb = 0, int64_t nb = 1, const float* Ub = nullptr,
-                       int64_t ldub = 0, int64_t nbu = 1) {
+                       int64_t ldub = 0, int64_t nbu = 1, float* R1 = nullptr, float* R2 = nullptr, int64_t ldr = 0) {
     const int grid = (int)nnf_cdiv(m, 128);
     // column splits: aim at ~8 workgroups per resident slot, keep at least 4 column blocks per workgroup
     const int nblk_all = (int)nnf_cdiv(n, 64);
@@ -779,11 +812,12 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
     }
     if (x_vec_ok(X, ldx))
         hipLaunchKernelGGL((nnf_cost_kernel<OP, true>), dim3(grid, csplit), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, Vf, r, beta,
-                           partial, Ub, ldub, nbu);
+                           partial, Ub, ldub, nbu, R1, R2, ldr);
     else
         hipLaunchKernelGGL((nnf_cost_kernel<OP, false>), dim3(grid, csplit), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, Vf, r, beta,
-                           partial, Ub, ldub, nbu);
+                           partial, Ub, ldub, nbu, R1, R2, ldr);
     NNF_CHECK_LAUNCH();
+    if (OP == NNF_RATIO_KL || OP == NNF_RATIO_GEN) return NNF_OK;   // nothing to sum
     hipLaunchKernelGGL(nnf_sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)grid * csplit, scale, out_f64);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
@@ -816,6 +850,23 @@ extern "C" int nnf_betadiv_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t 
     if (beta == 1.0) return launch_cost<NNF_COST_KL>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 1.f, 1.0, out_f64, st);
     if (beta == 0.0) return launch_cost<NNF_COST_IS>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 0.f, 1.0, out_f64, st);
     return launch_cost<NNF_COST_GEN>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, (float)beta, 1.0, out_f64, st);
+}
+
+// Element-wise operands of mu_betadivmin (mu.py:84-97) for ranks beyond the fused kernels (64 < r <= 128):
+//   R1 = X .* (U V)^(beta-2)   and, unless beta == 1,   R2 = (U V)^(beta-1),   both m x n with row stride ldr.
+extern "C" int nnf_mu_ratio_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                                const float* V, int64_t ldv, int r, double beta, float* R1, float* R2, int64_t ldr,
+                                void* stream) {
+    double dummy;
+    const int rc = cost_args_ok(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, &dummy);
+    if (rc != NNF_OK) return rc;
+    if (!(beta >= 0.0) || !R1 || ldr < n || (beta != 1.0 && !R2)) return NNF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (beta == 1.0)
+        return launch_cost<NNF_RATIO_KL>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 1.f, 1.0, nullptr, st, nullptr, 0, 1, nullptr, 0, 1,
+                                         R1, R2, ldr);
+    return launch_cost<NNF_RATIO_GEN>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, (float)beta, 1.0, nullptr, st, nullptr, 0, 1, nullptr, 0, 1,
+                                      R1, R2, ldr);
 }
 
 // beta-divergence between a dense 3-way tensor and its CP model [[F0, F1, F2]]: the cost kernel on T seen as an

@@ -158,10 +158,37 @@ class Engine:
         return nd[:int(nsweeps)]
 
     # ---- MU / beta-divergence -----------------------------------------------------------------------
+    MU_FUSED_MAX_RANK = 64   # the fused two-MFMA kernels are built for r <= 64 (beta = 2 has no limit: Gram form)
+
+    def _mu_large_rank(self, X, Ut, V, beta, side):
+        """64 < r <= 128, beta != 2: one pass writes the element-wise operands R1 = X.*(UV)^(beta-2), R2 = (UV)^(beta-1)
+        (m x n device scratch each), then the numerator / denominator are plain X H^T ('left') or W^T X ('right') products.
+        Returns (num, den or None, den_vec or None) like mu_right_accum."""
+        m, n = X.shape
+        r = Ut.shape[0]
+        kl = float(beta) == 1.0
+        R1 = torch.empty((m, n), dtype=torch.float32, device=X.device)
+        R2 = None if kl else torch.empty((m, n), dtype=torch.float32, device=X.device)
+        _lib.check(self.lib.nnf_mu_ratio_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
+                                             V.stride(0), r, float(beta), _ptr(R1), _ptr(R2) if R2 is not None else None,
+                                             R1.stride(0), self._stream()), "nnf_mu_ratio_f32")
+        if side == "left":
+            num = self.xht(R1, V)
+            den = None if kl else self.xht(R2, V)
+            dvec = V.sum(dim=1, dtype=torch.float64) if kl else None          # mu.py:86-87
+        else:
+            num = self.xty(R1, Ut)
+            den = None if kl else self.xty(R2, Ut)
+            dvec = Ut.sum(dim=1, dtype=torch.float64) if kl else None
+        return num, den, dvec
+
     def mu_left(self, X, Ut, V, beta, out=None):
         _chk2d(X, "mu X"), _chk2d(Ut, "mu Ut"), _chk2d(V, "mu V")
         m, n = X.shape
         r = Ut.shape[0]
+        if r > self.MU_FUSED_MAX_RANK and float(beta) != 2.0:
+            num, den, dvec = self._mu_large_rank(X, Ut, V, beta, "left")
+            return self.mu_apply(Ut, num, den, dvec, beta, out=out)
         O = out if out is not None else torch.empty_like(Ut)
         _lib.check(self.lib.nnf_mu_left_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
                                             V.stride(0), r, float(beta), _ptr(O), O.stride(0), self._stream()),
@@ -172,6 +199,9 @@ class Engine:
         _chk2d(X, "mu X"), _chk2d(Ut, "mu Ut"), _chk2d(V, "mu V")
         m, n = X.shape
         r = Ut.shape[0]
+        if r > self.MU_FUSED_MAX_RANK and float(beta) != 2.0:
+            num, den, dvec = self._mu_large_rank(X, Ut, V, beta, "right")
+            return self.mu_apply(V, num, den, dvec, beta, out=out)
         O = out if out is not None else torch.empty_like(V)
         _lib.check(self.lib.nnf_mu_right_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
                                              V.stride(0), r, float(beta), _ptr(O), O.stride(0), self._stream()),
@@ -184,6 +214,8 @@ class Engine:
         _chk2d(X, "mu X"), _chk2d(Ut, "mu Ut"), _chk2d(V, "mu V")
         m, n = X.shape
         r = Ut.shape[0]
+        if r > self.MU_FUSED_MAX_RANK and float(beta) != 2.0:
+            return self._mu_large_rank(X, Ut, V, beta, "right")
         num = torch.empty((r, n), dtype=torch.float32, device=X.device)
         den = torch.empty((r, n), dtype=torch.float32, device=X.device) if float(beta) != 1.0 else None
         dvec = torch.empty(r, dtype=torch.float64, device=X.device) if float(beta) == 1.0 else None

@@ -215,7 +215,8 @@ def test_hals_fixed_sweeps_mode(eng, layout, monkeypatch):
     np.testing.assert_allclose(nd, log, rtol=5e-3)
 
 
-MU_SHAPES = [(200, 100, 10), (73, 25, 9), (1000, 260, 50), (513, 130, 33), (300, 7, 3), (5, 300, 2), (2000, 500, 64)]
+MU_SHAPES = [(200, 100, 10), (73, 25, 9), (1000, 260, 50), (513, 130, 33), (300, 7, 3), (5, 300, 2), (2000, 500, 64),
+             (700, 333, 65), (1500, 400, 100), (300, 200, 128)]     # r > 64: ratio kernel + plain contractions
 
 
 @pytest.mark.parametrize("m,n,r", MU_SHAPES)

@@ -159,9 +159,10 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_right_kerne
         const f32x4* imgA = ldsA + (size_t)(q & 1) * MT * 256;
         const f32x4* imgK = ldsK + (size_t)(q & 1) * MT * 256;
         // next chunk's operand images: global loads now, LDS writes after this chunk's MFMAs (past the end: zeros)
+        // the two images are staged through registers one after the other (A during groups 0-1, K during groups 2-3):
+        // half the staging registers of loading both up front
         f32x4 sa[MT], sk[MT];
         stageA_load<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), a_vec_ok, sa);
-        stageK_load<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), sk);
         const int soff_q = q * 64 * ldx4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -211,8 +212,11 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_right_kerne
                     }
 #pragma unroll
             for (int c = 0; c < 4; ++c) xb[t & 1][c] = nnf_bload4<VEC>(rs, voff, soff_q + (16 * (t + 2) + c) * ldx4);
+            if (t == 1) {
+                stageA_store<MT>(ldsA + (size_t)((q + 1) & 1) * MT * 256, sa);
+                stageK_load<MT>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), sk);
+            }
         }
-        stageA_store<MT>(ldsA + (size_t)((q + 1) & 1) * MT * 256, sa);
         stageK_store<MT>(ldsK + (size_t)((q + 1) & 1) * MT * 256, sk);
         __syncthreads();
     }
@@ -344,9 +348,8 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel
     for (int q = 0; q < nchunk; ++q) {
         const f32x4* imgA = ldsA + (size_t)(q & 1) * MT * 256;
         const f32x4* imgK = ldsK + (size_t)(q & 1) * MT * 256;
-        f32x4 sa[MT], sk[MT];
+        f32x4 sa[MT], sk[MT];   // staged one after the other (see the right kernel)
         stageA_load<MT>(V, ldv, r, n, 64 * (int64_t)(q + 1), a_vec_ok, sa);
-        stageK_load<MT>(V, ldv, r, n, 64 * (int64_t)(q + 1), sk);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             // MFMA #1 (transposed product): accP[nt][reg] = P[i0w+16nt+ii][64q+16t+4g+reg]
@@ -397,8 +400,11 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
                 xb[t & 1][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * q + 64 * (t + 2));
+            if (t == 1) {
+                stageA_store<MT>(ldsA + (size_t)((q + 1) & 1) * MT * 256, sa);
+                stageK_load<MT>(V, ldv, r, n, 64 * (int64_t)(q + 1), sk);
+            }
         }
-        stageA_store<MT>(ldsA + (size_t)((q + 1) & 1) * MT * 256, sa);
         stageK_store<MT>(ldsK + (size_t)((q + 1) & 1) * MT * 256, sk);
         __syncthreads();
     }

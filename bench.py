@@ -101,8 +101,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        # NNF_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
+        backend = os.environ.get("NNF_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
     device = torch.device(f"cuda:{torch.cuda.current_device()}")
@@ -145,6 +151,10 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+
+    sweeps_last = sweeps[-1] if sweeps else None
+    sweeps_mean = float(np.mean([sum(x) for x in sweeps])) if sweeps else None
+    final_cost = cost
 
     # fixed-work variant: 10 sweeps per inner solve whatever the data (delta = 0, maxiter = 10)
     fixed = None
@@ -214,9 +224,9 @@ def main():
                                    f"(configs[1] of BASELINE.json), deterministic (alpha=inf, delta=0.01, maxiter=100)",
                        "rows_total": world * M, "cols": N, "rank": R,
                        "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
-                       "inner_sweeps_per_step_last": sweeps[-1] if sweeps else None,
-                       "inner_sweeps_mean": float(np.mean([sum(s) for s in sweeps])) if sweeps else None,
-                       "final_cost": cost},
+                       "inner_sweeps_per_step_last": sweeps_last,
+                       "inner_sweeps_mean": sweeps_mean,
+                       "final_cost": final_cost},
             "roofline": {"kernel": "nnf_xty_kernel (W^T X, the main kernel of nnf_xty_f32; its fixed-order slab reduction "
                                    "nnf_reduce_slabs_kernel follows and is included in call_ms)", "bound": "mfma",
                          "achieved": achieved, "call_ms": xty_call_ms,

@@ -287,7 +287,7 @@ extern "C" int nnf_hals_sweeps_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, 
     if (snapshots) {
         // snapshots are written by the resident fast path only
         if ((flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) || snap_stride < (int64_t)r * ncols) return NNF_ERR_ARG;
-        if (nnf_cdiv(ncols, 256) > (int64_t)ctx->num_cus) return NNF_ERR_UNSUPPORTED;   // conservative residency bound
+        // (whether the columns fit the resident kernel is decided where the kernel is picked: launch_rp / the quad path)
     }
     return hals_entry<1>(ctx, UtM, ldm, UtU, ldg, V, ldv, r, ncols, nsweeps, 0.0, sparsity, flags, nullptr, nodelta_f64,
                          (hipStream_t)stream, snapshots, snap_stride);

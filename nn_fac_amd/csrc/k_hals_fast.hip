@@ -389,6 +389,7 @@ static int launch_rp(nnf_ctx* ctx, const hals_args& a, int max_blocks_cap, int* 
         *nblocks_out = (int)need;
         hipLaunchKernelGGL((nnf_hals_kernel<RP, true>), dim3((int)need), dim3(256), 0, st, a);
     } else {
+        if (a.snapshots != nullptr) return NNF_ERR_UNSUPPORTED;   // per-sweep snapshots are written by the resident kernel only
         bpc = bpc_of(false);
         if (bpc < 1) return NNF_ERR_LAUNCH;
         cap = (int64_t)bpc * ctx->num_cus;

@@ -267,6 +267,21 @@ def test_mu_dropin_signatures(golden):
         assert gamma_beta(b) == float(g[f"gamma_b{b}"])
 
 
+def test_hals_sweep_snapshots_at_bench_size(eng):
+    """The row-sharded step of bench.py asks for snapshots of a 50 x 100000 factor: 391 workgroups, two per CU."""
+    rng = np.random.RandomState(9)
+    r, n = 50, 100000
+    A = rng.rand(200, r)
+    UtU, UtM, V0 = dev(A.T @ A), dev(A.T @ (A @ rng.rand(r, 2000))).repeat(1, 50), dev(rng.rand(r, 2000)).repeat(1, 50)
+    snaps = torch.empty((3, r, n), dtype=torch.float32, device="cuda")
+    V3 = V0.clone()
+    nd = eng.hals_sweeps(UtM, UtU, V3, 3, snapshots=snaps)
+    assert torch.equal(snaps[2], V3)
+    V2 = V0.clone()
+    nd2 = eng.hals_sweeps(UtM, UtU, V2, 2)
+    assert torch.equal(snaps[1], V2) and torch.equal(nd2, nd[:2])
+
+
 @pytest.mark.parametrize("layout", LAYOUTS)
 def test_hals_sweep_snapshots(eng, layout, monkeypatch):
     """nnf_hals_sweeps_f32 with snapshots: block s must hold V after sweep s+1 (what a shorter run would return)."""

@@ -174,3 +174,18 @@ def test_ntd_argument_errors():
         ntd(T, [2, 2, 2], init="custom", factors_0=[f[0], f[1], None], **kw)
     with pytest.raises(err.CustomNotValidCore):
         ntd(T, [2, 2, 2], init="custom", factors_0=f, core_0=None, **kw)
+
+
+def test_ntd_wall_clock_rule_runs_and_decreases():
+    """deterministic=False keeps the reference's time-dependent sweep budget (alpha = 0.5, ntd.py:399-400): results vary
+    from run to run by design; the cost must still go down and the outputs keep shape and sign."""
+    from nn_fac_amd.ntd import ntd
+    rng = np.random.RandomState(3)
+    shape, ranks = (40, 30, 20), [5, 4, 3]
+    F = [rng.rand(shape[i], ranks[i]) for i in range(3)]
+    T = orc.multi_mode_dot(rng.rand(*ranks), F) + 0.01 * rng.rand(*shape)
+    core, facs, costs, toc = ntd(T, list(ranks), init="random", n_iter_max=6, tol=0, sparsity_coefficients=[None] * 4,
+                                 normalize=[False] * 4, return_costs=True, deterministic=False)
+    assert core.shape == tuple(ranks) and [f.shape for f in facs] == [(shape[i], ranks[i]) for i in range(3)]
+    assert all(np.all(f >= 0) for f in facs) and np.all(core >= 0)
+    assert costs[-1] < costs[0] and len(toc) == len(costs) == 6

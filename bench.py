@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- HALS NMF outer iterations/s on the MI355X engine (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--rule hals|mu] [--no-cpu]
+    python bench.py --gpus N --steps K --warmup W [--rule hals|mu] [--no-cpu] [--no-fixed]
 
 One "step" = one outer NMF iteration (nn_fac.nmf.one_nmf_step semantics: U update, V update, cost) on synthetic dense
 data already resident in HBM.  N = 1: configs[1] of BASELINE.json, 100000 x 2000 rank 50, HALS, fp32, deterministic
@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--rule", default="hals", choices=["hals", "mu"])
     ap.add_argument("--beta", type=float, default=None)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-fixed", action="store_true", help="skip the fixed-work line (profiling runs)")
     args = ap.parse_args()
     beta = args.beta if args.beta is not None else (2 if args.rule == "hals" else 1)
 
@@ -158,7 +159,7 @@ def main():
 
     # fixed-work variant: 10 sweeps per inner solve whatever the data (delta = 0, maxiter = 10)
     fixed = None
-    if args.rule == "hals":
+    if args.rule == "hals" and not args.no_fixed:
         keep = dict(nmf_mod.HALS_INNER)
         nmf_mod.HALS_INNER.update(maxiter=10, delta=0.0)
         try:

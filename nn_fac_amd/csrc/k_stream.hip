@@ -173,8 +173,62 @@ __global__ __launch_bounds__(256) void nnf_reduce_slabs4_kernel(const float* __r
     }
 }
 
+// Few output elements, many slabs (MTTKRP: 15000 elements x 256 slabs took 64 us with one thread per element): P threads
+// per element, each summing every P-th... a contiguous range of slabs, the P partials combined in part order through LDS.
+// Fixed order -> bitwise reproducible.  Threads with the same part are consecutive in the element index (coalesced).
+template <int P>
+__global__ __launch_bounds__(256) void nnf_reduce_slabs_par_kernel(const float* __restrict__ slabs, int nslab,
+                                                                   int64_t slab_stride, int rows, int64_t cols, int64_t lds,
+                                                                   float* __restrict__ out, int64_t ldo) {
+    constexpr int EPB = 256 / P;                 // elements per workgroup
+    __shared__ double part_sum[P][EPB];
+    const int el = threadIdx.x % EPB, part = threadIdx.x / EPB;
+    const int64_t total = (int64_t)rows * cols;
+    const int per = (nslab + P - 1) / P;
+    const int k0 = part * per, k1 = (k0 + per < nslab) ? (k0 + per) : nslab;
+    for (int64_t e0 = (int64_t)blockIdx.x * EPB; e0 < total; e0 += (int64_t)gridDim.x * EPB) {
+        const int64_t e = e0 + el;
+        double s = 0.0;
+        if (e < total) {
+            const int64_t row = e / cols, col = e - row * cols;
+            const float* p = slabs + row * lds + col;
+            for (int k = k0; k < k1; ++k) s += (double)p[(int64_t)k * slab_stride];
+        }
+        part_sum[part][el] = s;
+        __syncthreads();
+        if (part == 0 && e < total) {
+            double t = part_sum[0][el];
+#pragma unroll
+            for (int q = 1; q < P; ++q) t += part_sum[q][el];
+            const int64_t row = e / cols, col = e - row * cols;
+            out[row * ldo + col] = (float)t;
+        }
+        __syncthreads();
+    }
+}
+
 int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, int rows, int64_t cols, int64_t lds,
                             float* out, int64_t ldo, hipStream_t st) {
+    {   // enough threads to fill the chip: P parts per element when the output is small
+        const int64_t total = (int64_t)rows * cols;
+        int P = 1;
+        while (P < 16 && total * P < ((int64_t)1 << 19) && 2 * P <= nslab) P *= 2;
+        if (P > 1) {
+            const int epb = 256 / P;
+            int64_t grid = (total + epb - 1) / epb;
+            if (grid > 4096) grid = 4096;
+#define NNF_RSP(PP)                                                                                                          \
+    hipLaunchKernelGGL(nnf_reduce_slabs_par_kernel<PP>, dim3((int)grid), dim3(256), 0, st, slabs, nslab, slab_stride, rows, cols, \
+                       lds, out, ldo)
+            if (P == 2) NNF_RSP(2);
+            else if (P == 4) NNF_RSP(4);
+            else if (P == 8) NNF_RSP(8);
+            else NNF_RSP(16);
+#undef NNF_RSP
+            NNF_CHECK_LAUNCH();
+            return NNF_OK;
+        }
+    }
     // (four columns per thread only when that still leaves enough threads to fill the chip: 20 vs 16 us at r x n = 1e5)
     if ((lds & 3) == 0 && (slab_stride & 3) == 0 && (((uintptr_t)slabs) & 15) == 0 && (int64_t)rows * cols >= ((int64_t)1 << 21)) {
         const int64_t total4 = (int64_t)rows * ((cols + 3) >> 2);

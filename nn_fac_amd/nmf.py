@@ -142,8 +142,7 @@ class _StepBuffers:
         self.guess_u = _dist.SweepGuess()
         # the r x r Gram of an update is independent of its cross product (nmf.py:407-408, :432-433): it runs on a side
         # stream, with its own context (a context's workspace serves one stream at a time), under the streaming kernel
-        self.side_stream = torch.cuda.Stream(device=X.device) if X.is_cuda else None
-        self.side_eng = None
+        self.side_eng, self.side_stream = _engine.get_side_engine(X.device) if X.is_cuda else (None, None)
 
 
 
@@ -154,8 +153,6 @@ def _gram_on_side(ws, eng, A, out):
     if side is None or not isinstance(eng, _engine.Engine):
         eng.gram(A, out=out)
         return None
-    if ws.side_eng is None:
-        ws.side_eng = _engine.Engine(A.device, workspace_bytes=64 << 20)
     ready = torch.cuda.current_stream(A.device).record_event()
     with torch.cuda.stream(side):
         side.wait_event(ready)

@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_rows_kernel
                     for (int cc = 0; cc < 4; ++cc) acc[mt][cc] = MFMA16(af[mt][c], xb[t][c][cc], acc[mt][cc]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, soff_next + (16 * t + c) * ldx4);
+            __builtin_amdgcn_sched_barrier(0);   // keep this group's loads inside the group (see nnf_xty_kernel)
         }
         stageA_store<MT>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
         __syncthreads();

@@ -30,7 +30,7 @@
 // is otherwise idle here (fp32 MFMA and fp32 VALU have the same peak on gfx950, so padding r=50 to 64 would burn 22 % of
 // the MFMA time on zeros).  The leftover rows' operand is the (MT+1)-th tile of the same LDS image, read as a broadcast.
 template <int MT, int REM, bool VEC>
-__global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xty_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+__global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 3 : 1)) void nnf_xty_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                          const float* __restrict__ Ut, int64_t ldu, int r,
                                                          float* __restrict__ slabs, int64_t ldp, int ncb, int nsplit,
                                                          int64_t rows_per_split, int a_vec_ok) {
@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xty_ke
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) acc[mt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xb[4][4];  // [k-group t][k-step c]: row i_begin + 64q + 16t + 4g + c, columns jl..jl+3
+    // X prefetch ring: two 16-row groups (8 KB per wave) ahead of the MFMAs; with three workgroups per CU and the
+    // per-group scheduling fence below that is enough in flight, and it keeps the kernel under 168 VGPRs without spills
+    f32x4 xb[2][4];  // [group parity][k-step c]: row i_begin + 16*gi + 4g + c, columns jl..jl+3
     f32x4 areg[MTA];
     f32x4 ev[REM > 0 ? REM : 1];   // leftover rows: partial sums over this lane's rows, columns jl..jl+3
 #pragma unroll
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xty_ke
 
     stageA_load<MTA>(Ut, ldu, r, i_end, i_begin, a_vec_ok, areg);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, (16 * t + c) * ldx4);
     stageA_store<MTA>(ldsA[0], areg);
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xty_ke
         const f32x4* img = ldsA[q & 1];
         // next chunk's A tile: global loads now, LDS write after the MFMAs (rows past i_end come back as zeros)
         stageA_load<MTA>(Ut, ldu, r, i_end, i_begin + 64 * (int64_t)(q + 1), a_vec_ok, areg);
-        const int soff_next = (q + 1) * 64 * ldx4;
+        const int soff_q = q * 64 * ldx4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f32x4 af[MT];
@@ -86,18 +88,21 @@ __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xty_ke
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) acc[mt][cc] = MFMA16(af[mt][c], xb[t][c][cc], acc[mt][cc]);
+                    for (int cc = 0; cc < 4; ++cc) acc[mt][cc] = MFMA16(af[mt][c], xb[t & 1][c][cc], acc[mt][cc]);
             if constexpr (REM > 0) {
 #pragma unroll
                 for (int rr = 0; rr < REM; ++rr) {
                     const f32x4 uv = img[(MT * 4 + t) * 64 + 16 * g + rr];   // Ut[16MT+rr][row 16t+4g+c], c = 0..3
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) ev[rr] = __builtin_elementwise_fma(f32x4{uv[c], uv[c], uv[c], uv[c]}, xb[t][c], ev[rr]);
+                    for (int c = 0; c < 4; ++c) ev[rr] = __builtin_elementwise_fma(f32x4{uv[c], uv[c], uv[c], uv[c]}, xb[t & 1][c], ev[rr]);
                 }
             }
-            // refill the registers just consumed with the same rows of the next chunk (past the end: zeros)
+            // refill the registers just consumed with the rows two groups ahead (past the end: zeros)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, soff_next + (16 * t + c) * ldx4);
+            for (int c = 0; c < 4; ++c) xb[t & 1][c] = nnf_bload4<VEC>(rs, voff, soff_q + (16 * (t + 2) + c) * ldx4);
+            // keep every group's loads and leftover-row FMAs inside the group: without the fence hipcc moves all 16 refill
+            // loads and the whole VALU part to the end of the chunk, where nothing is left to hide them behind
+            __builtin_amdgcn_sched_barrier(0);
         }
         stageA_store<MTA>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
         __syncthreads();
@@ -254,7 +259,7 @@ static int launch_xty(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t 
                       int64_t ldu, float* out, int64_t ldo, hipStream_t st) {
     const int ncb = (int)nnf_cdiv(n, 256);
     const int64_t ldp = nnf_rup(n, 4);
-    int64_t target = 2 * (int64_t)ctx->num_cus / ncb;
+    int64_t target = (MT + (REM > 0) <= 4 ? 3 : 1) * (int64_t)ctx->num_cus / ncb;   // resident workgroups per CU
     if (target < 1) target = 1;
     int64_t nsplit = target;
     const int64_t max_split = nnf_cdiv(m, 64);

@@ -125,27 +125,32 @@ def main():
     ws = nmf_mod._StepBuffers(X, R)
     sweeps = []
 
-    def step():
+    def run(k):
+        """k outer iterations through the product's own loop (nn_fac_amd.nmf.run_steps, the `for iteration` loop of
+        compute_nmf: the cost + status block of every iteration is read back and handed to the stopping test's hook,
+        here a recorder that never stops)."""
         nonlocal Ut, V
-        Ut, V, nstat = nmf_mod._one_nmf_step_dev(eng, ws, X, R, Ut, V, args.rule, beta, [None, None], [],
-                                                 [False, False], True, group=group)
-        host = ws.block.cpu()                   # cost + status: the per-iteration host sync of compute_nmf
-        sweeps.append([int(host[8 * i + 1]) - 1 for i in range(nstat)])
-        return float(host[16])
+        last = [None]
+
+        def retired(it, cost, sw):
+            sweeps.append(sw)
+            last[0] = cost
+            return False
+
+        Ut, V = nmf_mod.run_steps(eng, ws, X, R, Ut, V, k, args.rule, beta, [None, None], [], [False, False], True,
+                                  retired, group=group)
+        return last[0]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     sweeps.clear()
     barrier()
     t0 = time.perf_counter()
-    cost = None
-    for _ in range(args.steps):
-        cost = step()
+    cost = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -163,12 +168,10 @@ def main():
         keep = dict(nmf_mod.HALS_INNER)
         nmf_mod.HALS_INNER.update(maxiter=10, delta=0.0)
         try:
-            for _ in range(2):
-                step()
+            run(2)
             barrier()
             t1 = time.perf_counter()
-            for _ in range(10):
-                step()
+            run(10)
             barrier()
             fdt = time.perf_counter() - t1
             if world > 1:

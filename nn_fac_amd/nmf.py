@@ -76,14 +76,11 @@ def compute_nmf(data, rank, U_in, V_in, n_iter_max=100, tol=1e-8,
         normalize = [False, False]
 
     ws = _StepBuffers(X, Ut.shape[0])
-    for iteration in range(n_iter_max):
-        Ut, V, nstat = _one_nmf_step_dev(eng, ws, X, rank, Ut, V, update_rule, beta, sparsity_coefficients,
-                                         fixed_modes, normalize, deterministic)
-        host = ws.block.cpu()   # the only host synchronisation of the iteration: cost + HALS status words
-        cost = float(host[16])
-        _raise_on_status(host, nstat)
+
+    def retired(iteration, cost, sweeps):
+        """Host side of one finished iteration (nmf.py:315-324); True = the stopping test fired."""
         if sweep_log is not None:
-            sweep_log.extend(int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(nstat))
+            sweep_log.extend(sweeps)
         toc.append(time.time() - tic)
         cost_fct_vals.append(cost)
 
@@ -101,7 +98,11 @@ def compute_nmf(data, rank, U_in, V_in, n_iter_max=100, tol=1e-8,
         if iteration > 0 and abs(cost_fct_vals[-2] - cost_fct_vals[-1]) < tol:
             if verbose:
                 print('Converged in {} iterations.'.format(iteration))
-            break
+            return True
+        return False
+
+    Ut, V = run_steps(eng, ws, X, rank, Ut, V, n_iter_max, update_rule, beta, sparsity_coefficients, fixed_modes,
+                      normalize, deterministic, retired)
 
     U_out, V_out = like_input(Ut.t(), U_in), like_input(V, V_in)
     if return_costs:
@@ -126,8 +127,16 @@ def one_nmf_step(data, rank, U_in, V_in, norm_data, update_rule, beta,
 
 
 # ------------------------------------------------------------------------------------------------------------
+PIPELINE_DEPTH = 1   # outer iterations enqueued ahead of the one whose cost the host is looking at
+
+
 class _StepBuffers:
     """Device scratch reused across iterations (cross terms, Grams, status words)."""
+
+    def select(self, slot):
+        self.slot = slot
+        self.block = self.blocks[slot]
+        self.cost = self.block[16:17]
 
     def __init__(self, X, r):
         m, n = X.shape
@@ -136,9 +145,14 @@ class _StepBuffers:
         self.UtM = torch.empty((r, n), **f32)
         self.G = torch.empty((r, r), **f32)
         self.G2 = torch.empty((r, r), **f32)
-        # one block read back per iteration: HALS status of the first / second solve at [0:8] / [8:16], cost at [16]
-        self.block = torch.zeros(24, dtype=torch.float64, device=X.device)
-        self.cost = self.block[16:17]
+        # one block read back per iteration: HALS status of the first / second solve at [0:8] / [8:16], cost at [16].
+        # A ring of PIPELINE_DEPTH + 1 blocks with pinned host mirrors: run_steps enqueues iteration i+1 before it reads
+        # the block of iteration i, so the device never waits for the host between iterations.
+        self.blocks = torch.zeros((PIPELINE_DEPTH + 1, 24), dtype=torch.float64, device=X.device)
+        self.host = torch.zeros((PIPELINE_DEPTH + 1, 24), dtype=torch.float64)
+        if X.is_cuda:
+            self.host = self.host.pin_memory()
+        self.select(0)
         self.guess_u = _dist.SweepGuess()
         # the r x r Gram of an update is independent of its cross product (nmf.py:407-408, :432-433): it runs on a side
         # stream, with its own context (a context's workspace serves one stream at a time), under the streaming kernel
@@ -167,6 +181,47 @@ def _raise_on_status(host, nstat):
             raise err.ZeroColumnWhenUnautorized("A column of U is zero with nonzero condition")
         if code != 0:
             raise err.EngineError("hals grid barrier timed out; result invalid")
+
+
+def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
+              deterministic, retired, group=None):
+    """The `for iteration` loop of compute_nmf (nmf.py:298-324) with the device running ahead of the host: iteration
+    i+1 is enqueued BEFORE the host reads the cost of iteration i (its 24-double block arrives through an asynchronous
+    copy into pinned memory + an event), so the per-iteration round trip -- D2H copy, stopping test in Python, ~15 launches
+    -- no longer leaves the GPU idle.  `retired(iteration, cost, sweeps)` is called once per iteration, in order, and
+    returns True when the loop has to stop (nmf.py:320-324); the factors returned are those of the iteration that
+    stopped it -- each step writes fresh factor tensors, so the speculative iteration in flight is simply dropped.
+    Paths that synchronise inside a step anyway (wall-clock rule, row-sharded solve) run through the same code."""
+    pending = []          # (iteration, slot, Ut, V, nstat, event)
+    result = (Ut, V)
+    stop = False
+
+    def retire():
+        nonlocal result, stop
+        it, slot, Ut_i, V_i, nstat, ev = pending.pop(0)
+        if ev is not None:
+            ev.synchronize()
+        host = ws.host[slot]
+        _raise_on_status(host, nstat)
+        result = (Ut_i, V_i)
+        stop = bool(retired(it, float(host[16]), [int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(nstat)]))
+
+    for iteration in range(n_iter):
+        ws.select(iteration % (PIPELINE_DEPTH + 1))
+        Ut, V, nstat = _one_nmf_step_dev(eng, ws, X, rank, Ut, V, update_rule, beta, sparsity_coefficients,
+                                         fixed_modes, normalize, deterministic, group=group)
+        ws.host[ws.slot].copy_(ws.block, non_blocking=True)
+        ev = torch.cuda.current_stream(X.device).record_event() if X.is_cuda else None
+        pending.append((iteration, ws.slot, Ut, V, nstat, ev))
+        if len(pending) > PIPELINE_DEPTH:
+            retire()
+            if stop:
+                break
+    while pending and not stop:
+        retire()
+    if pending and X.is_cuda:         # a dropped speculative iteration still uses the shared scratch: let it drain
+        torch.cuda.current_stream(X.device).synchronize()
+    return result
 
 
 # inner-solve settings of one_nmf_step (nmf.py:415-419,440-444: maxiter=100, delta=0.01).  bench.py's fixed-work line

@@ -138,13 +138,15 @@ class _StepBuffers:
         self.block = self.blocks[slot]
         self.cost = self.block[16:17]
 
-    def __init__(self, X, r):
+    def __init__(self, X, r, dtype=torch.float32):
         m, n = X.shape
-        f32 = dict(dtype=torch.float32, device=X.device)
+        f32 = dict(dtype=dtype, device=X.device)     # (float64 only in the CPU tests' engine double)
         self.VMt = torch.empty((r, m), **f32)
-        self.UtM = torch.empty((r, n), **f32)
+        # UtM (r x n) and UtU (r x r) share one allocation: row-sharded runs sum both with ONE all-reduce
+        self.v_terms = torch.empty(r * n + r * r, **f32)
+        self.UtM = self.v_terms[:r * n].view(r, n)
+        self.G2 = self.v_terms[r * n:].view(r, r)
         self.G = torch.empty((r, r), **f32)
-        self.G2 = torch.empty((r, r), **f32)
         # one block read back per iteration: HALS status of the first / second solve at [0:8] / [8:16], cost at [16].
         # A ring of PIPELINE_DEPTH + 1 blocks with pinned host mirrors: run_steps enqueues iteration i+1 before it reads
         # the block of iteration i, so the device never waits for the host between iterations.
@@ -303,9 +305,12 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             eng.xty(X, Ut, out=ws.UtM)                  # UtM  (nmf.py:433)
             if done is not None:
                 torch.cuda.current_stream(dev).wait_event(done)
-            if sharded:                                 # sum over the row blocks: r x r and r x n over xGMI
-                _dist.allreduce_(ws.G2, group)
-                _dist.allreduce_(ws.UtM, group)
+            if sharded:                                 # sum over the row blocks: r x n and r x r over xGMI, one collective
+                if getattr(ws, "v_terms", None) is not None:
+                    _dist.allreduce_(ws.v_terms, group)
+                else:
+                    _dist.allreduce_(ws.G2, group)
+                    _dist.allreduce_(ws.UtM, group)
             if not deterministic:
                 torch.cuda.synchronize(dev)
                 timer = time.time() - t0

@@ -80,18 +80,6 @@ class OracleEngine:
         return c if out is None else out.copy_(c)
 
 
-class _Bufs:
-    def __init__(self, X, r):
-        from nn_fac_amd import dist as nd
-        m, n = X.shape
-        kw = dict(dtype=torch.float64)
-        self.VMt, self.UtM = torch.empty((r, m), **kw), torch.empty((r, n), **kw)
-        self.G, self.G2 = torch.empty((r, r), **kw), torch.empty((r, r), **kw)
-        self.block = torch.zeros(24, **kw)
-        self.cost = self.block[16:17]
-        self.guess_u = nd.SweepGuess(first=3, max_chunk=5)   # small on purpose: exercises continue, exact stop, overshoot
-
-
 def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=nranks)
@@ -102,13 +90,18 @@ def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2
         Xl = torch.from_numpy(X[lo:hi].copy())
         Ut = torch.from_numpy(U0[lo:hi].T.copy())
         V = torch.from_numpy(V0.copy())
-        eng, ws = OracleEngine(), _Bufs(Xl, r)
+        # the product's own buffers and outer loop (status ring, fused all-reduce of the V-side terms), engine double below
+        eng, ws = OracleEngine(), nmf_mod._StepBuffers(Xl, r, dtype=torch.float64)
+        ws.guess_u = nd.SweepGuess(first=3, max_chunk=5)   # small on purpose: exercises continue, exact stop, overshoot
         costs, sweeps = [], []
-        for _ in range(iters):
-            Ut, V, nstat = nmf_mod._one_nmf_step_dev(eng, ws, Xl, r, Ut, V, rule, beta, sparsity, [], [False, False],
-                                                     True, group=dist.group.WORLD)
-            costs.append(float(ws.block[16]))
-            sweeps += [int(ws.block[8 * i + 1]) - 1 for i in range(nstat)]
+
+        def retired(it, cost, sw):
+            costs.append(cost)
+            sweeps.extend(sw)
+            return False
+
+        Ut, V = nmf_mod.run_steps(eng, ws, Xl, r, Ut, V, iters, rule, beta, sparsity, [], [False, False], True, retired,
+                                  group=dist.group.WORLD)
         q.put((rank, lo, hi, Ut.numpy().T.copy(), V.numpy().copy(), costs, sweeps))
     finally:
         dist.destroy_process_group()

@@ -155,3 +155,25 @@ def test_mid_size_mu_kl(golden, built_lib):
                                  deterministic=True)
     assert rel(U[::16], g["U_mu_b1"]) < 5e-5 and rel(V[:, ::4], g["V_mu_b1"]) < 5e-5
     np.testing.assert_allclose(costs, g["costs_mu_b1"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 1)])
+def test_early_stop_drops_the_speculative_iteration(golden, built_lib, rule, beta):
+    """compute_nmf keeps one iteration in flight ahead of the stopping test (run_steps): when the test of nmf.py:320-324
+    fires at iteration k, the factors returned must be those of iteration k, bit for bit, not of the iteration that was
+    already enqueued behind it."""
+    from nn_fac_amd.nmf import compute_nmf
+    g = golden("g4_nmf_configA.npz")
+    X, U0, V0 = g["X"].astype(np.float32), g["U0"].astype(np.float32), g["V0"].astype(np.float32)
+    _, _, costs, _ = compute_nmf(X, 10, U0, V0, n_iter_max=12, tol=0, update_rule=rule, beta=beta, return_costs=True,
+                                 deterministic=True)
+    k = 5
+    tol = 0.5 * (abs(costs[k - 1] - costs[k]) + abs(costs[k] - costs[k + 1]))   # fires first at iteration k+1 ... or earlier
+    first = next(i for i in range(1, len(costs)) if abs(costs[i - 1] - costs[i]) < tol)
+    Us, Vs, cs, toc = compute_nmf(X, 10, U0, V0, n_iter_max=12, tol=tol, update_rule=rule, beta=beta, return_costs=True,
+                                  deterministic=True)
+    assert len(cs) == first + 1 == len(toc) and first < 11
+    Uk, Vk, ck, _ = compute_nmf(X, 10, U0, V0, n_iter_max=first + 1, tol=0, update_rule=rule, beta=beta,
+                                return_costs=True, deterministic=True)
+    assert cs == ck[:first + 1] == costs[:first + 1]
+    assert np.array_equal(Us, Uk) and np.array_equal(Vs, Vk)

@@ -294,41 +294,41 @@ static int launch_xty(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t 
 //   workgroup = 256 rows of X (wave w: rows 64w..64w+63 as four 16-row N tiles), k runs over the n columns.
 //   B operand lane (ii = l&15, g = l>>4) of tile nt, k-group t: float4 X[i0w+16nt+ii][64q+16t+4g .. +3].
 // =========================================================================================================
-template <int MT, int REM, bool VEC>
-__global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xht_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
-                                                         const float* __restrict__ V, int64_t ldv, int r,
-                                                         float* __restrict__ out, int64_t ldo, int a_vec_ok) {
+// NT = 16-row tiles per wave (a workgroup covers 64*NT rows starting at row0).
+template <int MT, int REM, bool VEC, int NT>
+__device__ __forceinline__ void nnf_xht_body(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+                                             const float* __restrict__ V, int64_t ldv, int r, float* __restrict__ out,
+                                             int64_t ldo, int a_vec_ok, int64_t row0, f32x4 (*ldsA)[(MT + (REM > 0 ? 1 : 0)) * 256]) {
     constexpr int MTA = MT + (REM > 0 ? 1 : 0);
-    __shared__ f32x4 ldsA[2][MTA * 256];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ii = lane & 15, g = lane >> 4;
-    const int64_t i0w = (int64_t)blockIdx.x * 256 + 64 * w;
+    const int64_t i0w = row0 + 16 * NT * w;
     int64_t rows = m - i0w;
-    if (rows > 64) rows = 64;
+    if (rows > 16 * NT) rows = 16 * NT;
     const uint32_t bytes = rows > 0 ? (uint32_t)(((rows - 1) * ldx + n) * 4) : 0u;
     const rsrc_t rs = nnf_make_rsrc(X + (rows > 0 ? i0w : 0) * ldx, bytes);
     const int voff = (int)(((int64_t)ii * ldx + 4 * g) * 4);
     const int ldx4 = (int)(ldx * 4);
     const int nchunk = (int)((n + 63) >> 6);
 
-    f32x4 acc[MT][4];
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 xb[4][4];  // [k-group t][row tile nt]
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 xb[4][NT];  // [k-group t][row tile nt]
     f32x4 areg[MTA];
-    float ev[REM > 0 ? REM : 1][4];   // leftover rank rows x the four 16-row tiles: partial over this lane's k
+    float ev[REM > 0 ? REM : 1][NT];   // leftover rank rows x the 16-row tiles: partial over this lane's k
 #pragma unroll
     for (int rr = 0; rr < (REM > 0 ? REM : 1); ++rr)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) ev[rr][nt] = 0.f;
+        for (int nt = 0; nt < NT; ++nt) ev[rr][nt] = 0.f;
 
     stageA_load<MTA>(V, ldv, r, n, 0, a_vec_ok, areg);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 64 * t);
+        for (int nt = 0; nt < NT; ++nt) xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 64 * t);
     stageA_store<MTA>(ldsA[0], areg);
     __syncthreads();
 
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xht_ke
             const int64_t nrem = n - (64 * (int64_t)q + 16 * t + 4 * g);
             if (nrem < 4) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (c >= nrem) xb[t][nt][c] = 0.f;
@@ -354,13 +354,13 @@ __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xht_ke
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(af[mt][c], xb[t][nt][c], acc[mt][nt]);
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(af[mt][c], xb[t][nt][c], acc[mt][nt]);
             if constexpr (REM > 0) {
 #pragma unroll
                 for (int rr = 0; rr < REM; ++rr) {
                     const f32x4 uv = img[(MT * 4 + t) * 64 + 16 * g + rr];   // V[16MT+rr][64q+16t+4g+c], c = 0..3
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
+                    for (int nt = 0; nt < NT; ++nt) {
                         float e = ev[rr][nt];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) e = fmaf(uv[c], xb[t][nt][c], e);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xht_ke
                 }
             }
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
                 xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * (q + 1) + 64 * t);
         }
         stageA_store<MTA>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xht_ke
 
     // epilogue: tile (mt, nt): out[16mt + 4g + reg][i0w + 16nt + ii]
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         const int64_t i = i0w + 16 * nt + ii;
         if (i < m) {
 #pragma unroll
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xht_ke
 #pragma unroll
         for (int rr = 0; rr < REM; ++rr)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 float x = ev[rr][nt];
                 x += __shfl_xor(x, 16, 64);
                 x += __shfl_xor(x, 32, 64);
@@ -405,14 +405,51 @@ __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xht_ke
     }
 }
 
+// A resident wave is the unit the MFMA pipe is shared in, and one round of workgroups covers B's 100000 rows: with
+// 64 rows per wave everywhere that is 1563 waves on 1024 SIMDs -- the SIMDs holding two of them decide the time
+// (8 row tiles against 6.1 on average).  The first n_hi workgroups take NTH tiles per wave, the others NTH-1, chosen
+// on the host so that one full round of resident workgroups covers the matrix (7 tiles on the busiest SIMD).
+template <int MT, int REM, bool VEC, int NTH>
+__global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xht_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+                                                         const float* __restrict__ V, int64_t ldv, int r,
+                                                         float* __restrict__ out, int64_t ldo, int a_vec_ok, int n_hi) {
+    constexpr int MTA = MT + (REM > 0 ? 1 : 0);
+    __shared__ f32x4 ldsA[2][MTA * 256];
+    const int b = (int)blockIdx.x;
+    if (b < n_hi)
+        nnf_xht_body<MT, REM, VEC, NTH>(X, m, n, ldx, V, ldv, r, out, ldo, a_vec_ok, (int64_t)b * (64 * NTH), ldsA);
+    else
+        nnf_xht_body<MT, REM, VEC, NTH - 1>(X, m, n, ldx, V, ldv, r, out, ldo, a_vec_ok,
+                                            (int64_t)n_hi * (64 * NTH) + (int64_t)(b - n_hi) * (64 * (NTH - 1)), ldsA);
+}
+
 template <int MT, int REM, bool VEC>
-static int launch_xht(nnf_ctx*, nnf_ws_cursor&, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r, int64_t ldv,
+static int launch_xht(nnf_ctx* ctx, nnf_ws_cursor&, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r, int64_t ldv,
                       float* out, int64_t ldo, hipStream_t st) {
     if (64 * ldx * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
     const int a_vec_ok = ((((uintptr_t)V) & 15) == 0 && (ldv & 3) == 0) ? 1 : 0;
-    const int grid = (int)nnf_cdiv(m, 256);
-    hipLaunchKernelGGL((nnf_xht_kernel<MT, REM, VEC>), dim3(grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
-                       a_vec_ok);
+    const int64_t slots = (int64_t)(MT + (REM > 0) <= 4 ? 2 : 1) * ctx->num_cus;   // resident workgroups
+    const int64_t T = nnf_cdiv(m, 16), waves = 4 * slots;
+    int nth = 4;
+    int64_t n_hi, grid;
+    if (T > 4 * waves) {            // several rounds: 256-row workgroups
+        n_hi = grid = nnf_cdiv(m, 256);
+    } else if (T > 2 * waves) {     // one round: (4,3) or (3,2) tiles per wave
+        nth = T > 3 * waves ? 4 : 3;
+        n_hi = nnf_cdiv(T - 4 * (nth - 1) * slots, 4);
+        grid = slots;
+    } else {                        // small: 128-row workgroups
+        nth = 3;
+        n_hi = 0;
+        grid = nnf_cdiv(m, 128);
+    }
+    if (n_hi * 64 * nth + (grid - n_hi) * 64 * (nth - 1) < m) return NNF_ERR_UNSUPPORTED;   // (cannot happen: the split covers m by construction)
+    if (nth == 4)
+        hipLaunchKernelGGL((nnf_xht_kernel<MT, REM, VEC, 4>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
+                           a_vec_ok, (int)n_hi);
+    else
+        hipLaunchKernelGGL((nnf_xht_kernel<MT, REM, VEC, 3>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
+                           a_vec_ok, (int)n_hi);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
 }

@@ -49,6 +49,20 @@ def test_gram_xty_xht_frob(eng, m, n, r):
     assert abs(got - want) <= 1e-5 * want
 
 
+@pytest.mark.parametrize("m", [70001, 98304, 100000, 131072, 131075, 300007])
+@pytest.mark.parametrize("n,r", [(70, 50), (129, 64)])
+def test_xht_row_tilings(eng, m, n, r):
+    """X H^T picks its rows-per-workgroup from m (one balanced round of (3,2)- or (4,3)-tile workgroups, or several
+    rounds of 256-row workgroups): every branch, with ragged ends, against an fp64 product on the device."""
+    g = torch.Generator(device="cuda").manual_seed(m + n)
+    X = torch.rand(m, n, device="cuda", generator=g)
+    V = torch.rand(r, n, device="cuda", generator=g)
+    want = V.double() @ X.double().t()
+    got = eng.xht(X, V).double()
+    assert float((got - want).norm() / want.norm()) < 1e-5
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-5      # no row block missed or doubled
+
+
 def test_views_with_leading_dimension(eng):
     """Row-sharded / padded storage: ld > cols, base pointer not 16-byte aligned."""
     rng = np.random.RandomState(5)

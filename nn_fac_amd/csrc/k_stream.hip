@@ -580,13 +580,14 @@ __global__ __launch_bounds__(256) void nnf_cost_prepv_kernel(const float* __rest
     }
 }
 
-template <int OP, bool VEC>
+template <int OP, bool VEC, int NV>   // NV = float4 pieces of a V image per thread: 4 up to r = 64, 8 up to r = 128
 __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                           const float* __restrict__ Ut, int64_t ldu,
                                                           const f32x4* __restrict__ Vf, int r,
                                                           float beta, double* __restrict__ partial,
                                                           const float* __restrict__ Ub, int64_t ldub, int64_t nbu,
-                                                          float* __restrict__ R1, float* __restrict__ R2, int64_t ldr) {
+                                                          float* __restrict__ R1, float* __restrict__ R2, int64_t ldr,
+                                                          int u_vec_ok) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KS = (r + 3) >> 2;                               // k-steps of 4
     float* ldsU = reinterpret_cast<float*>(smem);              // [wave 4][rt 2][KS][64]
@@ -609,6 +610,36 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
     const int nblk = (blk0 + per < nblk_all) ? (blk0 + per) : nblk_all;
 
     // U fragments of this wave's 32 rows: ldsU[w][rt][s][lane] = Ut[4s + (lane>>4)][i0w + 16rt + (lane&15)]
+    if (Ub == nullptr && u_vec_ok && rows == 32) {
+        // four consecutive rows i of one rank row k are four consecutive floats of the image: 16-byte loads straight
+        // into 16-byte LDS stores, all of a wave's loads in flight together (the element-wise loop below costs a
+        // division and a dependent round trip per element -- a prologue as long as the MFMA work of a short column range)
+        const int nq = 8 * r;                      // float4 pieces: (k, j) -> Ut[k][i0w + 4j .. +3], j = 0..7
+        float* dstw = ldsU + (size_t)(w * 2) * KS * 64;
+        for (int e0 = 0; e0 < nq; e0 += 4 * 64) {
+            f32x4 piece[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 64 * u + lane;
+                piece[u] = (e < nq) ? *reinterpret_cast<const f32x4*>(Ut + (int64_t)(e >> 3) * ldu + i0w + 4 * (e & 7))
+                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 64 * u + lane;
+                const int k = e >> 3, j = e & 7;
+                if (e < nq)
+                    *reinterpret_cast<f32x4*>(dstw + ((j >> 2) * KS + (k >> 2)) * 64 + (k & 3) * 16 + 4 * (j & 3)) = piece[u];
+            }
+        }
+        if (r & 3) {   // rank rows r .. 4KS-1 of the last k-step are zero
+            const int k = r + (lane >> 4);
+            if (k < 4 * KS) {
+                dstw[(0 * KS + (k >> 2)) * 64 + (k & 3) * 16 + (lane & 15)] = 0.f;
+                dstw[(1 * KS + (k >> 2)) * 64 + (k & 3) * 16 + (lane & 15)] = 0.f;
+            }
+        }
+    } else
     for (int e = lane; e < 2 * KS * 64; e += 64) {
         const int rt = e / (KS * 64), rem = e - rt * KS * 64, s = rem >> 6, L = rem & 63;
         const int k = 4 * s + (L >> 4);
@@ -625,7 +656,6 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
     }
     // V fragments of one 64-column block: img[s][lane] = float4 V[4s + (lane>>4)][j0 + 4(lane&15) .. +3].
     // Staged in two halves: global loads into registers before the MFMAs of the current block, LDS writes after them.
-    constexpr int NV = 8;                       // KS*64/256 <= 8 float4 per thread (r <= 128)
     f32x4 vreg[NV];
     auto stageV_load = [&](int blk) {   // straight copies of the pre-arranged fragments (nnf_cost_prepv_kernel)
         const f32x4* src = Vf + (size_t)blk * KS * 64;
@@ -644,16 +674,25 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
     };
     stageV_load(blk0);
     stageV_store(ldsV + (size_t)(blk0 & 1) * KS * 64);
-    f32x4 xb[2][4];  // [rt][reg]: row i0w + 16rt + 4g + reg, columns j0+4jj..+3
+    // X ring: the blocks blk and blk+1 are in registers / in flight while block blk is worked on; the refill for blk+2
+    // is issued as soon as blk's registers are free.  One block ahead left HBM idle between the (phase-locked) bursts of
+    // a CU's waves: loads alone 175 us, MFMA alone ~130 us, together 290 us at B.  Blocks past the workgroup's column
+    // range are "read" through an out-of-range offset: zeros, no memory traffic.
+    f32x4 xbA[2][4], xbB[2][4];  // [rt][reg]: row i0w + 16rt + 4g + reg, columns j0+4jj..+3
+    auto xload = [&](f32x4 (&xb)[2][4], int blk) {
+        const int vo = (blk < nblk) ? voff : (int)0x7ffffff0;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) xb[rt][reg] = nnf_bload4<VEC>(rs, voff, (16 * rt + reg) * ldx4 + 256 * blk0);
+            for (int reg = 0; reg < 4; ++reg) xb[rt][reg] = nnf_bload4<VEC>(rs, vo, (16 * rt + reg) * ldx4 + 256 * blk);
+    };
+    xload(xbA, blk0);
+    xload(xbB, blk0 + 1);
     __syncthreads();
 
     double dsum = 0.0;
     const float* uf = ldsU + (size_t)(w * 2) * KS * 64 + lane;
-    for (int blk = blk0; blk < nblk; ++blk) {
+    auto do_block = [&](int blk, f32x4 (&xb)[2][4]) {
         const f32x4* img = ldsV + (size_t)(blk & 1) * KS * 64;
         stageV_load(blk + 1);   // past the last block every entry is masked to zero (j >= n)
         f32x4 acc[2][4];
@@ -764,13 +803,13 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
                 }
         }
         dsum += (double)loc;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                xb[rt][reg] = nnf_bload4<VEC>(rs, voff, (16 * rt + reg) * ldx4 + 256 * (blk + 1));
+        xload(xb, blk + 2);
         stageV_store(ldsV + (size_t)((blk + 1) & 1) * KS * 64);
         __syncthreads();
+    };
+    for (int blk = blk0; blk < nblk; blk += 2) {
+        do_block(blk, xbA);
+        if (blk + 1 < nblk) do_block(blk + 1, xbB);   // (workgroup-uniform: every wave passes the same barriers)
     }
     const double bs = nnf_block_sum_f64(dsum, red);
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = bs;
@@ -885,6 +924,10 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
     const int nblk_all = (int)nnf_cdiv(n, 64);
     int csplit = (int)nnf_cdiv((int64_t)8 * 2 * ctx->num_cus, grid);
     if (csplit > nblk_all / 4) csplit = nblk_all / 4;
+    {   // tuning knob (tools/cost_probe.py): NNF_COST_CSPLIT overrides the number of column splits
+        static const int forced = [] { const char* e = getenv("NNF_COST_CSPLIT"); return e ? atoi(e) : 0; }();
+        if (forced > 0) csplit = forced < nblk_all ? forced : nblk_all;
+    }
     if (csplit < 1) csplit = 1;
     nnf_ws_cursor cur(ctx);
     double* partial = (double*)cur.take((size_t)grid * csplit * 8);
@@ -899,19 +942,24 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
         hipLaunchKernelGGL(nnf_cost_prepv_kernel, dim3((int)pg), dim3(256), 0, st, V, ldv, r, n, KS, Vb, ldvb, nb, Vf, vf_total);
         NNF_CHECK_LAUNCH();
     }
+    const int u_vec_ok = ((((uintptr_t)Ut) & 15) == 0 && (ldu & 3) == 0) ? 1 : 0;
     const size_t shm = (size_t)4 * 2 * KS * 64 * 4 + (size_t)2 * KS * 64 * 16 + 64;
-    if (shm > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_cost_kernel<OP, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_cost_kernel<OP, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+#define NNF_COST_LAUNCH(VV, NN)                                                                                              \
+    do {                                                                                                                     \
+        if (shm > 48 * 1024)                                                                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_cost_kernel<OP, VV, NN>),                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                 \
+        hipLaunchKernelGGL((nnf_cost_kernel<OP, VV, NN>), dim3(grid, csplit), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, Vf, r, \
+                           beta, partial, Ub, ldub, nbu, R1, R2, ldr, u_vec_ok);                                             \
+    } while (0)
+    if (x_vec_ok(X, ldx)) {
+        if (KS <= 16) NNF_COST_LAUNCH(true, 4);
+        else NNF_COST_LAUNCH(true, 8);
+    } else {
+        if (KS <= 16) NNF_COST_LAUNCH(false, 4);
+        else NNF_COST_LAUNCH(false, 8);
     }
-    if (x_vec_ok(X, ldx))
-        hipLaunchKernelGGL((nnf_cost_kernel<OP, true>), dim3(grid, csplit), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, Vf, r, beta,
-                           partial, Ub, ldub, nbu, R1, R2, ldr);
-    else
-        hipLaunchKernelGGL((nnf_cost_kernel<OP, false>), dim3(grid, csplit), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, Vf, r, beta,
-                           partial, Ub, ldub, nbu, R1, R2, ldr);
+#undef NNF_COST_LAUNCH
     NNF_CHECK_LAUNCH();
     if (OP == NNF_RATIO_KL || OP == NNF_RATIO_GEN) return NNF_OK;   // nothing to sum
     hipLaunchKernelGGL(nnf_sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)grid * csplit, scale, out_f64);

@@ -106,3 +106,70 @@ def hals_nnls_acc(UtM, UtU, in_V, maxiter=500, atime=None, alpha=0.5, delta=0.01
     if maxiter < 1:
         eps, cnt = 1, 1
     return like_input(V, in_V), eps, cnt, rho
+
+
+def hals_coupling_nnls_acc(UtM, UtU, in_V, Vtarget, mu, maxiter=500, atime=None, alpha=0.5, delta=0.01,
+                           normalize=False, nonzero=False):
+    """HALS NNLS coupled to a target matrix, min_{V>=0} ||M-UV||_F^2 + mu ||V-Vtarget||_F^2 -- drop-in for
+    nn_fac/update_rules/nnls.py:204-352 (PARAFAC2's caller of the sweep, parafac2.py:548,581).
+
+    The coupled row update (nnls.py:317)
+        (UtM[k] - UtU[k]@V + mu (Vtarget[k] - V[k])) / (UtU[k,k] + mu)
+    is the plain update of hals_nnls_acc on the shifted operands  UtM + mu Vtarget  and  UtU + mu I , so the same
+    persistent device solve runs it (two tiny element-wise preparations, r x n and r x r).  What does NOT carry over is
+    the zero-diagonal test, which the reference makes on UtU[k,k] alone (nnls.py:316): such rows keep a zero diagonal
+    in the shifted Gram, which is how the kernels recognise a frozen row.  Same return tuple ``(V, eps, cnt, rho)``;
+    ``nonzero`` with a zero diagonal raises the reference's plain ValueError (nnls.py:331-332).  The reference does
+    not validate its arguments here (no ArgumentException checks); shapes are checked only as far as the device needs."""
+    dev = device_of(UtM, UtU, in_V)
+    eng = _engine.get_engine(dev)
+    M = to_dev(UtM, dev)
+    G = to_dev(UtU, dev)
+    T = to_dev(Vtarget, dev)
+    r, n = M.shape
+    if G.shape[0] < r or G.shape[1] < r or tuple(T.shape) != (r, n):
+        raise err.ArgumentException(f"Inconsistent shapes: UtM {tuple(M.shape)}, UtU {tuple(G.shape)}, "
+                                    f"Vtarget {tuple(T.shape)}.")
+    if not _size(in_V):
+        # nnls.py:297-303: unconstrained least squares on the UNshifted operands, clipped and rescaled (runs once)
+        V = torch.linalg.solve(G.double(), M.double())
+        V[V < 0] = 0
+        V = (torch.sum(M.double() * V) / torch.sum(G.double() * (V @ V.T))) * V
+        V = V.float().contiguous()
+    else:
+        V = to_dev(in_V, dev)
+        if isinstance(in_V, torch.Tensor) and V.data_ptr() == in_V.data_ptr():
+            V = V.clone()   # never touch the caller's array (nnls.py:305)
+    if tuple(V.shape) != (r, n):
+        raise err.ArgumentException(f"Inconsistent shapes: UtM {tuple(M.shape)}, V {tuple(V.shape)}.")
+    mu = float(mu)
+    Ms = torch.add(M, T, alpha=mu)                       # UtM + mu Vtarget
+    Gs = G[:r, :r].clone()
+    d = torch.diagonal(Gs)
+    frozen = d == 0
+    d.add_(mu)
+    d[frozen] = 0.0                                      # rows the reference skips stay skipped (nnls.py:316)
+
+    rho = 100000
+    budget = sweep_budget(maxiter, alpha, rho)
+    if atime and not math.isinf(alpha):
+        probe = V.clone()
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        eng.hals_sweeps(Ms, Gs, probe, 1, normalize=normalize, nonzero=nonzero)
+        torch.cuda.synchronize(dev)
+        btime = max(time.time() - t0, 10e-7)
+        rho = atime / btime
+        budget = max(1, sweep_budget(maxiter, alpha, rho)) if maxiter >= 1 else 0
+
+    st = eng.hals_solve(Ms, Gs, V, budget, delta=delta, normalize=normalize, nonzero=nonzero).cpu()
+    code = int(st[_engine.ST_ERR])
+    if code == 2:
+        k = int(torch.nonzero(frozen)[0])
+        raise ValueError("Column " + str(k) + " is zero with nonzero condition")
+    if code != 0:
+        raise err.EngineError("hals grid barrier timed out; result invalid")
+    eps, cnt = float(st[_engine.ST_EPS]), int(st[_engine.ST_CNT])
+    if maxiter < 1:
+        eps, cnt = 1, 1
+    return like_input(V, in_V), eps, cnt, rho

@@ -117,6 +117,54 @@ def hals_nnls_acc(UtM, UtU, in_V, maxiter=500, atime=None, alpha=0.5, delta=0.01
 
 
 # --------------------------------------------------------------------------------------
+# f4: HALS NNLS coupled to a target matrix (PARAFAC2's caller of the path)
+#     nn_fac/update_rules/nnls.py:204-352;  min_{V>=0} ||M - UV||_F^2 + mu ||V - Vtarget||_F^2
+# --------------------------------------------------------------------------------------
+def hals_coupling_nnls_acc(UtM, UtU, in_V, Vtarget, mu, maxiter=500, atime=None, alpha=0.5, delta=0.01,
+                           normalize=False, nonzero=False, sweep_log=None):
+    """nnls.py:296-305 start value; :307-310 state; :314 loop condition (maxiter first, same predicate);
+    :316-329 coupled row update -- the zero-diagonal test is on UtU[k,k], NOT on UtU[k,k] + mu;
+    :331-332 plain ValueError (not ZeroColumnWhenUnautorized); :334-340 normalisation; :342-350 bookkeeping."""
+    r, n = np.shape(UtM)
+    if not in_V.size:
+        V = np.linalg.solve(UtU, UtM)      # (np.linalg.linalg.solve in the reference: removed from NumPy 2)
+        V[V < 0] = 0
+        V = (np.sum(UtM * V) / np.sum(UtU * np.dot(V, V.T))) * V
+    else:
+        V = in_V.copy()
+    rho, eps0, cnt, eps = 100000, 0, 1, 1
+    t0 = time.time()
+    while cnt <= maxiter and eps >= delta * eps0 and cnt <= 1 + alpha * rho:
+        nodelta = 0
+        for k in range(r):
+            if UtU[k, k] != 0:
+                step = np.maximum((UtM[k, :] - UtU[k, :] @ V + mu * (Vtarget[k, :] - V[k, :])) / (UtU[k, k] + mu),
+                                  -V[k, :])
+                V[k, :] = V[k, :] + step
+                nodelta = nodelta + np.dot(step, np.transpose(step))
+                if nonzero and (V[k, :] == 0).all():
+                    V[k, :] = 1e-16 * np.max(V)
+            elif nonzero:
+                raise ValueError("Column " + str(k) + " is zero with nonzero condition")
+            if normalize:
+                nrm = np.linalg.norm(V[k, :])
+                if nrm != 0:
+                    V[k, :] /= nrm
+                else:
+                    V[k, :] = 1 / n ** (1 / 2)
+        if cnt == 1:
+            eps0 = nodelta
+            btime = max(time.time() - t0, 10e-7)
+            if atime:
+                rho = atime / btime
+        eps = nodelta
+        if sweep_log is not None:
+            sweep_log.append(float(nodelta))
+        cnt += 1
+    return V, eps, cnt, rho
+
+
+# --------------------------------------------------------------------------------------
 # a6: beta-divergence and the MU exponent  (nn_fac/utils/beta_divergence.py:17-80)
 # --------------------------------------------------------------------------------------
 def gamma_beta(beta):
@@ -262,10 +310,48 @@ def nmf_random_init(shape, rank, seed):
     return np.random.rand(m, rank), np.random.rand(rank, n)
 
 
+def nndsvd(V, rank):
+    """f3: NNDSVD start values, initialize_factors.py:160-206 (Boutsidis & Gallopoulos).  The negativity test of the
+    reference (`V.any() < 0`, :162) can never fire and is not restated.  np.linalg.svd(V) is the reference's call
+    (full_matrices=True, :173); only the first `rank` triplets are read, so the thin SVD gives the same result, and the
+    result does not depend on the sign convention of the singular vectors (flipping a pair swaps the two candidates)."""
+    U, S, Et = np.linalg.svd(V, full_matrices=False)
+    E = Et.T
+    W = np.zeros((V.shape[0], rank))
+    H = np.zeros((rank, V.shape[1]))
+    W[:, 0] = np.sqrt(S[0]) * np.abs(U[:, 0])
+    H[0, :] = np.sqrt(S[0]) * np.abs(E[:, 0].T)
+    for i in range(1, rank):
+        uu, vv = U[:, i], E[:, i]
+        uup, uun = np.multiply(uu >= 0, uu), np.multiply(uu < 0, -uu)
+        vvp, vvn = np.multiply(vv >= 0, vv), np.multiply(vv < 0, -vv)
+        n_uup, n_vvp = np.linalg.norm(uup, 2), np.linalg.norm(vvp, 2)
+        n_uun, n_vvn = np.linalg.norm(uun, 2), np.linalg.norm(vvn, 2)
+        termp, termn = n_uup * n_vvp, n_uun * n_vvn
+        if termp >= termn:
+            W[:, i] = np.sqrt(S[i] * termp) / n_uup * uup
+            H[i, :] = np.sqrt(S[i] * termp) / n_vvp * vvp.T
+        else:
+            W[:, i] = np.sqrt(S[i] * termn) / n_uun * uun
+            H[i, :] = np.sqrt(S[i] * termn) / n_vvn * vvn.T
+    return np.maximum(W, 1e-12), np.maximum(H, 1e-12)
+
+
+def ntf_nndsvd_init(tensor, rank):
+    """initialize_factors.py:98-105: NNDSVD of every unfolding (modes shorter than the rank fall back to rand)."""
+    out = []
+    for mode in range(tensor.ndim):
+        if tensor.shape[mode] < rank:
+            out.append(np.random.rand(tensor.shape[mode], rank))
+        else:
+            out.append(nndsvd(unfold(tensor, mode), rank)[0])
+    return out
+
+
 def nmf(data, rank, init="random", U_0=None, V_0=None, n_iter_max=100, tol=1e-8, update_rule="hals", beta=2,
         sparsity_coefficients=[None, None], fixed_modes=[], normalize=[False, False], verbose=False,
         return_costs=False, deterministic=False, seed=0, sweeps=None):
-    """nmf.py:175-193 (random and custom init only; nndsvd is an initialiser, out of scope)."""
+    """nmf.py:175-193."""
     if min(data.shape) < rank:
         rank = min(data.shape)
     if deterministic:
@@ -278,8 +364,10 @@ def nmf(data, rank, init="random", U_0=None, V_0=None, n_iter_max=100, tol=1e-8,
             U_0, V_0 = nmf_random_init(data.shape, rank, seed)
         else:
             U_0, V_0 = np.random.rand(data.shape[0], rank), np.random.rand(rank, data.shape[1])
+    elif init.lower() == "nndsvd":
+        U_0, V_0 = nndsvd(data, rank)
     else:
-        raise InvalidInitializationType("Initialization type not understood (oracle: random|custom).")
+        raise InvalidInitializationType("Initialization type not understood.")
     return compute_nmf(data, rank, U_0, V_0, n_iter_max=n_iter_max, tol=tol, update_rule=update_rule, beta=beta,
                        sparsity_coefficients=sparsity_coefficients, fixed_modes=fixed_modes, normalize=normalize,
                        verbose=verbose, return_costs=return_costs, deterministic=deterministic, sweeps=sweeps)

@@ -140,6 +140,39 @@ def test_hals_against_reference_fixtures(golden, layout, monkeypatch):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_hals_coupling_against_reference_fixtures(golden, layout, monkeypatch):
+    """hals_coupling_nnls_acc (nnls.py:204-352, PARAFAC2's caller of the sweep) vs the real reference's outputs (g8):
+    sweep counts equal, factors within the fp32 single-call tolerance, both kernel layouts."""
+    from nn_fac_amd.update_rules.nnls import hals_coupling_nnls_acc
+    monkeypatch.setenv("NNF_HALS_FORCE", layout)
+    g = golden("g8_hals_coupling.npz")
+    bad = []
+    for c in range(int(g["ncases"])):
+        s = int(g[f"c{c}_shape"])
+        vec = g[f"c{c}_kw"]
+        mu, zd = float(vec[0]), (None if vec[5] < 0 else int(vec[5]))
+        kw = dict(maxiter=int(vec[1]), delta=float(vec[2]), normalize=bool(vec[3]), nonzero=bool(vec[4]), alpha=math.inf)
+        G = g[f"s{s}_UtU"].copy()
+        if zd is not None:
+            G[zd, zd] = 0.0
+        Vin = g[f"s{s}_Vin"].copy()
+        V, eps, cnt, rho = hals_coupling_nnls_acc(g[f"s{s}_UtM"], G, Vin, g[f"s{s}_Vt"], mu, **kw)
+        want = g[f"c{c}_V"]
+        assert V.dtype == want.dtype and V.shape == want.shape and np.array_equal(Vin, g[f"s{s}_Vin"])
+        e = rel(V, want)
+        if cnt != int(g[f"c{c}_cnt"]) or e > 2e-4 or abs(eps - float(g[f"c{c}_eps"])) > 2e-3 * abs(float(g[f"c{c}_eps"])) + 1e-12:
+            bad.append((c, cnt, int(g[f"c{c}_cnt"]), e, eps, float(g[f"c{c}_eps"])))
+        if zd is not None:      # the row with a zero Gram diagonal is not touched although mu > 0 (nnls.py:316)
+            np.testing.assert_array_equal(V[zd], Vin[zd].astype(np.float32).astype(np.float64))
+    assert not bad, bad
+    r = np.random.RandomState(0)
+    G = r.rand(8, 8)
+    G[2, 2] = 0
+    with pytest.raises(ValueError):       # nnls.py:331-332
+        hals_coupling_nnls_acc(r.rand(8, 8), G, r.rand(8, 8), r.rand(8, 8), 1.0, nonzero=True)
+
+
 def test_hals_zero_column_raises():
     from nn_fac_amd.update_rules.nnls import hals_nnls_acc
     from nn_fac_amd.utils import errors as err

@@ -177,3 +177,42 @@ def test_early_stop_drops_the_speculative_iteration(golden, built_lib, rule, bet
                                 return_costs=True, deterministic=True)
     assert cs == ck[:first + 1] == costs[:first + 1]
     assert np.array_equal(Us, Uk) and np.array_equal(Vs, Vk)
+
+
+def test_nndsvd_known_answer_and_oracle(golden, built_lib):
+    """initialize_factors.py:160-206 on the device.  The reference's own known answer (tests/NMF_tests.py:33-36), then the
+    oracle on a square, a tall (Gram route over the columns) and a wide (Gram route over the rows) matrix."""
+    from nn_fac_amd.utils.initialize_factors import nmf_initialization, nndsvd
+    g = golden("g0_known_answers.npz")
+    U, V = nmf_initialization(g["data"], int(g["rank"]), init_type="nndsvd", deterministic=True)
+    assert isinstance(U, np.ndarray) and U.dtype == np.float64 and U.shape == (73, 9) and V.shape == (9, 25)
+    assert abs(U[0][0] - 1.4604530858567824) < 1e-7 and abs(V[0][0] - 1.3118383377996725) < 1e-7
+    Uo, Vo = orc.nndsvd(g["data"], int(g["rank"]))
+    np.testing.assert_allclose(U, Uo, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(V, Vo, rtol=1e-8, atol=1e-11)
+    for (m, n, r) in ((60, 50, 7), (3000, 120, 12), (90, 2500, 10)):
+        X, _, _ = orc.synth_nmf(m, n, r, seed=m, dtype=np.float64)
+        W, H = nndsvd(X, r)
+        Wo, Ho = orc.nndsvd(X, r)
+        assert rel(W, Wo) < 1e-8 and rel(H, Ho) < 1e-8 and W.min() >= 1e-12 and H.min() >= 1e-12
+    Xd = torch.from_numpy(orc.synth_nmf(500, 80, 5, seed=3, dtype=np.float32)[0]).cuda()
+    Wd, Hd = nndsvd(Xd, 5)                     # device tensor in -> device tensors out, input dtype
+    assert Wd.is_cuda and Wd.dtype == torch.float32 and tuple(Hd.shape) == (5, 80)
+
+
+def test_nmf_and_ntf_with_nndsvd_init(built_lib):
+    """nmf(init='nndsvd') end to end vs the oracle driven from the oracle's NNDSVD start (HALS tolerances of SURVEY 8c)."""
+    from nn_fac_amd.nmf import nmf
+    from nn_fac_amd.utils.initialize_factors import ntf_initialization
+    X, _, _ = orc.synth_nmf(400, 150, 8, seed=11, dtype=np.float64)
+    U, V, costs, _ = nmf(X, 8, init="nndsvd", n_iter_max=8, tol=0, update_rule="hals", return_costs=True,
+                         deterministic=True)
+    Uo, Vo, co, _ = orc.nmf(X, 8, init="nndsvd", n_iter_max=8, tol=0, update_rule="hals", return_costs=True,
+                            deterministic=True)
+    assert rel(U, Uo) < HALS_FRO and rel(V, Vo) < HALS_FRO
+    np.testing.assert_allclose(costs, co, rtol=HALS_COST)
+    T, _ = orc.synth_ntf((30, 25, 20), 4, seed=2, dtype=np.float64)
+    F = ntf_initialization(T, 4, "nndsvd", deterministic=True, seed=0)
+    Fo = orc.ntf_nndsvd_init(T, 4)
+    for a, b in zip(F, Fo):
+        assert rel(a, b) < 1e-8

@@ -36,6 +36,17 @@ def test_g0_random_init_stream():
     assert abs(U[0][0] - 0.5488135) < 1e-7 and abs(V[0][0] - 1.15834001e-01) < 1e-7   # NMF_tests.py:40-41
 
 
+def test_g0_nndsvd_known_answer(golden):
+    """tests/NMF_tests.py:33-36 of the reference: NNDSVD start values of the 73 x 25 rank-9 problem."""
+    g = golden("g0_known_answers.npz")
+    U, V = orc.nndsvd(g["data"], int(g["rank"]))
+    assert abs(U[0][0] - 1.4604530858567824) < 1e-7 and abs(V[0][0] - 1.3118383377996725) < 1e-7
+    assert U.shape == (73, 9) and V.shape == (9, 25) and U.min() >= 1e-12 and V.min() >= 1e-12
+    # sign convention of the SVD does not matter
+    Uf, Vf = orc.nndsvd(g["data"][::-1, ::-1].copy(), int(g["rank"]))
+    np.testing.assert_allclose(Uf[::-1], U, rtol=1e-9, atol=1e-12)
+
+
 def test_g1_hals(golden):
     g = golden("g1_hals.npz")
     for c in range(int(g["ncases"])):
@@ -47,6 +58,34 @@ def test_g1_hals(golden):
         np.testing.assert_allclose(V, g[f"c{c}_V"], rtol=1e-12, atol=1e-15)
         np.testing.assert_allclose(eps, float(g[f"c{c}_eps"]), rtol=1e-12)
         np.testing.assert_allclose(log, g[f"c{c}_nodelta"], rtol=1e-12)
+
+
+def _kw8(vec):
+    kw = dict(maxiter=int(vec[1]), delta=float(vec[2]), normalize=bool(vec[3]), nonzero=bool(vec[4]), alpha=math.inf)
+    return float(vec[0]), kw, (None if vec[5] < 0 else int(vec[5]))
+
+
+def test_g8_hals_coupling(golden):
+    """nnls.py:204-352 (coupled sweep used by PARAFAC2): outputs of the real reference, oracle/gen_golden_g8.py."""
+    g = golden("g8_hals_coupling.npz")
+    for c in range(int(g["ncases"])):
+        s = int(g[f"c{c}_shape"])
+        mu, kw, zd = _kw8(g[f"c{c}_kw"])
+        G = g[f"s{s}_UtU"].copy()
+        if zd is not None:
+            G[zd, zd] = 0.0
+        log = []
+        V, eps, cnt, _ = orc.hals_coupling_nnls_acc(g[f"s{s}_UtM"], G, g[f"s{s}_Vin"], g[f"s{s}_Vt"], mu,
+                                                    sweep_log=log, **kw)
+        assert cnt == int(g[f"c{c}_cnt"]), c
+        np.testing.assert_allclose(V, g[f"c{c}_V"], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(eps, float(g[f"c{c}_eps"]), rtol=1e-12)
+        np.testing.assert_allclose(log, g[f"c{c}_nodelta"], rtol=1e-12)
+    r = np.random.RandomState(0)
+    G = r.rand(8, 8)
+    G[2, 2] = 0
+    with pytest.raises(ValueError):       # nnls.py:331-332: a plain ValueError, not ZeroColumnWhenUnautorized
+        orc.hals_coupling_nnls_acc(r.rand(8, 8), G, r.rand(8, 8), r.rand(8, 8), 1.0, nonzero=True)
 
 
 def test_hals_argument_errors():

@@ -674,25 +674,24 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
     };
     stageV_load(blk0);
     stageV_store(ldsV + (size_t)(blk0 & 1) * KS * 64);
-    // X ring: the blocks blk and blk+1 are in registers / in flight while block blk is worked on; the refill for blk+2
-    // is issued as soon as blk's registers are free.  One block ahead left HBM idle between the (phase-locked) bursts of
-    // a CU's waves: loads alone 175 us, MFMA alone ~130 us, together 290 us at B.  Blocks past the workgroup's column
-    // range are "read" through an out-of-range offset: zeros, no memory traffic.
-    f32x4 xbA[2][4], xbB[2][4];  // [rt][reg]: row i0w + 16rt + 4g + reg, columns j0+4jj..+3
-    auto xload = [&](f32x4 (&xb)[2][4], int blk) {
+    // X one block ahead.  (A two-block ring was tried: same time, 12 more registers -- and at <= 136 registers three of these
+    // waves leave room on a SIMD for a wave of the persistent V-side sweep kernel, which the outer loop overlaps this
+    // kernel with.)  The block past the workgroup's column range is "read" through an out-of-range offset: zeros, no
+    // memory traffic (the prefetch used to fetch the next rows' data: 1.24 GB instead of 0.82 GB per launch).
+    f32x4 xb[2][4];  // [rt][reg]: row i0w + 16rt + 4g + reg, columns j0+4jj..+3
+    auto xload = [&](int blk) {
         const int vo = (blk < nblk) ? voff : (int)0x7ffffff0;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) xb[rt][reg] = nnf_bload4<VEC>(rs, vo, (16 * rt + reg) * ldx4 + 256 * blk);
     };
-    xload(xbA, blk0);
-    xload(xbB, blk0 + 1);
+    xload(blk0);
     __syncthreads();
 
     double dsum = 0.0;
     const float* uf = ldsU + (size_t)(w * 2) * KS * 64 + lane;
-    auto do_block = [&](int blk, f32x4 (&xb)[2][4]) {
+    for (int blk = blk0; blk < nblk; ++blk) {
         const f32x4* img = ldsV + (size_t)(blk & 1) * KS * 64;
         stageV_load(blk + 1);   // past the last block every entry is masked to zero (j >= n)
         f32x4 acc[2][4];
@@ -803,13 +802,9 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
                 }
         }
         dsum += (double)loc;
-        xload(xb, blk + 2);
+        xload(blk + 1);
         stageV_store(ldsV + (size_t)((blk + 1) & 1) * KS * 64);
         __syncthreads();
-    };
-    for (int blk = blk0; blk < nblk; blk += 2) {
-        do_block(blk, xbA);
-        if (blk + 1 < nblk) do_block(blk + 1, xbB);   // (workgroup-uniform: every wave passes the same barriers)
     }
     const double bs = nnf_block_sum_f64(dsum, red);
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = bs;

@@ -331,14 +331,14 @@ def get_engine(device=None):
 _side = {}
 
 
-def get_side_engine(device):
-    """Process-wide second context + stream of `device`, for work that overlaps with a launch on the main stream (a
+def get_side_engine(device, role="gram"):
+    """Process-wide extra context + stream of `device` per role, for work that overlaps with a launch on the main stream (a
     context's workspace serves one stream at a time).  Created once: context creation allocates and clears its workspace."""
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     with _lock:
-        e = _side.get(idx)
+        e = _side.get((idx, role))
         if e is None:
             e = (Engine(torch.device(f"cuda:{idx}"), workspace_bytes=64 << 20), torch.cuda.Stream(device=idx))
-            _side[idx] = e
+            _side[(idx, role)] = e
         return e

@@ -150,8 +150,8 @@ class _StepBuffers:
         # one block read back per iteration: HALS status of the first / second solve at [0:8] / [8:16], cost at [16].
         # A ring of PIPELINE_DEPTH + 1 blocks with pinned host mirrors: run_steps enqueues iteration i+1 before it reads
         # the block of iteration i, so the device never waits for the host between iterations.
-        self.blocks = torch.zeros((PIPELINE_DEPTH + 1, 24), dtype=torch.float64, device=X.device)
-        self.host = torch.zeros((PIPELINE_DEPTH + 1, 24), dtype=torch.float64)
+        self.blocks = torch.zeros((PIPELINE_DEPTH + 2, 24), dtype=torch.float64, device=X.device)
+        self.host = torch.zeros((PIPELINE_DEPTH + 2, 24), dtype=torch.float64)
         if X.is_cuda:
             self.host = self.host.pin_memory()
         self.select(0)
@@ -159,6 +159,8 @@ class _StepBuffers:
         # the r x r Gram of an update is independent of its cross product (nmf.py:407-408, :432-433): it runs on a side
         # stream, with its own context (a context's workspace serves one stream at a time), under the streaming kernel
         self.side_eng, self.side_stream = _engine.get_side_engine(X.device) if X.is_cuda else (None, None)
+        # a third context + stream: the cost of one iteration runs under the V-side solve of the next (run_steps)
+        self.cost_eng, self.cost_stream = _engine.get_side_engine(X.device, "cost") if X.is_cuda else (None, None)
 
 
 
@@ -187,42 +189,91 @@ def _raise_on_status(host, nstat):
 
 def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
               deterministic, retired, group=None):
-    """The `for iteration` loop of compute_nmf (nmf.py:298-324) with the device running ahead of the host: iteration
-    i+1 is enqueued BEFORE the host reads the cost of iteration i (its 24-double block arrives through an asynchronous
-    copy into pinned memory + an event), so the per-iteration round trip -- D2H copy, stopping test in Python, ~15 launches
-    -- no longer leaves the GPU idle.  `retired(iteration, cost, sweeps)` is called once per iteration, in order, and
-    returns True when the loop has to stop (nmf.py:320-324); the factors returned are those of the iteration that
-    stopped it -- each step writes fresh factor tensors, so the speculative iteration in flight is simply dropped.
-    Paths that synchronise inside a step anyway (wall-clock rule, row-sharded solve) run through the same code."""
-    pending = []          # (iteration, slot, Ut, V, nstat, event)
+    """The `for iteration` loop of compute_nmf (nmf.py:298-324) with the device running ahead of the host.
+
+    * Iteration i+1 is enqueued BEFORE the host reads the cost of iteration i (its 24-double block arrives through an
+      asynchronous copy into pinned memory + an event), so the per-iteration round trip -- D2H copy, stopping test in
+      Python, ~15 launches -- no longer leaves the GPU idle.
+    * HALS: the cost of iteration i (nmf.py:452: one MFMA/HBM-bound pass over X, ~290 us at B) is not launched at the end
+      of iteration i but next to the V-side solve of iteration i+1, on its own stream and context: that solve is a
+      persistent kernel of ceil(n/16) single-wave workgroups (125 at n = 2000, ~270 us) which leaves the chip all but
+      empty, and everything else of iteration i+1 depends on it.  The cost kernel's waves are small enough (<= 136 VGPRs)
+      for a sweep wave to fit on a SIMD they fill, so the order in which the two get their CUs does not matter.  The main
+      stream waits for that cost before it launches the next U-side solve (whose 1563 waves should find the chip free).
+      The host then looks at costs two iterations behind the device.  Single-GPU runs only: with the row-sharded step
+      (collectives + a second persistent kernel per iteration) the extra stream could only be rehearsed with two
+      processes sharing one GPU, where it was pathologically slow, so sharded runs keep the cost inside the step.
+
+    `retired(iteration, cost, sweeps)` is called once per iteration, in order, and returns True when the loop has to stop
+    (nmf.py:320-324); the factors returned are those of the iteration that stopped it -- each step writes fresh factor
+    tensors, so the speculative iterations in flight are simply dropped.  Paths that synchronise inside a step anyway
+    (wall-clock rule, row-sharded solve) run through the same code."""
+    cuda = X.is_cuda
+    overlap = (cuda and update_rule == "hals" and 1 not in fixed_modes and isinstance(eng, _engine.Engine)
+               and ws.cost_stream is not None and _dist.world(group) == 1)
+    depth = PIPELINE_DEPTH + (1 if overlap else 0)
+    assert ws.blocks.shape[0] > depth
+    pending = []          # steps not yet handed to `retired`: dicts {it, slot, Ut, V, nstat, ev}
     result = (Ut, V)
     stop = False
+    main = torch.cuda.current_stream(X.device) if cuda else None
+
+    def cost_of(step, stream):
+        """Launch the cost of `step` (+ the copy of its status block to the host) on `stream`."""
+        block = ws.blocks[step["slot"]]
+        with torch.cuda.stream(stream):
+            if stream is not main:
+                stream.wait_event(main.record_event())       # factors, status words of `step`: all enqueued on main
+            _step_cost(ws.cost_eng if stream is not main else eng, X, step["Ut"], step["V"], update_rule, beta,
+                       sparsity_coefficients, block[16:17], group)
+            ws.host[step["slot"]].copy_(block, non_blocking=True)
+            step["ev"] = stream.record_event()
 
     def retire():
         nonlocal result, stop
-        it, slot, Ut_i, V_i, nstat, ev = pending.pop(0)
-        if ev is not None:
-            ev.synchronize()
-        host = ws.host[slot]
-        _raise_on_status(host, nstat)
-        result = (Ut_i, V_i)
-        stop = bool(retired(it, float(host[16]), [int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(nstat)]))
+        step = pending.pop(0)
+        if step["ev"] is not None:
+            step["ev"].synchronize()
+        host = ws.host[step["slot"]]
+        _raise_on_status(host, step["nstat"])
+        result = (step["Ut"], step["V"])
+        stop = bool(retired(step["it"], float(host[16]),
+                            [int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(step["nstat"])]))
 
+    owed = None           # overlap: the step whose cost has not been launched yet
+    costed = None         # overlap: the step whose cost was launched during the previous step
     for iteration in range(n_iter):
-        ws.select(iteration % (PIPELINE_DEPTH + 1))
+        ws.select(iteration % ws.blocks.shape[0])
+        hooks = {}
+        if overlap and owed is not None:
+            hooks["before_v_solve"] = lambda prev=owed: cost_of(prev, ws.cost_stream)
+        if overlap and costed is not None:
+            # the cost launched during the previous step must be out of the way before this step's U-side solve
+            hooks["before_u_solve"] = lambda ev=costed["ev"]: main.wait_event(ev)
         Ut, V, nstat = _one_nmf_step_dev(eng, ws, X, rank, Ut, V, update_rule, beta, sparsity_coefficients,
-                                         fixed_modes, normalize, deterministic, group=group)
-        ws.host[ws.slot].copy_(ws.block, non_blocking=True)
-        ev = torch.cuda.current_stream(X.device).record_event() if X.is_cuda else None
-        pending.append((iteration, ws.slot, Ut, V, nstat, ev))
-        if len(pending) > PIPELINE_DEPTH:
+                                         fixed_modes, normalize, deterministic, group=group, skip_cost=overlap, **hooks)
+        step = dict(it=iteration, slot=ws.slot, Ut=Ut, V=V, nstat=nstat, ev=None)
+        if overlap:
+            costed = owed
+            owed = step
+        elif cuda:
+            ws.host[ws.slot].copy_(ws.block, non_blocking=True)
+            step["ev"] = main.record_event()
+        else:
+            ws.host[ws.slot].copy_(ws.block)
+        pending.append(step)
+        if len(pending) > depth:
             retire()
             if stop:
                 break
+    if overlap and not stop and owed is not None and owed["ev"] is None:
+        cost_of(owed, main)               # the last step has no V-side solve behind it to hide under
     while pending and not stop:
         retire()
-    if pending and X.is_cuda:         # a dropped speculative iteration still uses the shared scratch: let it drain
-        torch.cuda.current_stream(X.device).synchronize()
+    if cuda and (pending or overlap):     # dropped speculative iterations still use the shared scratch: let them drain
+        main.synchronize()
+        if overlap:
+            ws.cost_stream.synchronize()
     return result
 
 
@@ -249,11 +300,43 @@ def _hals_call(eng, cross, gram, F, sparsity, normalize, deterministic, timer, s
                           status=status)
 
 
+def _step_cost_local(eng, X, Ut, V, update_rule, beta, out):
+    """The tensor-sized part of the cost line (nmf.py:452 / :455) over this rank's rows, into the 1-element float64 `out`."""
+    if update_rule == "hals":
+        eng.frob_resid(X, Ut, V, out=out)                         # nmf.py:452
+    else:
+        eng.betadiv(X, Ut, V, beta, out=out)                      # nmf.py:455
+
+
+def _step_cost_finish(Ut, V, update_rule, sparsity_coefficients, out, group=None):
+    """Sum over the row blocks and the sparsity terms of nmf.py:452."""
+    sharded = _dist.world(group) > 1
+    if sharded:
+        _dist.allreduce_(out, group)
+    sp = [0 if s is None else s for s in sparsity_coefficients]
+    if update_rule == "hals" and (sp[0] or sp[1]):
+        # matrix 1-norm (max column abs-sum, np.linalg.norm(., ord=1)) -- NOT the entry-wise l1 (nmf.py:452)
+        cs = Ut.abs().sum(dim=1).double()         # columns of U are rows of Ut
+        if sharded:
+            _dist.allreduce_(cs, group)
+        nU = cs.max()
+        nV = V.abs().sum(dim=0).max().double()
+        out.add_(2 * (sp[0] * nU + sp[1] * nV))
+
+
+def _step_cost(eng, X, Ut, V, update_rule, beta, sparsity_coefficients, out, group=None):
+    """The cost line of one_nmf_step (nmf.py:449-455) into the 1-element float64 device tensor `out`, on the current stream."""
+    _step_cost_local(eng, X, Ut, V, update_rule, beta, out)
+    _step_cost_finish(Ut, V, update_rule, sparsity_coefficients, out, group)
+
+
 def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
-                      deterministic, group=None):
+                      deterministic, group=None, skip_cost=False, before_u_solve=None, before_v_solve=None):
     """Device-resident step.  Ut_in (r x m) and V_in (r x n) are not modified.  Returns the new factors and the number
     of HALS solves run; the cost and the solves' status words are left in ws.block (read back by the caller).
-    With `group` (torch.distributed process group) X / Ut are this rank's row block and V is replicated (dist.py)."""
+    With `group` (torch.distributed process group) X / Ut are this rank's row block and V is replicated (dist.py).
+    run_steps' hooks: `before_u_solve` / `before_v_solve` are called right before the U-side / V-side HALS solve is
+    launched; with `skip_cost` the cost line is left to the caller (who overlaps it with the next V-side solve)."""
     sharded = _dist.world(group) > 1
     if sharded:
         if update_rule == "hals" and (not deterministic or normalize[0]):
@@ -283,6 +366,8 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                 torch.cuda.synchronize(dev)
                 timer = time.time() - t0
             Ut = Ut_in.clone()                          # solve starts from U_in^T (nmf.py:415)
+            if before_u_solve is not None:
+                before_u_solve()
             if sharded:
                 eps, cnt, eps0 = _dist.sharded_hals_solve(eng, ws.VMt, ws.G, Ut, group, ws.guess_u,
                                                           budget=HALS_INNER["maxiter"], delta=HALS_INNER["delta"],
@@ -315,6 +400,8 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                 torch.cuda.synchronize(dev)
                 timer = time.time() - t0
             V = V_in.clone()                            # solve starts from V_in (nmf.py:440)
+            if before_v_solve is not None:
+                before_v_solve()
             _hals_call(eng, ws.UtM, ws.G2, V, sparsity_coefficients[1], normalize[1], deterministic, timer,
                        ws.block[8 * nstat:8 * nstat + 8])
             nstat += 1
@@ -329,21 +416,6 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             else:
                 V = eng.mu_right(X, Ut, V_in, beta)     # nmf.py:447
 
-    sp = [0 if s is None else s for s in sparsity_coefficients]
-    if update_rule == "hals":
-        eng.frob_resid(X, Ut, V, out=ws.cost)                     # nmf.py:452
-        if sharded:
-            _dist.allreduce_(ws.cost, group)
-        if sp[0] or sp[1]:
-            # matrix 1-norm (max column abs-sum, np.linalg.norm(., ord=1)) -- NOT the entry-wise l1 (nmf.py:452)
-            cs = Ut.abs().sum(dim=1).double()         # columns of U are rows of Ut
-            if sharded:
-                _dist.allreduce_(cs, group)
-            nU = cs.max()
-            nV = V.abs().sum(dim=0).max().double()
-            ws.cost.add_(2 * (sp[0] * nU + sp[1] * nV))
-    else:
-        eng.betadiv(X, Ut, V, beta, out=ws.cost)                  # nmf.py:455
-        if sharded:
-            _dist.allreduce_(ws.cost, group)
+    if not skip_cost:
+        _step_cost(eng, X, Ut, V, update_rule, beta, sparsity_coefficients, ws.cost, group)
     return Ut, V, nstat

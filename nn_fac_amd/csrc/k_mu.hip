@@ -259,15 +259,42 @@ __global__ __launch_bounds__(256) void nnf_mu_finish_kernel(const float* __restr
     }
 }
 
-// out[k] = sum_j A[k][j]  (fp64)
+// out[k] = sum_j A[k][j]  (fp64).  Long rows (the r x m factor: one workgroup per row took 112 us at m = 100000) are cut
+// into gridDim.y pieces whose partial sums (part[k][piece]) are added in piece order by a second, tiny launch.
 __global__ __launch_bounds__(256) void nnf_rowsum_kernel(const float* __restrict__ A, int64_t lda, int64_t K,
-                                                         double* __restrict__ out) {
+                                                         double* __restrict__ out, int64_t per) {
     __shared__ double red[4];
     const float* p = A + (int64_t)blockIdx.x * lda;
+    const int64_t j0 = (int64_t)blockIdx.y * per, j1 = (j0 + per < K) ? (j0 + per) : K;
     double s = 0.0;
-    for (int64_t j = threadIdx.x; j < K; j += 256) s += (double)p[j];
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) s += (double)p[j];
     const double t = nnf_block_sum_f64(s, red);
-    if (threadIdx.x == 0) out[blockIdx.x] = t;
+    if (threadIdx.x == 0) out[(int64_t)blockIdx.x * gridDim.y + blockIdx.y] = t;
+}
+__global__ __launch_bounds__(64) void nnf_rowsum_fin_kernel(const double* __restrict__ part, int np, int r,
+                                                            double* __restrict__ out) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= r) return;
+    double s = 0.0;
+    for (int i = 0; i < np; ++i) s += part[(int64_t)k * np + i];
+    out[k] = s;
+}
+// rowsum of an r x K matrix into out[r] on stream st; scratch from the cursor only when the rows are long
+static int nnf_launch_rowsum(nnf_ws_cursor& cur, const float* A, int64_t lda, int r, int64_t K, double* out, hipStream_t st) {
+    int np = (int)(K / 8192);
+    if (np > 64) np = 64;
+    if (np <= 1) {
+        hipLaunchKernelGGL(nnf_rowsum_kernel, dim3(r, 1), dim3(256), 0, st, A, lda, K, out, K);
+        NNF_CHECK_LAUNCH();
+        return NNF_OK;
+    }
+    double* part = (double*)cur.take((size_t)r * np * 8);
+    if (!part) return NNF_ERR_WORKSPACE;
+    hipLaunchKernelGGL(nnf_rowsum_kernel, dim3(r, np), dim3(256), 0, st, A, lda, K, part, nnf_cdiv(K, (int64_t)np));
+    NNF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nnf_rowsum_fin_kernel, dim3((r + 63) / 64), dim3(64), 0, st, part, np, r, out);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
 }
 
 // =========================================================================================================
@@ -467,6 +494,10 @@ static int launch_mu_right(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int
     const int64_t slab_elems = (int64_t)r * ldp;
     double* dvec = (double*)cur.take((size_t)r * 8);
     if (!dvec) return NNF_ERR_WORKSPACE;
+    if (BM == BM_KL) {  // den[k] = colsum(U)[k] = rowsum(Ut)[k]   (mu.py:86-87 on the transposed problem)
+        const int rc = nnf_launch_rowsum(cur, Ut, ldu, r, m, num_out ? den_vec_out : dvec, st);
+        if (rc != NNF_OK) return rc;
+    }
     const int64_t ws_max = (int64_t)(cur.remaining() / 4) / (slab_elems * nacc);
     if (ws_max < 1) return NNF_ERR_WORKSPACE;
     if (nsplit > ws_max) nsplit = ws_max;
@@ -484,10 +515,6 @@ static int launch_mu_right(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int
     const size_t shm = mu_shm(MT, r, BM == BM_KL);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_mu_right_kernel<MT, BM, VEC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    if (BM == BM_KL) {  // den[k] = colsum(U)[k] = rowsum(Ut)[k]   (mu.py:86-87 on the transposed problem)
-        hipLaunchKernelGGL(nnf_rowsum_kernel, dim3(r), dim3(256), 0, st, Ut, ldu, m, num_out ? den_vec_out : dvec);
-        NNF_CHECK_LAUNCH();
-    }
     const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * ncb;
     hipLaunchKernelGGL((nnf_mu_right_kernel<MT, BM, VEC>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
                        (float)beta, snum, sden, ldp, ncb, (int)nsplit, rps, a_vec_ok);
@@ -518,8 +545,8 @@ static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int6
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_mu_left_kernel<MT, BM, VEC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (BM == BM_KL) {  // den[k] = rowsum(V)[k]   (mu.py:86-87)
-        hipLaunchKernelGGL(nnf_rowsum_kernel, dim3(r), dim3(256), 0, st, V, ldv, n, dvec);
-        NNF_CHECK_LAUNCH();
+        const int rc = nnf_launch_rowsum(cur, V, ldv, r, n, dvec, st);
+        if (rc != NNF_OK) return rc;
     }
     const int grid = (int)nnf_cdiv(m, 256);
     hipLaunchKernelGGL((nnf_mu_left_kernel<MT, BM, VEC>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,

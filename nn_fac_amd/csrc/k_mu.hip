@@ -298,15 +298,17 @@ static int nnf_launch_rowsum(nnf_ws_cursor& cur, const float* A, int64_t lda, in
 }
 
 // =========================================================================================================
-// left update: workgroup = 256 rows of X (wave: 64 rows as four 16-row N tiles), sweeping all columns; no split.
+// left update: workgroup = 64*NT rows of X (wave: NT 16-row N tiles), sweeping all columns; no split.
 // =========================================================================================================
-template <int MT, int BM, bool VEC>
-__global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
-                                                             const float* __restrict__ Ut, int64_t ldu,
-                                                             const float* __restrict__ V, int64_t ldv, int r, float beta,
-                                                             const double* __restrict__ den_vec, float gamma,
-                                                             float* __restrict__ Ut_out, int64_t lduo, int a_vec_ok) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// NT = 16-row tiles per wave: a workgroup covers 64*NT rows starting at row0 (see nnf_xht_kernel for why the host mixes
+// workgroups of NTH and NTH-1 tiles: one balanced round of resident workgroups instead of 391 on 512 slots).
+template <int MT, int BM, bool VEC, int NT>
+__device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+                                                 const float* __restrict__ Ut, int64_t ldu,
+                                                 const float* __restrict__ V, int64_t ldv, int r, float beta,
+                                                 const double* __restrict__ den_vec, float gamma,
+                                                 float* __restrict__ Ut_out, int64_t lduo, int a_vec_ok, int64_t row0,
+                                                 char* smem) {
     const int KS = (r + 3) >> 2;
     constexpr bool REGF = (BM == BM_KL);                             // resident fragments in registers / in LDS
     f32x4* ldsUf = reinterpret_cast<f32x4*>(smem);                 // !REGF: [4][KS][64]: comps nt: Ut[4s+g][i0w+16nt+ii]
@@ -314,9 +316,9 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel
     f32x4* ldsK = ldsA + (size_t)2 * MT * 256;                       // [2][MT*256]  F_K image of the V chunk
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ii = lane & 15, g = lane >> 4;
-    const int64_t i0w = (int64_t)blockIdx.x * 256 + 64 * w;
+    const int64_t i0w = row0 + 16 * NT * w;
     int64_t rows = m - i0w;
-    if (rows > 64) rows = 64;
+    if (rows > 16 * NT) rows = 16 * NT;
     const uint32_t bytes = rows > 0 ? (uint32_t)(((rows - 1) * ldx + n) * 4) : 0u;
     const rsrc_t rs = nnf_make_rsrc(X + (rows > 0 ? i0w : 0) * ldx, bytes);
     const int voff = (int)(((int64_t)ii * ldx + 4 * g) * 4);
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (k < r) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
                     const int64_t i = i0w + 16 * nt + ii;
                     if (i < m) v[nt] = Ut[(int64_t)k * ldu + i];
                 }
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (k < r) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int64_t i = (int64_t)blockIdx.x * 256 + 64 * ww + 16 * nt + (L & 15);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int64_t i = row0 + 16 * NT * ww + 16 * nt + (L & 15);
                     if (i < m) v[nt] = Ut[(int64_t)k * ldu + i];
                 }
             }
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             num[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (BM == BM_GEN) den[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 64 * t);
+        for (int nt = 0; nt < NT; ++nt) xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 64 * t);
     stageA_direct<MT>(V, ldv, r, n, 0, a_vec_ok, ldsA);
     stageK<MT>(V, ldv, r, n, 0, ldsK);
     __syncthreads();
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel
             // MFMA #1 (transposed product): accP[nt][reg] = P[i0w+16nt+ii][64q+16t+4g+reg]
             f32x4 accP[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) accP[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NT; ++nt) accP[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s4 = 0; s4 < MT; ++s4) {
                 const f32x4 ak = imgK[(t * MT + s4) * 64 + lane];
@@ -393,14 +395,14 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel
                         if constexpr (REGF) bu = ufr[4 * s4 + c];
                         else bu = ldsUf[(size_t)w * KS * 64 + (4 * s4 + c) * 64 + lane];
 #pragma unroll
-                        for (int nt = 0; nt < 4; ++nt) accP[nt] = MFMA16(ak[c], bu[nt], accP[nt]);
+                        for (int nt = 0; nt < NT; ++nt) accP[nt] = MFMA16(ak[c], bu[nt], accP[nt]);
                     }
                 }
             }
             const int64_t colrem = n - (64 * (int64_t)q + 16 * t + 4 * g);
             f32x4 R1[4], R2[BM == BM_GEN ? 4 : 1];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 const bool rowok = (16 * nt + ii) < rows;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
@@ -420,12 +422,12 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
+                    for (int nt = 0; nt < NT; ++nt) {
                         num[mt][nt] = MFMA16(af[mt][reg], R1[nt][reg], num[mt][nt]);
                         if constexpr (BM == BM_GEN) den[mt][nt] = MFMA16(af[mt][reg], R2[nt][reg], den[mt][nt]);
                     }
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
                 xb[t & 1][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * q + 64 * (t + 2));
             if (t == 1) {
                 stageA_store<MT>(ldsA + (size_t)((q + 1) & 1) * MT * 256, sa);
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel
     }
     // epilogue: tile (mt, nt): rk = 16mt+4g+reg, i = i0w+16nt+ii
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         const int64_t i = i0w + 16 * nt + ii;
         if (i < m) {
 #pragma unroll
@@ -455,6 +457,22 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel
                 }
         }
     }
+}
+
+template <int MT, int BM, bool VEC>
+__global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+                                                             const float* __restrict__ Ut, int64_t ldu,
+                                                             const float* __restrict__ V, int64_t ldv, int r, float beta,
+                                                             const double* __restrict__ den_vec, float gamma,
+                                                             float* __restrict__ Ut_out, int64_t lduo, int a_vec_ok, int n_hi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = (int)blockIdx.x;
+    if (b < n_hi)
+        nnf_mu_left_body<MT, BM, VEC, 4>(X, m, n, ldx, Ut, ldu, V, ldv, r, beta, den_vec, gamma, Ut_out, lduo, a_vec_ok,
+                                         (int64_t)b * 256, smem);
+    else
+        nnf_mu_left_body<MT, BM, VEC, 3>(X, m, n, ldx, Ut, ldu, V, ldv, r, beta, den_vec, gamma, Ut_out, lduo, a_vec_ok,
+                                         (int64_t)n_hi * 256 + (int64_t)(b - n_hi) * 192, smem);
 }
 
 // beta = 2 (Gram form): out[k][j] = max(F[k][j] * num[k][j] / (sum_l G[k][l] F[l][j]), 1e-12)
@@ -548,9 +566,17 @@ static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int6
         const int rc = nnf_launch_rowsum(cur, V, ldv, r, n, dvec, st);
         if (rc != NNF_OK) return rc;
     }
-    const int grid = (int)nnf_cdiv(m, 256);
-    hipLaunchKernelGGL((nnf_mu_left_kernel<MT, BM, VEC>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
-                       (float)beta, dvec, gamma_of(beta), Ut_out, lduo, a_vec_ok);
+    // rows per workgroup: 256 everywhere, unless one round of resident workgroups covers the matrix with 3 to 4 row tiles
+    // per wave -- then n_hi workgroups of 256 rows and the rest of 192 fill exactly one round
+    const int64_t slots = (int64_t)(BM == BM_KL ? 2 : 1) * ctx->num_cus, T = nnf_cdiv(m, 16);
+    int64_t n_hi = nnf_cdiv(m, 256), grid = n_hi;
+    if (T > 12 * slots && T <= 16 * slots) {
+        n_hi = nnf_cdiv(T - 12 * slots, 4);
+        grid = slots;
+    }
+    if (n_hi * 256 + (grid - n_hi) * 192 < m) return NNF_ERR_UNSUPPORTED;   // (cannot happen)
+    hipLaunchKernelGGL((nnf_mu_left_kernel<MT, BM, VEC>), dim3((int)grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
+                       (float)beta, dvec, gamma_of(beta), Ut_out, lduo, a_vec_ok, (int)n_hi);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
 }

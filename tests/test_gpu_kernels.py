@@ -284,6 +284,28 @@ def test_mu_and_betadiv_kernels(eng, m, n, r, beta):
     assert abs(got - want) <= 2e-5 * abs(want)
 
 
+@pytest.mark.parametrize("m", [98304, 100000, 131072, 131100])
+@pytest.mark.parametrize("beta", [1, 0.5])
+def test_mu_left_row_tilings(eng, m, beta):
+    """The left MU update picks its rows-per-workgroup from m like X H^T (one balanced round of 256- and 192-row
+    workgroups when that covers the matrix, beta = 1): every branch against an fp64 evaluation of mu.py:84-97 on the device."""
+    n, r = 70, 50
+    g = torch.Generator(device="cuda").manual_seed(m)
+    Ut = torch.rand(r, m, device="cuda", generator=g) + 0.05
+    V = torch.rand(r, n, device="cuda", generator=g) + 0.05
+    X = (torch.rand(m, r, device="cuda", generator=g) @ torch.rand(r, n, device="cuda", generator=g)) + 0.05
+    U64, V64, X64 = Ut.double().t(), V.double(), X.double()
+    K = U64 @ V64
+    if beta == 1:
+        want = torch.clamp(U64 * ((X64 / K) @ V64.t() / V64.sum(dim=1)), min=1e-12)
+    else:
+        want = torch.clamp(U64 * ((K ** (beta - 2) * X64) @ V64.t() / (K ** (beta - 1) @ V64.t())) ** orc.gamma_beta(beta),
+                           min=1e-12)
+    got = eng.mu_left(X, Ut, V, beta).double().t()
+    assert float((got - want).norm() / want.norm()) < 2e-5
+    assert float(((got - want).abs() / want).max()) < 1e-3       # no row block missed or doubled
+
+
 def test_betadiv_near_convergence_has_no_cancellation(eng):
     """K ~ X: the naive fp32 form of KL/IS loses everything; the h(t) = t - log1p(t) form does not."""
     rng = np.random.RandomState(4)

@@ -86,8 +86,17 @@ class _NtdState:
         self.norm2 = eng.dot(self.t0, self.t0)          # float64 device scalar, ||T||^2 (read once by the driver)
         self.norm2_host = None
         self._unf_t = {}
-        # 3 HALS status blocks (8 doubles each) + 6 doubles of the core update + the cost
-        self.block = torch.zeros(8 * 3 + 8, dtype=torch.float64, device=T.device)
+        # 3 HALS status blocks (8 doubles each) + 6 doubles of the core update + the cost; two of them with pinned host
+        # mirrors: compute_ntd enqueues iteration i+1 before it looks at the block of iteration i
+        self.blocks = torch.zeros((2, 8 * 3 + 8), dtype=torch.float64, device=T.device)
+        self.host = torch.zeros((2, 8 * 3 + 8), dtype=torch.float64)
+        if T.is_cuda:
+            self.host = self.host.pin_memory()
+        self.select(0)
+
+    def select(self, slot):
+        self.slot = slot
+        self.block = self.blocks[slot]
 
     def unfolded_t(self, mode):
         """tl.unfold(T, mode)^T as a contiguous (prod(other dims)) x I_mode matrix (MU path).  The last mode is a view of T;
@@ -295,16 +304,20 @@ def compute_ntd(tensor_in, ranks, core_in, factors_in, n_iter_max=100, tol=1e-6,
         print("The core was asked NOT to be normalized, but mode_core_norm was set to a valid norm. Is this a mistake?")
     cost_fct_vals, toc = [], []
     tic = time.time()
-    for iteration in range(n_iter_max):
-        nstat = 0
-        if update_rule == "hals":
-            core, Ft, nstat = _one_ntd_step_dev(st, core, Ft, sparsity_coefficients, fixed_modes, normalize, mode_core_norm,
-                                                math.inf if deterministic else 0.5, 0.01)
-        elif update_rule == "mu":
-            core, Ft = _one_ntd_step_mu_dev(st, core, Ft, beta, fixed_modes, normalize, mode_core_norm)
-        else:
-            raise err.InvalidArgumentValue(f"The update rule provided is not valid. Please choose between 'hals' and 'mu' (Got {update_rule}).")
-        host = st.block.cpu()
+    if update_rule not in ("hals", "mu"):
+        raise err.InvalidArgumentValue(f"The update rule provided is not valid. Please choose between 'hals' and 'mu' (Got {update_rule}).")
+    cuda = st.T.is_cuda
+    main = torch.cuda.current_stream(st.T.device) if cuda else None
+    pending, stop = [], False
+    result = (core, Ft)
+
+    def retire():
+        """Host side of one finished iteration (ntd.py:410-428), one iteration behind the device."""
+        nonlocal result, stop
+        iteration, slot, core_i, Ft_i, nstat, ev = pending.pop(0)
+        if ev is not None:
+            ev.synchronize()
+        host = st.host[slot]
         cost = float(host[30])
         for i in range(nstat):
             if int(host[8 * i + _engine.ST_ERR]) != 0:
@@ -313,6 +326,7 @@ def compute_ntd(tensor_in, ranks, core_in, factors_in, n_iter_max=100, tol=1e-6,
             sweep_log.extend(int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(nstat))
         if pg_log is not None and update_rule == "hals":
             pg_log.append(int(host[24]))
+        result = (core_i, Ft_i)
         toc.append(time.time() - tic)
         cost_fct_vals.append(cost)
         if verbose:
@@ -328,7 +342,27 @@ def compute_ntd(tensor_in, ranks, core_in, factors_in, n_iter_max=100, tol=1e-6,
         if iteration > 0 and abs(cost_fct_vals[-2] - cost_fct_vals[-1]) < tol:
             if verbose:
                 print('Converged in {} iterations.'.format(iteration))
-            break
+            stop = True
+
+    for iteration in range(n_iter_max):
+        st.select(iteration % 2)
+        nstat = 0
+        if update_rule == "hals":
+            core, Ft, nstat = _one_ntd_step_dev(st, core, Ft, sparsity_coefficients, fixed_modes, normalize, mode_core_norm,
+                                                math.inf if deterministic else 0.5, 0.01)
+        else:
+            core, Ft = _one_ntd_step_mu_dev(st, core, Ft, beta, fixed_modes, normalize, mode_core_norm)
+        st.host[st.slot].copy_(st.block, non_blocking=cuda)
+        pending.append((iteration, st.slot, core, Ft, nstat, main.record_event() if cuda else None))
+        if len(pending) > 1:
+            retire()
+            if stop:
+                break
+    while pending and not stop:
+        retire()
+    if cuda and pending:
+        main.synchronize()
+    core, Ft = result
     core_out = like_input(core, core_in)
     factors = [like_input(f.t(), factors_in[i]) for i, f in enumerate(Ft)]
     if return_costs:

@@ -14,8 +14,12 @@ a chunk of C sweeps is executed blind (nnf_hals_sweeps_f32 records the local sum
 factor after every sweep), ONE all-reduce of the C partials follows, and the first sweep at which the reference would
 have stopped is located.  If that is not the last sweep of the chunk, the factor is taken from that sweep's snapshot
 (bitwise what a straight run would hold; the kernels are deterministic).  The chunk length follows the sweep count of
-the previous outer iteration, which changes slowly; the snapshot ring is sized for a whole solve (100 sweeps of an
-r x m_local factor: 2 GB at config B, 5 GB at E -- small change on a 288 GB device) so that a solve is normally one chunk.
+the previous outer iteration, which changes slowly, so a solve is normally one chunk and its stopping sweep falls in the
+chunk's last few sweeps.  Only those (`SweepGuess.window`, 8) are run with snapshots -- writing the factor out costs
+1.65 us per sweep next to an 8.6 us sweep at config B (tools/snap_probe.py) --; the sweeps before them run as a plain
+launch, with one copy of the factor taken at the start of the chunk.  A stop before the window (rare: the count dropped by
+more than the window since the previous outer iteration) restores that copy and re-runs exactly the right number of
+sweeps -- the kernels are deterministic, so the result is bitwise what a straight run would hold.
 """
 import torch
 import torch.distributed as dist
@@ -41,15 +45,17 @@ def shard_rows(m, rank, nranks):
 class SweepGuess:
     """Per-factor state of the sharded solve: chunk length memory and the reusable snapshot buffer."""
 
-    def __init__(self, first=16, max_chunk=104):
+    def __init__(self, first=16, max_chunk=104, window=8):
         self.value = first
         self.max_chunk = max_chunk
+        self.window = window
         self.snap = None
 
-    def snapshots(self, F, C):
-        if self.snap is None or self.snap.shape[0] < C or tuple(self.snap.shape[1:]) != tuple(F.shape) \
+    def snapshots(self, F, W):
+        if self.snap is None or self.snap.shape[0] < W or tuple(self.snap.shape[1:]) != tuple(F.shape) \
                 or self.snap.device != F.device or self.snap.dtype != F.dtype:
-            self.snap = torch.empty((max(C, min(self.max_chunk, 16)),) + tuple(F.shape), dtype=F.dtype, device=F.device)
+            self.snap = torch.empty((max(W, min(self.max_chunk, self.window)),) + tuple(F.shape), dtype=F.dtype,
+                                    device=F.device)
         return self.snap
 
 
@@ -57,17 +63,27 @@ def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01
     """In-place HALS on the local columns F (r x m_local) with the GLOBAL stopping rule.  Returns (eps, cnt, eps0) of
     the reference (cnt = sweeps + 1).  normalize / nonzero need row-level reductions across shards: not supported.
 
-    Chunks of C sweeps run blind; the kernel records every sweep's local sum of squared steps and a snapshot of F after
-    every sweep.  ONE all-reduce per chunk locates the sweep at which the reference stops; if that is before the end of the
-    chunk, F is restored from that sweep's snapshot (bitwise what a straight run would hold)."""
+    Chunks of C sweeps run blind; the kernel records every sweep's local sum of squared steps and, for the last
+    `guess.window` sweeps of the chunk, a snapshot of F after the sweep.  ONE all-reduce per chunk locates the sweep at which
+    the reference stops; if that is before the end of the chunk, F is restored from that sweep's snapshot, or -- before the
+    window -- from the copy taken at the start of the chunk followed by a re-run of exactly that many sweeps (both bitwise
+    what a straight run would hold)."""
     done, eps0, eps = 0, 0.0, 1.0
     if budget < 1:
         return 1.0, 1, 0.0
     C = max(1, min(int(guess.value), guess.max_chunk, budget))
     while done < budget:
         C = max(1, min(C, budget - done))
-        snap = guess.snapshots(F, C)
-        nd = eng.hals_sweeps(cross, gram, F, C, sparsity=sparsity, snapshots=snap)
+        W = max(1, min(C, int(guess.window)))
+        head = C - W
+        parts = []
+        F0 = None
+        if head > 0:
+            F0 = F.clone()
+            parts.append(eng.hals_sweeps(cross, gram, F, head, sparsity=sparsity))
+        snap = guess.snapshots(F, W)
+        parts.append(eng.hals_sweeps(cross, gram, F, W, sparsity=sparsity, snapshots=snap))
+        nd = torch.cat(parts) if len(parts) > 1 else parts[0]
         allreduce_(nd, group)
         ndh = nd.cpu().tolist()                    # one host round trip per chunk
         stop = None
@@ -82,8 +98,12 @@ def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01
             done += C
             C = min(guess.max_chunk, 2 * C)        # keep going with longer chunks
             continue
-        if stop < C - 1:                           # overshoot: take the snapshot after sweep stop+1
-            F.copy_(snap[stop])
+        if stop < C - 1:                           # overshoot
+            if stop >= head:                       # inside the window: the snapshot after sweep stop+1
+                F.copy_(snap[stop - head])
+            else:                                  # before it: start of the chunk + stop+1 sweeps again
+                F.copy_(F0)
+                eng.hals_sweeps(cross, gram, F, stop + 1, sparsity=sparsity)
         done += stop + 1
         break
     guess.value = max(8, min(done + 4, guess.max_chunk))

@@ -92,7 +92,7 @@ def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2
         V = torch.from_numpy(V0.copy())
         # the product's own buffers and outer loop (status ring, fused all-reduce of the V-side terms), engine double below
         eng, ws = OracleEngine(), nmf_mod._StepBuffers(Xl, r, dtype=torch.float64)
-        ws.guess_u = nd.SweepGuess(first=3, max_chunk=5)   # small on purpose: exercises continue, exact stop, overshoot
+        ws.guess_u = nd.SweepGuess(first=3, max_chunk=5, window=2)   # small on purpose: continue, exact stop, snapshot, replay
         costs, sweeps = [], []
 
         def retired(it, cost, sw):
@@ -174,3 +174,38 @@ def test_shard_rows_partition():
         assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
         sizes = [hi - lo for lo, hi in edges]
         assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("first,max_chunk,window", [(40, 64, 4), (3, 5, 2), (6, 8, 8), (100, 104, 8), (2, 3, 1)])
+@pytest.mark.parametrize("delta,budget", [(0.01, 100), (0.3, 100), (0.0, 7), (0.01, 1)])
+def test_chunked_solve_protocol_single_rank(first, max_chunk, window, delta, budget):
+    """dist.sharded_hals_solve on one rank (no process group): whatever the chunk length, the snapshot window and the
+    position of the stopping sweep -- in the window (snapshot), before it (copy + re-run), at the end of a chunk, in a later
+    chunk, at the sweep budget -- the result is the straight solve of nnls.py:156-196, bit for bit in the double."""
+    from nn_fac_amd import dist as nd
+    rng = np.random.RandomState(first * 7 + window)
+    r, n = 6, 50
+    U = rng.rand(80, r)
+    M = U @ rng.rand(r, n) + 1e-2 * rng.rand(80, n)
+    UtU, UtM, V0 = U.T @ U, U.T @ M, rng.rand(r, n)
+    want, eps, cnt, _ = orc.hals_nnls_acc(UtM, UtU, V0, maxiter=budget, alpha=math.inf, delta=delta)
+    calls = []
+
+    class Counting(OracleEngine):
+        def hals_sweeps(self, UtM, UtU, V, nsweeps, **kw):
+            calls.append((nsweeps, kw.get("snapshots") is not None))
+            return super().hals_sweeps(UtM, UtU, V, nsweeps, **kw)
+
+    F = torch.from_numpy(V0.copy())
+    guess = nd.SweepGuess(first=first, max_chunk=max_chunk, window=window)
+    e2, c2, _ = nd.sharded_hals_solve(Counting(), torch.from_numpy(UtM), torch.from_numpy(UtU), F, None, guess,
+                                      budget=budget, delta=delta)
+    assert c2 == cnt and np.array_equal(F.numpy(), want) and e2 == eps
+    assert all(ns <= window for ns, snapped in calls if snapped)          # only window-sized launches take snapshots
+    # a second call starts from the remembered count: one chunk, stop inside its window, no re-run
+    calls.clear()
+    F = torch.from_numpy(V0.copy())
+    nd.sharded_hals_solve(Counting(), torch.from_numpy(UtM), torch.from_numpy(UtU), F, None, guess, budget=budget, delta=delta)
+    assert np.array_equal(F.numpy(), want)
+    if cnt - 1 + 4 <= max_chunk and cnt - 1 >= 8:
+        assert len(calls) <= 2, calls

@@ -21,7 +21,7 @@ Xl = torch.from_numpy(X[lo:hi]).cuda()
 Ut = torch.from_numpy(U0[lo:hi].T.copy()).cuda()
 V = torch.from_numpy(V0).cuda()
 ws = nm._StepBuffers(Xl, r)
-ws.guess_u = nd.SweepGuess(first=4, max_chunk=6)
+ws.guess_u = nd.SweepGuess(first=4, max_chunk=6, window=3)
 costs, sweeps = [], []
 
 

@@ -519,8 +519,9 @@ __global__ __launch_bounds__(256) void nnf_gram_kernel(const float* __restrict__
 template <int MT>
 static int launch_gram(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
                        hipStream_t st) {
-    // few, long splits: the r x r slab reduction is serial in the split count and the operand is only r*K*4 bytes
-    int64_t nsplit = ctx->num_cus / 4 > 8 ? ctx->num_cus / 4 : 8;
+    // one split per CU (the slab reduction spreads every output element over up to 16 threads, so its cost grows slowly
+    // with the split count): 64 splits left a 50 x 100000 Gram at 22 us and a 100 x 125000 one at 127 us
+    int64_t nsplit = ctx->num_cus > 8 ? ctx->num_cus : 8;
     const int64_t max_split = nnf_cdiv(K, 64);
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;

@@ -189,3 +189,29 @@ def test_ntd_wall_clock_rule_runs_and_decreases():
     assert core.shape == tuple(ranks) and [f.shape for f in facs] == [(shape[i], ranks[i]) for i in range(3)]
     assert all(np.all(f >= 0) for f in facs) and np.all(core >= 0)
     assert costs[-1] < costs[0] and len(toc) == len(costs) == 6
+
+
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 1)])
+def test_ntd_early_stop_drops_the_speculative_iteration(built_lib, rule, beta):
+    """compute_ntd keeps one iteration in flight ahead of the stopping test: a stop at iteration k returns the core,
+    factors and costs of iteration k, bit for bit."""
+    from nn_fac_amd.ntd import compute_ntd
+    rng = np.random.RandomState(3)
+    shape, ranks = (20, 18, 16), (4, 3, 2)
+    F = [rng.rand(s, q) for s, q in zip(shape, ranks)]
+    T = (np.einsum('abc,ia,jb,kc->ijk', rng.rand(*ranks), *F) + 1e-2 * rng.rand(*shape)).astype(np.float32)
+    C0 = rng.rand(*ranks).astype(np.float32)
+    F0 = [rng.rand(s, q).astype(np.float32) for s, q in zip(shape, ranks)]
+    kw = dict(update_rule=rule, beta=beta, sparsity_coefficients=[None] * 4, normalize=[False] * 4, return_costs=True,
+              deterministic=True)
+    _, _, costs, _ = compute_ntd(T, ranks, C0, F0, n_iter_max=12, tol=0, **kw)
+    k = 5
+    tol = 0.5 * (abs(costs[k - 1] - costs[k]) + abs(costs[k] - costs[k + 1]))
+    first = next(i for i in range(1, len(costs)) if abs(costs[i - 1] - costs[i]) < tol)
+    Cs, Fs, cs, toc = compute_ntd(T, ranks, C0, F0, n_iter_max=12, tol=tol, **kw)
+    assert len(cs) == first + 1 == len(toc) and first < 11
+    Ck, Fk, ck, _ = compute_ntd(T, ranks, C0, F0, n_iter_max=first + 1, tol=0, **kw)
+    assert cs == ck == costs[:first + 1]
+    assert np.array_equal(Cs, Ck)
+    for a, b in zip(Fs, Fk):
+        assert np.array_equal(a, b)

@@ -101,3 +101,23 @@ def test_ntf_mid_size_vs_oracle(built_lib):
         assert rel(F[i], Fo[i]) < 2e-3
     np.testing.assert_allclose(costs, co, rtol=2e-3)
     assert sw == swo
+
+
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 1)])
+def test_ntf_early_stop_drops_the_speculative_iteration(built_lib, rule, beta):
+    """compute_ntf keeps one iteration in flight ahead of the stopping test (run_ntf_steps): a stop at iteration k returns
+    the factors and costs of iteration k, bit for bit."""
+    from nn_fac_amd.ntf import compute_ntf
+    T, F0 = orc.synth_ntf((30, 25, 20), 4, seed=5, dtype=np.float32)
+    kw = dict(update_rule=rule, beta=beta, alpha=math.inf, sparsity_coefficients=[None] * 3, normalize=[False] * 3,
+              return_costs=True)
+    _, costs, _ = compute_ntf(T, 4, F0, n_iter_max=12, tol=0, **kw)
+    k = 5
+    tol = 0.5 * (abs(costs[k - 1] - costs[k]) + abs(costs[k] - costs[k + 1]))
+    first = next(i for i in range(1, len(costs)) if abs(costs[i - 1] - costs[i]) < tol)
+    Fs, cs, toc = compute_ntf(T, 4, F0, n_iter_max=12, tol=tol, **kw)
+    assert len(cs) == first + 1 == len(toc) and first < 11
+    Fk, ck, _ = compute_ntf(T, 4, F0, n_iter_max=first + 1, tol=0, **kw)
+    assert cs == ck == costs[:first + 1]
+    for a, b in zip(Fs, Fk):
+        assert np.array_equal(a, b)

@@ -200,9 +200,12 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
       empty, and everything else of iteration i+1 depends on it.  The cost kernel's waves are small enough (<= 136 VGPRs)
       for a sweep wave to fit on a SIMD they fill, so the order in which the two get their CUs does not matter.  The main
       stream waits for that cost before it launches the next U-side solve (whose 1563 waves should find the chip free).
-      The host then looks at costs two iterations behind the device.  Single-GPU runs only: with the row-sharded step
-      (collectives + a second persistent kernel per iteration) the extra stream could only be rehearsed with two
-      processes sharing one GPU, where it was pathologically slow, so sharded runs keep the cost inside the step.
+      The host then looks at costs two iterations behind the device.  Row-sharded runs keep the cost inside the step
+      unless NNF_SHARDED_OVERLAP=1: the only multi-rank rehearsal available while this was written is two processes
+      sharing ONE GPU, and there two persistent sweep kernels (one per process) plus the extra cost kernels can each end
+      up partially resident and wait for the other's workgroups until the bounded spins expire (0.5 s per step).  With one
+      process per GPU there is only ever one persistent kernel per device and the cost kernel always drains, but that
+      configuration could not be measured here, so it is opt-in.
 
     `retired(iteration, cost, sweeps)` is called once per iteration, in order, and returns True when the loop has to stop
     (nmf.py:320-324); the factors returned are those of the iteration that stopped it -- each step writes fresh factor
@@ -210,7 +213,8 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
     (wall-clock rule, row-sharded solve) run through the same code."""
     cuda = X.is_cuda
     overlap = (cuda and update_rule == "hals" and 1 not in fixed_modes and isinstance(eng, _engine.Engine)
-               and ws.cost_stream is not None and _dist.world(group) == 1)
+               and ws.cost_stream is not None
+               and (_dist.world(group) == 1 or __import__("os").environ.get("NNF_SHARDED_OVERLAP") == "1"))
     depth = PIPELINE_DEPTH + (1 if overlap else 0)
     assert ws.blocks.shape[0] > depth
     pending = []          # steps not yet handed to `retired`: dicts {it, slot, Ut, V, nstat, ev}

@@ -195,6 +195,44 @@ __device__ __forceinline__ bool hals_collect1(const hals_sync& sy, int s, int nb
     return *lds_flag != 0u;
 }
 
+// block sum of this sweep's partial AND collect of an earlier sweep's global sum behind ONE barrier: both are "every wave
+// leaves a double in LDS, everybody adds the four up", so the two values of a wave travel together (red_p: two slot arrays
+// of the current sweep parity).  Returns the block sum in `bs` (every thread), the global sum of sweep c in `total`.
+__device__ __forceinline__ bool hals_sum_collect1(const hals_sync& sy, double nd, double& bs, int c, int nblocks, double& total,
+                                                  double* red_bs, double* red_tot, unsigned* lds_flag,
+                                                  const hals_prefetch& pf) {
+    const unsigned tag = sy.epoch * 1024u + (unsigned)c;
+    const unsigned long long* base = reinterpret_cast<const unsigned long long*>(sy.sslots) + (size_t)c * nblocks * 2;
+    double v = 0.0;
+    int i = 0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x, ++i) {
+        unsigned long long g0 = 0ull, g1 = 0ull;
+        if (pf.s == c) {
+#pragma unroll
+            for (int u = 0; u < HALS_PF; ++u)
+                if (u == i) { g0 = pf.g0[u]; g1 = pf.g1[u]; }
+        }
+        unsigned spins = 0;
+        while (!((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag)) {
+            if (spins > 0) __builtin_amdgcn_s_sleep(1);
+            if (++spins > HALS_SPIN_LIMIT) { *lds_flag = 0u; break; }
+            g0 = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g1 = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        v += __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xffffffffull));
+    }
+    v = nnf_wave_sum_f64(v);
+    nd = nnf_wave_sum_f64(nd);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { red_bs[w] = nd; red_tot[w] = v; }
+    __syncthreads();
+    double t = red_tot[0], b2 = red_bs[0];
+    for (int k = 1; k < nw; ++k) { t += red_tot[k]; b2 += red_bs[k]; }
+    total = t;
+    bs = b2;
+    return *lds_flag != 0u;
+}
+
 struct hals_args {
     const float* UtM; int64_t ldm;
     const float* Gp;      // padded Gram  RP x RP (zeros outside r x r), workspace

@@ -304,8 +304,18 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
             }
         }
         double bs;
-        if (RES && a.mode == 0) bs = hals_block_sum1(nd, red2[s & 1][0]);   // valid in every thread
-        else bs = nnf_block_sum_f64(nd, red);
+        bool merged = false;    // SPEC: this sweep's block sum and the collect of sweep s-1 share one barrier
+        double tot_m = 0.0;
+        if constexpr (RES && SPEC) {
+            if (a.mode == 0 && s >= 2) {
+                ok = hals_sum_collect1(a.sy, nd, bs, s - 1, nblocks, tot_m, red2[s & 1][0], red2[s & 1][1], &lds_flag, pf);
+                merged = true;
+            }
+        }
+        if (!merged) {
+            if constexpr (RES) bs = hals_block_sum1(nd, red2[s & 1][0]);   // valid in every thread; one barrier
+            else bs = nnf_block_sum_f64(nd, red);
+        }
         if (a.mode == 1) {
             if (threadIdx.x == 0) a.sweep_partials[(size_t)(s - 1) * nblocks + blockIdx.x] = bs;
             if constexpr (RES) {
@@ -323,7 +333,8 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
         const int c = SPEC ? s - 1 : s;         // sweep whose global sum is examined now
         if (c >= 1) {
             double tot;
-            if constexpr (RES) ok = hals_collect1(a.sy, c, nblocks, tot, red2[s & 1][1], &lds_flag, pf);
+            if (merged) tot = tot_m;
+            else if constexpr (RES) ok = hals_collect1(a.sy, c, nblocks, tot, red2[s & 1][1], &lds_flag, pf);
             else ok = hals_collect(a.sy, c, nblocks, tot, red, &lds_flag, &pf);
             if (!ok) break;
             if (c == 1) eps0 = tot;

@@ -195,6 +195,35 @@ __device__ __forceinline__ bool hals_collect1(const hals_sync& sy, int s, int nb
     return *lds_flag != 0u;
 }
 
+// Single-wave workgroups (k_hals_quad.hip): the same sum in the same order -- granules strided over the 64 lanes, DPP wave
+// sum -- with no LDS and no barrier at all.  Returns false on a time-out (wave-uniform).
+__device__ __forceinline__ bool hals_collect_wave(const hals_sync& sy, int s, int nblocks, double& total,
+                                                  const hals_prefetch* pf = nullptr) {
+    const unsigned tag = sy.epoch * 1024u + (unsigned)s;
+    const unsigned long long* base = reinterpret_cast<const unsigned long long*>(sy.sslots) + (size_t)s * nblocks * 2;
+    double v = 0.0;
+    bool late = false;
+    int i = 0;
+    for (int b = threadIdx.x; b < nblocks; b += 64, ++i) {
+        unsigned long long g0 = 0ull, g1 = 0ull;
+        if (pf != nullptr && pf->s == s) {
+#pragma unroll
+            for (int u = 0; u < HALS_PF; ++u)
+                if (u == i) { g0 = pf->g0[u]; g1 = pf->g1[u]; }
+        }
+        unsigned spins = 0;
+        while (!((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag)) {
+            if (spins > 0) __builtin_amdgcn_s_sleep(1);
+            if (++spins > HALS_SPIN_LIMIT) { late = true; break; }
+            g0 = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g1 = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        v += __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xffffffffull));
+    }
+    total = nnf_wave_sum_f64(v);
+    return __ballot(late) == 0ull;
+}
+
 // block sum of this sweep's partial AND collect of an earlier sweep's global sum behind ONE barrier: both are "every wave
 // leaves a double in LDS, everybody adds the four up", so the two values of a wave travel together (red_p: two slot arrays
 // of the current sweep parity).  Returns the block sum in `bs` (every thread), the global sum of sweep c in `total`.

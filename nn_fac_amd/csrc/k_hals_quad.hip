@@ -145,8 +145,6 @@ template <int CH>
 __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
     constexpr int RQ = 4 * CH, CHP = (CH + 3) & ~3, RS = 4 * CHP;
     extern __shared__ __attribute__((aligned(16))) float lg[];   // RQ * RS floats (dynamic: 64 KB at r = 128)
-    __shared__ double red[4];
-    __shared__ unsigned lds_flag;
     const int lane = threadIdx.x, q = lane & 3;
     const int nblocks = gridDim.x;
     const int64_t col = (int64_t)blockIdx.x * 16 + (lane >> 2);
@@ -205,7 +203,7 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
             f = 0.f;
             quad_rows_checked<CH, 0>::run(lg + q * CHP, v, b, own, nz_lo, nz_hi, f);
         }
-        const double bs = nnf_block_sum_f64(valid ? (double)f : 0.0, red);
+        const double bs = nnf_wave_sum_f64(valid ? (double)f : 0.0);   // the workgroup IS one wave: no LDS, no barrier
         if (a.mode == 1) {
             if (threadIdx.x == 0) a.sweep_partials[(size_t)(s - 1) * nblocks + blockIdx.x] = bs;
             if (a.snapshots != nullptr && valid) {   // V after sweep s (fire-and-forget stores)
@@ -221,7 +219,7 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
         const int c = s - 1;   // lag-one speculation (k_hals_fast.hip): sweep whose global sum is examined now
         if (c >= 1) {
             double tot;
-            ok = hals_collect(a.sy, c, nblocks, tot, red, &lds_flag, &pf);
+            ok = hals_collect_wave(a.sy, c, nblocks, tot, &pf);
             if (!ok) break;
             if (c == 1) eps0 = tot;
             eps = tot;
@@ -236,7 +234,7 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
     if (a.max_sweeps >= 1) store_col();
     if (a.mode == 0 && ok && !stopped && a.max_sweeps >= 1) {
         double tot;   // ran to the sweep budget: the last sweep's sum is still due
-        ok = hals_collect(a.sy, a.max_sweeps, nblocks, tot, red, &lds_flag);
+        ok = hals_collect_wave(a.sy, a.max_sweeps, nblocks, tot);
         if (ok) {
             if (a.max_sweeps == 1) eps0 = tot;
             eps = tot;

@@ -18,34 +18,29 @@
 #include <cstdlib>
 
 // prep: padded Gram, 1/diag, zeroed barrier words and status
+// One workgroup per Gram row (a single workgroup walked the 50 x 64 image in 13 dependent round trips: 11.5 us in front of
+// every solve); block 0 also writes the per-row pairs, the all-live flag, the barrier word and the status block.
 __global__ void nnf_hals_prep_kernel(const float* __restrict__ UtU, int64_t ldg, int r, int RP, float* __restrict__ Gp,
                                      float* __restrict__ dinv, float* __restrict__ Gs, unsigned* counter, double* status) {
     const int RS = 32 * ((RP + 31) / 32);      // row stride of the padded Gram (32-float blocks, k_hals_fast.hip)
-    for (int e = threadIdx.x; e < RP * RS; e += blockDim.x) {
-        const int a = e / RS, b = e - a * RS;
-        Gp[e] = (a < r && b < r) ? UtU[(int64_t)a * ldg + b] : 0.f;
+    const int a = blockIdx.x;                   // 0 .. RP-1
+    const float da = (a < r) ? UtU[(int64_t)a * ldg + a] : 0.f;
+    const float dia = (da != 0.f) ? (float)(1.0 / (double)da) : 0.f;
+    for (int b = threadIdx.x; b < RS; b += blockDim.x) {
+        const float g = (a < r && b < r) ? UtU[(int64_t)a * ldg + b] : 0.f;
+        Gp[a * RS + b] = g;
+        if (Gs) Gs[a * RS + b] = g * dia;      // rows scaled by 1/diag (rows with a zero diagonal: all zero), same padding
     }
+    if (blockIdx.x != 0) return;
     for (int k = threadIdx.x; k < RP; k += blockDim.x) {
         const float d = (k < r) ? UtU[(int64_t)k * ldg + k] : 0.f;
         dinv[2 * k] = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;   // pair (1/diag, nz): nz = 0 = leave the row alone
         dinv[2 * k + 1] = (d != 0.f) ? 1.f : 0.f;
     }
-    {   // all-live flag: no zero on the diagonal of the r x r Gram (r <= 128 < blockDim)
+    {   // all-live flag: no zero on the diagonal of the r x r Gram (r <= 128 <= blockDim)
         const int dead = (threadIdx.x < r) && (UtU[(int64_t)threadIdx.x * ldg + threadIdx.x] == 0.f);
         const int any_dead = __syncthreads_or(dead);
         if (threadIdx.x == 0) dinv[2 * RP] = any_dead ? 0.f : 1.f;
-    }
-    if (Gs) {   // rows scaled by 1/diag (rows with a zero diagonal: all zero), same padding
-        __shared__ float di_s[NNF_MAX_RANK];
-        for (int k = threadIdx.x; k < RP; k += blockDim.x) {
-            const float d = (k < r) ? UtU[(int64_t)k * ldg + k] : 0.f;
-            di_s[k] = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;
-        }
-        __syncthreads();
-        for (int e = threadIdx.x; e < RP * RS; e += blockDim.x) {
-            const int a = e / RS, b = e - a * RS;
-            Gs[e] = (a < r && b < r) ? UtU[(int64_t)a * ldg + b] * di_s[a] : 0.f;
-        }
     }
     if (threadIdx.x == 0) {
         *counter = 0u;
@@ -221,7 +216,7 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     if (!Gp || !dinv || !counter || !slots || !sslots || (MODE == 1 && !sweep_partials))
         return NNF_ERR_WORKSPACE;
     if (!quad) {
-        hipLaunchKernelGGL(nnf_hals_prep_kernel, dim3(1), dim3(256), 0, st, UtU, ldg, r, RP, Gp, dinv,
+        hipLaunchKernelGGL(nnf_hals_prep_kernel, dim3(RP), dim3(128), 0, st, UtU, ldg, r, RP, Gp, dinv,
                            want_gs ? Gp + gs_off : (float*)nullptr, counter, MODE == 0 ? status : (double*)nullptr);
         NNF_CHECK_LAUNCH();
         if (nsweeps == 0) return NNF_OK;

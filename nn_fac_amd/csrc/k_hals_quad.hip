@@ -33,19 +33,15 @@ __device__ __forceinline__ float dpp_quad(float x) {
 __global__ void nnf_hals_prep_quad_kernel(const float* __restrict__ UtU, int64_t ldg, int r, int CH, float* __restrict__ Gq,
                                           float* __restrict__ dinvq, unsigned* counter, double* status) {
     const int RQ = 4 * CH, CHP = (CH + 3) & ~3, RS = 4 * CHP;
-    __shared__ float di_s[NNF_MAX_RANK];
-    for (int k = threadIdx.x; k < RQ; k += blockDim.x) {
-        const float d = (k < r) ? UtU[(int64_t)k * ldg + k] : 0.f;
-        const float di = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;
-        di_s[k] = di;
-        dinvq[k] = di;
+    const int k = blockIdx.x;                   // one workgroup per image row, 0 .. RQ-1
+    const float d = (k < r) ? UtU[(int64_t)k * ldg + k] : 0.f;
+    const float di = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;
+    for (int c = threadIdx.x; c < RS; c += blockDim.x) {
+        const int q = c / CHP, jj = c - q * CHP, j = q * CH + jj;
+        Gq[k * RS + c] = (k < r && jj < CH && j < r) ? UtU[(int64_t)k * ldg + j] * di : 0.f;
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < RQ * RS; e += blockDim.x) {
-        const int k = e / RS, c = e - k * RS, q = c / CHP, jj = c - q * CHP, j = q * CH + jj;
-        Gq[e] = (k < r && jj < CH && j < r) ? UtU[(int64_t)k * ldg + j] * di_s[k] : 0.f;
-    }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) dinvq[k] = di;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         *counter = 0u;
         if (status) {
             status[NNF_HALS_ST_EPS] = 1.0;
@@ -348,7 +344,7 @@ int nnf_hals_quad_run(nnf_ctx* ctx, const float* UtU, int64_t ldg, float* Gq, un
     const int ch = quad_ch(a.r), rq = 4 * ch, rs = 4 * ((ch + 3) & ~3);
     if (ch == 0) return NNF_ERR_UNSUPPORTED;
     float* dinvq = Gq + (size_t)rq * rs;
-    hipLaunchKernelGGL(nnf_hals_prep_quad_kernel, dim3(1), dim3(256), 0, st, UtU, ldg, a.r, ch, Gq, dinvq, counter,
+    hipLaunchKernelGGL(nnf_hals_prep_quad_kernel, dim3(4 * ch), dim3(64), 0, st, UtU, ldg, a.r, ch, Gq, dinvq, counter,
                        a.mode == 0 ? a.status : (double*)nullptr);
     NNF_CHECK_LAUNCH();
     if (a.max_sweeps == 0) return NNF_OK;

@@ -164,18 +164,25 @@ class _StepBuffers:
 
 
 
-def _gram_on_side(ws, eng, A, out):
-    """eng.gram(A, out=out) overlapped with whatever the caller launches next on the current stream; returns the event the
-    current stream has to wait on before `out` is used (None: ran inline -- CPU test doubles, buffers without a side stream)."""
+def _gram_on_side(ws, eng, A, out, start_from=None):
+    """eng.gram(A, out=out) overlapped with whatever the caller launches next on the current stream.  With `start_from` the
+    copy the following solve works on (nmf.py:415/440: the solve starts from a copy of the current factor) is made on the
+    side stream as well, instead of between the streaming kernel and the solve (a 20 MB copy + two dispatch gaps on the
+    critical path at config B).  Returns (event the current stream has to wait on before `out` / the copy are used -- None:
+    everything ran inline (CPU test doubles, buffers without a side stream) --, the copy or None)."""
     side = getattr(ws, "side_stream", None)
     if side is None or not isinstance(eng, _engine.Engine):
         eng.gram(A, out=out)
-        return None
-    ready = torch.cuda.current_stream(A.device).record_event()
+        return None, (start_from.clone() if start_from is not None else None)
+    main = torch.cuda.current_stream(A.device)
+    copy = torch.empty_like(start_from) if start_from is not None else None    # allocated in the main stream's pool
+    ready = main.record_event()
     with torch.cuda.stream(side):
         side.wait_event(ready)
+        if copy is not None:
+            copy.copy_(start_from)
         ws.side_eng.gram(A, out=out)
-        return side.record_event()
+        return side.record_event(), copy
 
 
 def _raise_on_status(host, nstat):
@@ -362,14 +369,13 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             if not deterministic:
                 torch.cuda.synchronize(dev)
                 t0 = time.time()
-            done = _gram_on_side(ws, eng, V, ws.G)      # VVt  (nmf.py:407)
+            done, Ut = _gram_on_side(ws, eng, V, ws.G, start_from=Ut_in)   # VVt (nmf.py:407); solve starts from U_in^T (:415)
             eng.xht(X, V, out=ws.VMt)                   # VMt  (nmf.py:408)
             if done is not None:
                 torch.cuda.current_stream(dev).wait_event(done)
             if not deterministic:
                 torch.cuda.synchronize(dev)
                 timer = time.time() - t0
-            Ut = Ut_in.clone()                          # solve starts from U_in^T (nmf.py:415)
             if before_u_solve is not None:
                 before_u_solve()
             if sharded:
@@ -390,7 +396,7 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             if not deterministic:
                 torch.cuda.synchronize(dev)
                 t0 = time.time()
-            done = _gram_on_side(ws, eng, Ut, ws.G2)    # UtU  (nmf.py:432)
+            done, V = _gram_on_side(ws, eng, Ut, ws.G2, start_from=V_in)   # UtU (nmf.py:432); solve starts from V_in (:440)
             eng.xty(X, Ut, out=ws.UtM)                  # UtM  (nmf.py:433)
             if done is not None:
                 torch.cuda.current_stream(dev).wait_event(done)
@@ -403,7 +409,6 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             if not deterministic:
                 torch.cuda.synchronize(dev)
                 timer = time.time() - t0
-            V = V_in.clone()                            # solve starts from V_in (nmf.py:440)
             if before_v_solve is not None:
                 before_v_solve()
             _hals_call(eng, ws.UtM, ws.G2, V, sparsity_coefficients[1], normalize[1], deterministic, timer,

@@ -78,13 +78,16 @@ enum { NNF_COST_FROB = 0, NNF_COST_KL = 1, NNF_COST_IS = 2, NNF_COST_GEN = 3,
 __device__ __forceinline__ float nnf_ln(float x) { return 0.69314718056f * __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float nnf_pow(float x, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x)); }
 
-__device__ __forceinline__ float nnf_h(float t) {
-    // small |t|: alternating series (no cancellation); otherwise t - ln(1+t) directly (no cancellation left to fear)
+// h(t) = t - log1p(t) with q = 1 + t handed over separately: callers form q as a plain ratio (>= 0 by construction),
+// because 1 + (a-b)/b can round to a tiny NEGATIVE number when a << b (data entries of 1e-12 next to a model of order 1:
+// the clamped zeros of an NNDSVD start, multilayer NMF's inner layers) and the logarithm then returns NaN.
+__device__ __forceinline__ float nnf_h(float t, float q) {
+    // small |t|: alternating series (no cancellation); otherwise t - ln(q) directly (no cancellation left to fear)
     float s = 1.f / 14.f;
 #pragma unroll
     for (int k = 11; k >= 0; --k) s = fmaf(s, -t, 1.f / (float)(k + 2));
     const float series = t * t * s;
-    const float direct = t - nnf_ln(1.f + t);
+    const float direct = t - nnf_ln(q);
     return fabsf(t) < 0.25f ? series : direct;
 }
 
@@ -94,16 +97,20 @@ __device__ __forceinline__ float nnf_cost_term(float x, float p, float beta) {
         const float d = x - p;
         return d * d;
     } else if constexpr (OP == NNF_COST_KL) {
-        return x > 0.f ? x * nnf_h((p - x) * __builtin_amdgcn_rcpf(x)) : p;
+        const float rx = __builtin_amdgcn_rcpf(x);
+        return x > 0.f ? x * nnf_h((p - x) * rx, p * rx) : p;
     } else if constexpr (OP == NNF_COST_IS) {
-        return nnf_h((x - p) * __builtin_amdgcn_rcpf(p));
+        const float rp = __builtin_amdgcn_rcpf(p);
+        return nnf_h((x - p) * rp, x * rp);
     } else {
-        const float u = (x - p) * __builtin_amdgcn_rcpf(p);
+        const float rp = __builtin_amdgcn_rcpf(p);
+        const float u = (x - p) * rp;
         float s = 1.f;
 #pragma unroll
         for (int k = 16; k >= 3; --k) s = fmaf(s, (beta - (float)(k - 1)) * u * (1.f / (float)k), 1.f);
         const float series = 0.5f * u * u * s;
-        const float direct = (nnf_pow(1.f + u, beta) - 1.f - beta * u) / (beta * (beta - 1.f));
+        // (1+u)^beta from the ratio x/p itself (>= 0), not from 1 + u (see nnf_h); beta > 0 here, so 0^beta = 0
+        const float direct = (nnf_pow(x * rp, beta) - 1.f - beta * u) / (beta * (beta - 1.f));
         const float phi = fabsf(u) < 0.3f ? series : direct;
         return nnf_pow(p, beta) * phi;
     }

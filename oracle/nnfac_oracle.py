@@ -374,6 +374,41 @@ def nmf(data, rank, init="random", U_0=None, V_0=None, n_iter_max=100, tol=1e-8,
 
 
 # --------------------------------------------------------------------------------------
+# f4: multilayer beta-NMF (nn_fac/multilayer_nmf.py:7-51) and its scaling (nn_fac/utils/normalize_wh.py:6-22)
+# --------------------------------------------------------------------------------------
+def normalize_WH(W, H, matrix):
+    if matrix == "H":
+        scalH = np.sum(H, axis=1)
+        return W @ np.diag(scalH), np.diag(1 / scalH) @ H
+    if matrix == "W":
+        scalW = np.sum(W, axis=0)
+        return W @ np.diag(1 / scalW), np.diag(scalW) @ H
+    raise ValueError(f"Matrix must be either 'W' or 'H', but it is {matrix}")
+
+
+def multilayer_beta_NMF(data, all_ranks, beta=1, n_iter_max_each_nmf=100, init_each_nmf="nndsvd", deterministic=False,
+                        seed=0):
+    """multilayer_nmf.py:7-44: layer 0 on the data, layer i on W[i-1]; each layer = nmf(mu, beta) + normalize_WH(.,"H")
+    (:46-51).  Returns W, H, errors (L x n_iter_max_each_nmf)."""
+    if deterministic:
+        np.random.seed(seed)
+    L = len(all_ranks)
+    if sorted(all_ranks, reverse=True) != all_ranks:
+        raise ValueError("The ranks of deep NMF should be decreasing.")
+    W, H = [None] * L, [None] * L
+    errors = np.empty((L, n_iter_max_each_nmf))
+    cur = data
+    for i in range(L):
+        Wi, Hi, costs, _ = nmf(cur, all_ranks[i], init=init_each_nmf, n_iter_max=n_iter_max_each_nmf, tol=1e-8,
+                               update_rule="mu", beta=beta, normalize=[False, True], return_costs=True,
+                               deterministic=deterministic, seed=seed)
+        W[i], H[i] = normalize_WH(Wi, Hi, "H")
+        errors[i] = np.array(costs)
+        cur = W[i]
+    return W, H, errors
+
+
+# --------------------------------------------------------------------------------------
 # tensorly 0.6.0 semantics used by ntf.py (published behaviour; see SURVEY.md appendix B)
 # --------------------------------------------------------------------------------------
 def unfold(t, mode):

@@ -306,6 +306,22 @@ def test_mu_left_row_tilings(eng, m, beta):
     assert float(((got - want).abs() / want).max()) < 1e-3       # no row block missed or doubled
 
 
+@pytest.mark.parametrize("beta", [0, 0.5, 1, 1.5, 3])
+def test_betadiv_with_tiny_data_entries(eng, beta):
+    """Data entries of 1e-12 next to a model of order 1 (the clamped zeros of an NNDSVD start, the inner layers of
+    multilayer NMF): 1 + (x-p)/p rounds to a tiny negative number in fp32 and a logarithm of it is NaN -- the terms are
+    formed from the ratio x/p instead."""
+    rng = np.random.RandomState(7)
+    m, n, r = 300, 130, 6
+    U, V = rng.rand(m, r) + 0.1, rng.rand(r, n) + 0.1
+    X = U @ V * (1 + 0.1 * rng.randn(m, n)).clip(0.5, 1.5)
+    X[rng.rand(m, n) < 0.2] = 1e-12
+    X32, U32, V32 = (a.astype(np.float32).astype(np.float64) for a in (X, U, V))
+    want = orc.beta_divergence(X32, U32 @ V32, beta)
+    got = float(eng.betadiv(dev(X32), dev(U32.T), dev(V32), beta))
+    assert np.isfinite(got) and abs(got - want) <= 5e-5 * abs(want), (beta, got, want)
+
+
 def test_betadiv_near_convergence_has_no_cancellation(eng):
     """K ~ X: the naive fp32 form of KL/IS loses everything; the h(t) = t - log1p(t) form does not."""
     rng = np.random.RandomState(4)

@@ -216,3 +216,22 @@ def test_nmf_and_ntf_with_nndsvd_init(built_lib):
     Fo = orc.ntf_nndsvd_init(T, 4)
     for a, b in zip(F, Fo):
         assert rel(a, b) < 1e-8
+
+
+@pytest.mark.parametrize("beta", [1, 2, 0.5])
+def test_multilayer_nmf_against_reference_fixture(golden, built_lib, beta):
+    """multilayer_beta_NMF (multilayer_nmf.py:7-51: NNDSVD start on the device, MU layers, normalize_WH) vs the real
+    reference's outputs (g9): MU tolerances of SURVEY 8c, widened for three chained factorisations."""
+    from nn_fac_amd.multilayer_nmf import multilayer_beta_NMF
+    g = golden("g9_multilayer.npz")
+    ranks = [int(x) for x in g["ranks"]]
+    W, H, errors, toc = multilayer_beta_NMF(g["data"].copy(), list(ranks), beta=beta, n_iter_max_each_nmf=int(g["n_iter"]),
+                                            return_errors=True, deterministic=True, seed=int(g["seed"]))
+    assert len(W) == len(H) == len(toc) == 3 and errors.shape == (3, int(g["n_iter"]))
+    for i in range(3):
+        assert isinstance(W[i], np.ndarray) and W[i].shape == g[f"b{beta}_W{i}"].shape
+        assert rel(W[i], g[f"b{beta}_W{i}"]) < 2e-4 and rel(H[i], g[f"b{beta}_H{i}"]) < 2e-4, (i, beta)
+        np.testing.assert_allclose(H[i].sum(axis=1), 1.0, rtol=1e-5)
+    np.testing.assert_allclose(errors, g[f"b{beta}_errors"], rtol=2e-4)
+    with pytest.raises(ValueError):
+        multilayer_beta_NMF(g["data"], [4, 8], n_iter_max_each_nmf=2)

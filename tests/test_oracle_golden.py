@@ -88,6 +88,22 @@ def test_g8_hals_coupling(golden):
         orc.hals_coupling_nnls_acc(r.rand(8, 8), G, r.rand(8, 8), r.rand(8, 8), 1.0, nonzero=True)
 
 
+def test_g9_multilayer(golden):
+    """multilayer_nmf.py:7-51 (NNDSVD start, MU layers, normalize_WH): outputs of the real reference, oracle/gen_golden_g9.py."""
+    g = golden("g9_multilayer.npz")
+    ranks = [int(x) for x in g["ranks"]]
+    for beta in (1, 2, 0.5):
+        W, H, errors = orc.multilayer_beta_NMF(g["data"].copy(), list(ranks), beta=beta, n_iter_max_each_nmf=int(g["n_iter"]),
+                                               deterministic=True, seed=int(g["seed"]))
+        for i in range(len(ranks)):
+            np.testing.assert_allclose(W[i], g[f"b{beta}_W{i}"], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(H[i], g[f"b{beta}_H{i}"], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(H[i].sum(axis=1), 1.0, rtol=1e-12)       # normalize_WH(., "H")
+        np.testing.assert_allclose(errors, g[f"b{beta}_errors"], rtol=1e-10)
+    with pytest.raises(ValueError):
+        orc.multilayer_beta_NMF(g["data"], [4, 8], n_iter_max_each_nmf=2)
+
+
 def test_hals_argument_errors():
     r = np.random.RandomState(0)
     with pytest.raises(orc.ArgumentException):

@@ -23,6 +23,13 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _ld(t):
+    """Leading dimension (elements) of a 2-D tensor for the C ABI.  PyTorch leaves the stride of a size-1 dimension
+    arbitrary (a 1 x m factor -- rank 1 -- can report stride(0) == 1); with a single row it is never used to address
+    anything, so any value >= the row length is valid."""
+    return t.stride(0) if t.shape[0] > 1 else max(int(t.stride(0)), int(t.shape[1]))
+
+
 def _chk2d(t, name):
     if t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
         raise EngineError(f"{name}: expected a 2-D float32 device tensor with unit inner stride, got "
@@ -58,7 +65,7 @@ class Engine:
         _chk2d(A, "gram A")
         r, K = A.shape
         G = out if out is not None else torch.empty((r, r), dtype=torch.float32, device=A.device)
-        _lib.check(self.lib.nnf_gram_f32(self.ctx, _ptr(A), r, K, A.stride(0), _ptr(G), G.stride(0), self._stream()),
+        _lib.check(self.lib.nnf_gram_f32(self.ctx, _ptr(A), r, K, _ld(A), _ptr(G), _ld(G), self._stream()),
                    "nnf_gram_f32")
         return G
 
@@ -70,8 +77,8 @@ class Engine:
         if V.shape[1] != n:
             raise EngineError("xht: shape mismatch")
         O = out if out is not None else torch.empty((r, m), dtype=torch.float32, device=X.device)
-        _lib.check(self.lib.nnf_xht_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(V), r, V.stride(0), _ptr(O),
-                                        O.stride(0), self._stream()), "nnf_xht_f32")
+        _lib.check(self.lib.nnf_xht_f32(self.ctx, _ptr(X), m, n, _ld(X), _ptr(V), r, _ld(V), _ptr(O),
+                                        _ld(O), self._stream()), "nnf_xht_f32")
         return O
 
     def xty(self, X, Ut, out=None):
@@ -82,8 +89,8 @@ class Engine:
         if Ut.shape[1] != m:
             raise EngineError("xty: shape mismatch")
         O = out if out is not None else torch.empty((r, n), dtype=torch.float32, device=X.device)
-        _lib.check(self.lib.nnf_xty_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), r, Ut.stride(0), _ptr(O),
-                                        O.stride(0), self._stream()), "nnf_xty_f32")
+        _lib.check(self.lib.nnf_xty_f32(self.ctx, _ptr(X), m, n, _ld(X), _ptr(Ut), r, _ld(Ut), _ptr(O),
+                                        _ld(O), self._stream()), "nnf_xty_f32")
         return O
 
     def frob_resid(self, X, Ut, V, out=None):
@@ -94,14 +101,14 @@ class Engine:
         if Ut.shape[1] != m or V.shape != (r, n):
             raise EngineError("frob_resid: shape mismatch")
         o = out if out is not None else torch.empty(1, dtype=torch.float64, device=X.device)
-        _lib.check(self.lib.nnf_frob_resid_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
-                                               V.stride(0), r, _ptr(o), self._stream()), "nnf_frob_resid_f32")
+        _lib.check(self.lib.nnf_frob_resid_f32(self.ctx, _ptr(X), m, n, _ld(X), _ptr(Ut), _ld(Ut), _ptr(V),
+                                               _ld(V), r, _ptr(o), self._stream()), "nnf_frob_resid_f32")
         return o
 
     def dot(self, A, B):
         _chk2d(A, "dot A"), _chk2d(B, "dot B")
         o = torch.empty(1, dtype=torch.float64, device=A.device)
-        _lib.check(self.lib.nnf_dot_f32(self.ctx, _ptr(A), A.stride(0), _ptr(B), B.stride(0), A.shape[0], A.shape[1],
+        _lib.check(self.lib.nnf_dot_f32(self.ctx, _ptr(A), _ld(A), _ptr(B), _ld(B), A.shape[0], A.shape[1],
                                         _ptr(o), self._stream()), "nnf_dot_f32")
         return o
 
@@ -132,8 +139,8 @@ class Engine:
         if UtM.shape != (r, ncols) or UtU.shape[0] < r or UtU.shape[1] < r:
             raise EngineError("hals_solve: shape mismatch")
         st = status if status is not None else torch.empty(ST_WORDS, dtype=torch.float64, device=V.device)
-        _lib.check(self.lib.nnf_hals_solve_f32(self.ctx, _ptr(UtM), UtM.stride(0), _ptr(UtU), UtU.stride(0), _ptr(V),
-                                               V.stride(0), r, ncols, int(max_sweeps), float(delta),
+        _lib.check(self.lib.nnf_hals_solve_f32(self.ctx, _ptr(UtM), _ld(UtM), _ptr(UtU), _ld(UtU), _ptr(V),
+                                               _ld(V), r, ncols, int(max_sweeps), float(delta),
                                                float(sparsity or 0.0),
                                                self._hals_flags(sparsity, normalize, nonzero), _ptr(st),
                                                self._stream()), "nnf_hals_solve_f32")
@@ -151,8 +158,8 @@ class Engine:
                     or snapshots.shape[0] < nsweeps or tuple(snapshots.shape[1:]) != (r, ncols)):
                 raise EngineError("hals_sweeps: snapshots must be a contiguous float32 [>= nsweeps, r, ncols] tensor")
             sp, ss = _ptr(snapshots), snapshots.stride(0)
-        _lib.check(self.lib.nnf_hals_sweeps_f32(self.ctx, _ptr(UtM), UtM.stride(0), _ptr(UtU), UtU.stride(0), _ptr(V),
-                                                V.stride(0), r, ncols, int(nsweeps), float(sparsity or 0.0),
+        _lib.check(self.lib.nnf_hals_sweeps_f32(self.ctx, _ptr(UtM), _ld(UtM), _ptr(UtU), _ld(UtU), _ptr(V),
+                                                _ld(V), r, ncols, int(nsweeps), float(sparsity or 0.0),
                                                 self._hals_flags(sparsity, normalize, nonzero), _ptr(nd), sp, ss,
                                                 self._stream()), "nnf_hals_sweeps_f32")
         return nd[:int(nsweeps)]
@@ -169,9 +176,9 @@ class Engine:
         kl = float(beta) == 1.0
         R1 = torch.empty((m, n), dtype=torch.float32, device=X.device)
         R2 = None if kl else torch.empty((m, n), dtype=torch.float32, device=X.device)
-        _lib.check(self.lib.nnf_mu_ratio_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
-                                             V.stride(0), r, float(beta), _ptr(R1), _ptr(R2) if R2 is not None else None,
-                                             R1.stride(0), self._stream()), "nnf_mu_ratio_f32")
+        _lib.check(self.lib.nnf_mu_ratio_f32(self.ctx, _ptr(X), m, n, _ld(X), _ptr(Ut), _ld(Ut), _ptr(V),
+                                             _ld(V), r, float(beta), _ptr(R1), _ptr(R2) if R2 is not None else None,
+                                             _ld(R1), self._stream()), "nnf_mu_ratio_f32")
         if side == "left":
             num = self.xht(R1, V)
             den = None if kl else self.xht(R2, V)
@@ -190,8 +197,8 @@ class Engine:
             num, den, dvec = self._mu_large_rank(X, Ut, V, beta, "left")
             return self.mu_apply(Ut, num, den, dvec, beta, out=out)
         O = out if out is not None else torch.empty_like(Ut)
-        _lib.check(self.lib.nnf_mu_left_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
-                                            V.stride(0), r, float(beta), _ptr(O), O.stride(0), self._stream()),
+        _lib.check(self.lib.nnf_mu_left_f32(self.ctx, _ptr(X), m, n, _ld(X), _ptr(Ut), _ld(Ut), _ptr(V),
+                                            _ld(V), r, float(beta), _ptr(O), _ld(O), self._stream()),
                    "nnf_mu_left_f32")
         return O
 
@@ -203,8 +210,8 @@ class Engine:
             num, den, dvec = self._mu_large_rank(X, Ut, V, beta, "right")
             return self.mu_apply(V, num, den, dvec, beta, out=out)
         O = out if out is not None else torch.empty_like(V)
-        _lib.check(self.lib.nnf_mu_right_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
-                                             V.stride(0), r, float(beta), _ptr(O), O.stride(0), self._stream()),
+        _lib.check(self.lib.nnf_mu_right_f32(self.ctx, _ptr(X), m, n, _ld(X), _ptr(Ut), _ld(Ut), _ptr(V),
+                                             _ld(V), r, float(beta), _ptr(O), _ld(O), self._stream()),
                    "nnf_mu_right_f32")
         return O
 
@@ -219,10 +226,10 @@ class Engine:
         num = torch.empty((r, n), dtype=torch.float32, device=X.device)
         den = torch.empty((r, n), dtype=torch.float32, device=X.device) if float(beta) != 1.0 else None
         dvec = torch.empty(r, dtype=torch.float64, device=X.device) if float(beta) == 1.0 else None
-        _lib.check(self.lib.nnf_mu_right_accum_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
-                                                   V.stride(0), r, float(beta), _ptr(num), num.stride(0),
+        _lib.check(self.lib.nnf_mu_right_accum_f32(self.ctx, _ptr(X), m, n, _ld(X), _ptr(Ut), _ld(Ut), _ptr(V),
+                                                   _ld(V), r, float(beta), _ptr(num), _ld(num),
                                                    _ptr(den) if den is not None else None,
-                                                   den.stride(0) if den is not None else 0,
+                                                   _ld(den) if den is not None else 0,
                                                    _ptr(dvec) if dvec is not None else None, self._stream()),
                    "nnf_mu_right_accum_f32")
         return num, den, dvec
@@ -232,11 +239,11 @@ class Engine:
         _chk2d(F, "mu F"), _chk2d(num, "mu num")
         r, cols = F.shape
         O = out if out is not None else torch.empty_like(F)
-        _lib.check(self.lib.nnf_mu_apply_f32(self.ctx, _ptr(F), F.stride(0), r, cols, _ptr(num), num.stride(0),
+        _lib.check(self.lib.nnf_mu_apply_f32(self.ctx, _ptr(F), _ld(F), r, cols, _ptr(num), _ld(num),
                                              _ptr(den) if den is not None else None,
-                                             den.stride(0) if den is not None else 0,
+                                             _ld(den) if den is not None else 0,
                                              _ptr(den_vec) if den_vec is not None else None, float(beta), _ptr(O),
-                                             O.stride(0), self._stream()), "nnf_mu_apply_f32")
+                                             _ld(O), self._stream()), "nnf_mu_apply_f32")
         return O
 
     def set_probe(self, ev_begin=None, ev_end=None):
@@ -258,7 +265,7 @@ class Engine:
         r = Ft.shape[0]
         shape = (r, J, K) if mode == 0 else ((I, r, K) if mode == 1 else (r, I, J))
         out = torch.empty(shape, dtype=torch.float32, device=T.device)
-        _lib.check(self.lib.nnf_ttm3_f32(self.ctx, _ptr(T), I, J, K, _ptr(Ft), Ft.stride(0), r, int(mode), _ptr(out),
+        _lib.check(self.lib.nnf_ttm3_f32(self.ctx, _ptr(T), I, J, K, _ptr(Ft), _ld(Ft), r, int(mode), _ptr(out),
                                          self._stream()), "nnf_ttm3_f32")
         return out
 
@@ -281,8 +288,8 @@ class Engine:
         m, n = X.shape
         r = Ut.shape[0]
         o = out if out is not None else torch.empty(1, dtype=torch.float64, device=X.device)
-        _lib.check(self.lib.nnf_betadiv_f32(self.ctx, _ptr(X), m, n, X.stride(0), _ptr(Ut), Ut.stride(0), _ptr(V),
-                                            V.stride(0), r, float(beta), _ptr(o), self._stream()), "nnf_betadiv_f32")
+        _lib.check(self.lib.nnf_betadiv_f32(self.ctx, _ptr(X), m, n, _ld(X), _ptr(Ut), _ld(Ut), _ptr(V),
+                                            _ld(V), r, float(beta), _ptr(o), self._stream()), "nnf_betadiv_f32")
         return o
 
     def mttkrp3(self, T, Ft, mode, out=None):
@@ -294,9 +301,9 @@ class Engine:
         I, J, K = T.shape
         R = Ft[0].shape[0]
         O = out if out is not None else torch.empty((R, T.shape[mode]), dtype=torch.float32, device=T.device)
-        _lib.check(self.lib.nnf_mttkrp3_f32(self.ctx, _ptr(T), I, J, K, _ptr(Ft[0]), Ft[0].stride(0), _ptr(Ft[1]),
-                                            Ft[1].stride(0), _ptr(Ft[2]), Ft[2].stride(0), R, int(mode), _ptr(O),
-                                            O.stride(0), self._stream()), "nnf_mttkrp3_f32")
+        _lib.check(self.lib.nnf_mttkrp3_f32(self.ctx, _ptr(T), I, J, K, _ptr(Ft[0]), _ld(Ft[0]), _ptr(Ft[1]),
+                                            _ld(Ft[1]), _ptr(Ft[2]), _ld(Ft[2]), R, int(mode), _ptr(O),
+                                            _ld(O), self._stream()), "nnf_mttkrp3_f32")
         return O
 
 
@@ -307,8 +314,8 @@ class Engine:
         I, J, K = T.shape
         R = Ft[0].shape[0]
         o = out if out is not None else torch.empty(1, dtype=torch.float64, device=T.device)
-        _lib.check(self.lib.nnf_cp3_betadiv_f32(self.ctx, _ptr(T), I, J, K, _ptr(Ft[0]), Ft[0].stride(0), _ptr(Ft[1]),
-                                                Ft[1].stride(0), _ptr(Ft[2]), Ft[2].stride(0), R, float(beta), _ptr(o),
+        _lib.check(self.lib.nnf_cp3_betadiv_f32(self.ctx, _ptr(T), I, J, K, _ptr(Ft[0]), _ld(Ft[0]), _ptr(Ft[1]),
+                                                _ld(Ft[1]), _ptr(Ft[2]), _ld(Ft[2]), R, float(beta), _ptr(o),
                                                 self._stream()), "nnf_cp3_betadiv_f32")
         return o
 

@@ -235,3 +235,20 @@ def test_multilayer_nmf_against_reference_fixture(golden, built_lib, beta):
     np.testing.assert_allclose(errors, g[f"b{beta}_errors"], rtol=2e-4)
     with pytest.raises(ValueError):
         multilayer_beta_NMF(g["data"], [4, 8], n_iter_max_each_nmf=2)
+
+
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 1), ("mu", 0.5), ("mu", 2)])
+@pytest.mark.parametrize("m,n", [(97, 130), (64, 1), (2, 130)])
+def test_rank_one(built_lib, rule, beta, m, n):
+    """Rank 1: the transposed factor is a 1 x m tensor, whose row stride PyTorch leaves arbitrary (found by
+    tools/stress_parity.py: the C ABI refused ld < cols)."""
+    from nn_fac_amd.nmf import compute_nmf
+    rng = np.random.RandomState(m + n)
+    X = (rng.rand(m, 1) @ rng.rand(1, n) + 1e-2 * rng.rand(m, n)).astype(np.float32)
+    U0, V0 = rng.rand(m, 1).astype(np.float32) + 0.01, rng.rand(1, n).astype(np.float32) + 0.01
+    kw = dict(n_iter_max=4, tol=0, update_rule=rule, beta=beta, return_costs=True, deterministic=True)
+    U, V, costs, _ = compute_nmf(X, 1, U0, V0, **kw)
+    Uo, Vo, co, _ = orc.compute_nmf(X.astype(np.float64), 1, U0.astype(np.float64), V0.astype(np.float64), **kw)
+    assert rel(U, Uo) < HALS_FRO and rel(V, Vo) < HALS_FRO
+    # (n = 1: a rank-1 model fits a single column exactly, the cost is rounding noise in either precision)
+    np.testing.assert_allclose(costs, co, rtol=HALS_COST, atol=1e-9 * float(np.sum(X.astype(np.float64) ** 2)))

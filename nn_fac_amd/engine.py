@@ -31,7 +31,8 @@ def _ld(t):
 
 
 def _chk2d(t, name):
-    if t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
+    # (the stride of a size-1 dimension is arbitrary in PyTorch: a k x 1 tensor need not report stride(1) == 1)
+    if t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or (t.shape[1] > 1 and t.stride(1) != 1):
         raise EngineError(f"{name}: expected a 2-D float32 device tensor with unit inner stride, got "
                           f"{tuple(t.shape)} {t.dtype} {t.device} strides {t.stride()}")
     return t

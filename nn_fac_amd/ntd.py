@@ -203,10 +203,12 @@ def _one_ntd_step_dev(st, core_in, Ft_in, sparsity_coefficients, fixed_modes, no
     cost = st.block[30:31]
     if normalize[-1]:
         core = _normalize_core(core, mode_core_norm)
-        full = _core_mode_dots(core, grams)
-        cost.copy_((st.norm2 - 2 * (all_MtX.double() * core.double()).sum() + (full.double() * core.double()).sum()).reshape(1))
-    else:
-        cost.copy_(pg[4:5])
+    # ||T - core x_0 F_0 x_1 F_1 x_2 F_2||^2.  The reference evaluates it in the Gram form ||T||^2 - 2<MtX, core> + <MtM core,
+    # core> (ntd.py:635-639) in fp64; with fp32 contractions that form is good to ~1e-7 ||T||^2, which is the size of the cost
+    # itself for a near-exact fit (tools/stress_tensor.py: 1e-2 ... 2e-1 relative error on normalised costs of 1e-6).  One
+    # streaming pass over T against the mode-0 matrix form (the cost kernel, product never materialised) is exact to ~1e-6
+    # relative and costs ~1 % of the iteration.
+    eng.frob_resid(st.t0, Ft[0], _core_expand_mode0(core, Ft), out=cost)
     sparsity_error = None
     for index, sp in enumerate(sparsity_coefficients):
         if sp:

@@ -121,3 +121,20 @@ def test_ntf_early_stop_drops_the_speculative_iteration(built_lib, rule, beta):
     assert cs == ck == costs[:first + 1]
     for a, b in zip(Fs, Fk):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape,R", [((7, 1, 5), 3), ((17, 5, 1), 1), ((6, 5, 4), 1), ((1, 33, 2), 4)])
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 1), ("mu", 2)])
+def test_ntf_degenerate_dimensions(built_lib, shape, R, rule, beta):
+    """Modes of length 1 and rank 1: k x 1 and 1 x k operands, whose size-1 stride PyTorch leaves arbitrary (found by
+    tools/stress_tensor.py: the boundary refused them)."""
+    from nn_fac_amd.ntf import compute_ntf
+    T, F0 = orc.synth_ntf(shape, R, seed=sum(shape) + R, dtype=np.float32)
+    kw = dict(n_iter_max=3, tol=0, update_rule=rule, beta=beta, alpha=math.inf, sparsity_coefficients=[None] * 3,
+              normalize=[False] * 3, return_costs=True)
+    F, costs, _ = compute_ntf(T, R, F0, **kw)
+    Fo, co, _ = orc.compute_ntf(T.astype(np.float64), R, [f.astype(np.float64) for f in F0], **kw)
+    for a, b in zip(F, Fo):
+        assert a.shape == b.shape and rel(a, b) < 5e-4
+    assert np.all(np.isfinite(costs))
+    np.testing.assert_allclose(costs, co, rtol=2e-3, atol=1e-7)

@@ -21,8 +21,12 @@ for c in range(cases):
     kind = ["ntf", "ntd", "nnls", "coupling"][rng.randint(4)]
     try:
         if kind == "ntf":
-            shape = tuple(int(rng.choice([1, 2, 5, 16, 17, 33, 64, 70])) for _ in range(3))
+            shape = [int(rng.choice([2, 5, 16, 17, 33, 64, 70])) for _ in range(3)]
+            if rng.rand() < 0.3:
+                shape[rng.randint(3)] = 1                      # at most one mode of length 1
+            shape = tuple(shape)
             R = int(rng.choice([1, 2, 3, 7, 16, 17, 30, 64]))
+            R = min(R, 2 * min(s_ for s_ in shape if s_ > 1))  # far more components than rows: nothing is identifiable
             rule, beta = [("hals", 2), ("mu", 1), ("mu", 2), ("mu", 0.5)][rng.randint(4)]
             T, F0 = orc.synth_ntf(shape, R, seed=c, dtype=np.float32)
             kw = dict(n_iter_max=3, tol=0, update_rule=rule, beta=beta, alpha=math.inf, sparsity_coefficients=[None] * 3,
@@ -30,7 +34,7 @@ for c in range(cases):
             F, costs, _ = compute_ntf(T, R, F0, **kw)
             Fo, co, _ = orc.compute_ntf(T.astype(np.float64), R, [f.astype(np.float64) for f in F0], **kw)
             e = max(rel(a, b) for a, b in zip(F, Fo))
-            ec = max(abs(a - b) / max(abs(b), 1e-30) for a, b in zip(costs, co))
+            ec = max(abs(a - b) / max(abs(b), 1e-6) for a, b in zip(costs, co))   # normalised costs: 1e-6 = an exact fit
             if not np.all(np.isfinite(costs)) or e > 2e-3 or ec > 5e-3:
                 flag("NTF", (shape, R, rule, beta), f"rel {e:.1e} cost {ec:.1e}")
         elif kind == "ntd":
@@ -60,6 +64,9 @@ for c in range(cases):
             if kind == "nnls":
                 if rng.rand() < 0.4:
                     kw["sparsity_coefficient"] = float(rng.rand() * 0.2)
+                if rng.rand() < 0.3:
+                    kw["nonzero"] = True
+                    UtM = UtM - 0.6 * np.abs(UtM).max() * (rng.rand(r, 1) < 0.3)    # some rows are driven to zero
                 V, eps, cnt, _ = hals_nnls_acc(UtM, UtU, V0, **kw)
                 Vo, epso, cnto, _ = orc.hals_nnls_acc(UtM, UtU, V0, **kw)
             else:

@@ -266,14 +266,14 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
     const int voff0 = gtid < a.ncols ? (int)(gtid * 4) : (int)0x7ffffff0;
     if constexpr (RES) load_col(voff0);
     // Sweep loop.  mode 1: fixed count, per-sweep local partials, nothing to decide.
-    // mode 0, resident columns, RP <= 56: lag-one speculation.  After sweep s the workgroup publishes its partial and goes
+    // mode 0, resident columns, RP <= 64 (240 VGPRs at RP = 64, no spills): lag-one speculation.  After sweep s the workgroup publishes its partial and goes
     // straight on to sweep s+1 in registers; only then does it collect the global sum of sweep s (published by every
     // workgroup a whole sweep ago, its granule loads issued a sweep ago: the wait is normally free).  If that sum says
     // "stop" (nnls.py:156) the registers hold one sweep too many and V is taken from a register copy made before the
     // sweep; V is written to memory once, at the end.  Cost: one wasted sweep at the end instead of a stall per sweep.
     // Larger ranks have no registers for the copy; storing V after every confirmed sweep instead costs more than it saves
     // (125000 x 100: 100 vs 45 us per sweep), so they -- and the strided mode -- wait for the sum of the sweep just done.
-    constexpr bool BACKUP = RES && RP <= 56;
+    constexpr bool BACKUP = RES && RP <= 64;
     constexpr bool SPEC = BACKUP;
     f32x2 vb[BACKUP ? RP / 2 : 1];
 

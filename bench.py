@@ -1,69 +1,181 @@
 #!/usr/bin/env python3
-"""bench.py -- HALS NMF outer iterations/s on the MI355X engine (BASELINE.json metric).
+"""bench.py -- outer iterations/s of the MI355X inner-update engine on BASELINE.json's configurations.
 
-    python bench.py --gpus N --steps K --warmup W [--rule hals|mu] [--no-cpu] [--no-fixed]
+    python bench.py --gpus N --steps K --warmup W [--config B|C|D|E] [--no-cpu] [--no-fixed] [--no-extra]
 
-One "step" = one outer NMF iteration (nn_fac.nmf.one_nmf_step semantics: U update, V update, cost) on synthetic dense
-data already resident in HBM.  N = 1: configs[1] of BASELINE.json, 100000 x 2000 rank 50, HALS, fp32, deterministic
-(alpha = inf, delta = 0.01, maxiter = 100).  N > 1 (torchrun, one rank per GPU, RCCL): the data matrix is row-sharded,
-every rank holds a 100000 x 2000 block of an (N*100000) x 2000 matrix (weak scaling); the r x r Gram and r x n cross term
-are all-reduced.  `value` counts 100000-row blocks processed per second = N * iterations/s, so it is
-the whole-job aggregate and equals iterations/s at N = 1.
+One "step" = one outer iteration (nn_fac one_nmf_step / one_ntf_step semantics: every factor update + the cost) on
+synthetic dense data already resident in HBM when the timed region starts.
 
-The JSON line also carries
-  roofline     -- the dominant kernel (nnf_xty_kernel, "W^T X"): algorithmic flops 2*r*m*n per launch / its mean launch
-                  duration, measured live with HIP events recorded on the launch stream right around the kernel (probe hook
-                  of the C ABI), against the dense fp32 MFMA peak (157.3 TFLOP/s);
-  cpu_baseline -- the NumPy restatement of the reference (oracle/, kind "port") timed on this box's host cores on a
-                  bounded sample of the same workload -- 4 iterations of the full-size problem -- (rank 0, N = 1 only).
+  B (default)  100000 x 2000 rank 50 NMF, HALS, fp32, deterministic (alpha = inf, delta = 0.01, maxiter = 100) -- configs[1],
+               the configuration BASELINE.json's metric is quoted on.  N > 1: X row-sharded, one 100000 x 2000 block per
+               rank (weak scaling), RCCL all-reduce of the r x r Gram and r x n cross term;
+               value = N * iterations/s = 100000-row blocks per second.
+  C            same data, MU beta = 1 (configs[2]).
+  D            500^3 rank-30 NTF, HALS, alpha = inf (configs[3]).  N > 1: leading mode sharded, one 500^3 block per rank.
+  E            1e6 x 4000 rank 100 NMF, HALS (configs[4]): the SAME 1e6-row problem split over the N ranks (strong scaling;
+               N = 1 holds all 16 GB).  Generated on the device in 8 row blocks of 125000 with per-block seeds, so every
+               N factorises identical data.  The default (B) line carries a short E measurement under "extra_configs".
+
+--gpus N > 1 without a torchrun environment: this process starts N ranks itself (python -m torch.distributed.run, one per
+GPU, RCCL) BEFORE it touches the GPU, relays rank 0's JSON line and exits with the child's code.  Under torchrun
+(WORLD_SIZE set) it is one of the ranks.  NNF_BENCH_BACKEND=gloo runs the ranks over gloo (ranks may then share devices:
+a rehearsal, not a measurement).
+
+The JSON line carries
+  roofline      -- the dominant streaming kernel of the configuration (B/E: nnf_xty_kernel "W^T X"; C: nnf_mu_left_kernel;
+                   D: the MTTKRP kernels): algorithmic flops or bytes per launch / mean launch duration, measured live
+                   with HIP events recorded by the library on the launch stream right around that kernel;
+  roofline_more -- the same for the other kernels of the step (the HALS sweep kernels against the fp32 VALU peak, X H^T,
+                   the cost kernels, ...);
+  cpu_baseline  -- the NumPy restatement of the reference (oracle/, kind "port") timed on this box's host cores on a
+                   bounded sample of the same workload: the SAME X and the factors the GPU's timed region started from
+                   (rank 0, N = 1 only).
 """
 import argparse
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-M, N, R = 100000, 2000, 50
-MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, "Peak FP32 (matrix)" = the fp32 vector peak
 HBM_PEAK_GBS = 8000.0
 
+CONFIGS = {
+    "B": dict(kind="nmf", rule="hals", beta=2, m=100000, n=2000, r=50, scaling="weak", ref="configs[1]"),
+    "C": dict(kind="nmf", rule="mu", beta=1, m=100000, n=2000, r=50, scaling="weak", ref="configs[2]"),
+    "D": dict(kind="ntf", rule="hals", beta=2, m=500, n=500, r=30, scaling="weak", ref="configs[3]"),
+    "E": dict(kind="nmf", rule="hals", beta=2, m=1000000, n=4000, r=100, scaling="strong", ref="configs[4]"),
+}
+E_BLOCKS = 8            # config E is generated in 8 row blocks of m/8 rows (per-shard seeds)
 
-def synth_on_device(m, n, r, seed, device):
-    """X = W*H* + 1e-2*rand (strictly positive), U0, V0 -- same recipe as SURVEY.md 8d, generated in HBM."""
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS))
+    ap.add_argument("--rule", default=None, choices=["hals", "mu"], help="alias: --rule mu = --config C")
+    ap.add_argument("--beta", type=float, default=None)
+    ap.add_argument("--shape", default=None, help="m,n,r override (tests / rehearsals; the line then says so)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-fixed", action="store_true", help="skip the fixed-work line (profiling runs)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-E leg of the default line")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline probes")
+    args = ap.parse_args(argv)
+    if args.config is None:
+        args.config = "C" if args.rule == "mu" else "B"
+    return args
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 outside torchrun: start N fresh ranks (nothing in this process has touched the GPU), relay their
+    output and return the launcher's exit code.  Never an exec: this process stays the parent."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---- synthetic inputs --------------------------------------------------------------------------------
+def synth_nmf_host(m, n, r, seed):
+    """X = W*H* + 1e-2*rand (strictly positive), U0, V0 from one legacy RandomState(seed) stream, fp32 -- the recipe the CPU
+    baseline leg reads too (same arrays, not a re-generation)."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    W, H = rng.rand(m, r), rng.rand(r, n)
+    X = (W @ H + 1e-2 * rng.rand(m, n)).astype(np.float32)
+    return X, rng.rand(m, r).astype(np.float32), rng.rand(r, n).astype(np.float32)
+
+
+def synth_ntf_host(I, R, seed):
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    A, B, C = (rng.rand(I, R) for _ in range(3))
+    kr = (A[:, None, :] * B[None, :, :]).reshape(-1, R)
+    T = (kr @ C.T).reshape(I, I, I)
+    T += 1e-2 * rng.rand(I, I, I)
+    return T.astype(np.float32), [rng.rand(I, R).astype(np.float32) for _ in range(3)]
+
+
+def synth_nmf_block_device(rows, n, r, seed, hseed, device, torch):
+    """One row block of a device-generated problem (config E: its 16 GB never exist on the host): rows of W*, the noise and
+    U0 from the block's own seed, H* from `hseed` (the same for every block of a problem)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    W = torch.rand(m, r, device=device, generator=g)
-    H = torch.rand(r, n, device=device, generator=g)
+    W = torch.rand(rows, r, device=device, generator=g)
+    H = torch.rand(r, n, device=device, generator=torch.Generator(device=device).manual_seed(hseed))
     X = W @ H
-    X += 1e-2 * torch.rand(m, n, device=device, generator=g)
-    U0 = torch.rand(m, r, device=device, generator=g)
-    V0 = torch.rand(r, n, device=device, generator=g)
-    return X, U0, V0
+    X += 1e-2 * torch.rand(rows, n, device=device, generator=g)
+    U0 = torch.rand(rows, r, device=device, generator=g)
+    return X, U0
 
 
-def time_kernel(fn, reps, stream):
-    """Mean duration (ms) of `fn` launches, HIP events recorded on the launch stream."""
-    for _ in range(2):
-        fn()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    stream.synchronize()
-    e0.record(stream)
-    for _ in range(reps):
-        fn()
-    e1.record(stream)
-    e1.synchronize()
-    return e0.elapsed_time(e1) / reps
+# ---- CPU baseline ---------------------------------------------------------------------------------------------------
+def cpu_baseline_nmf(X, U, V, r, rule, beta, gpu_sweeps):
+    """Bounded sample of the same workload through the CPU oracle (the reference's statement sequence): the same X, starting
+    from the factors the GPU's timed region started from.  fp32 on all host threads (the headline), fp64 (the reference's
+    default dtype) and a 1-thread figure on a row sample."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nnfac_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        threadpool_limits, threads = None, os.cpu_count() or 1
+    m, n = X.shape
+
+    def run(Xd, Ud, Vd, its):
+        sw = []
+        t0 = time.time()
+        for _ in range(its):
+            log = []
+            Ud, Vd, _ = orc.one_nmf_step(Xd, r, Ud, Vd, None, rule, beta, [None, None], [], [False, False], True,
+                                         sweeps=log) if rule == "hals" else \
+                orc.one_nmf_step(Xd, r, Ud, Vd, None, rule, beta, [None, None], [], [False, False], True)
+            sw.append(log)
+        return (time.time() - t0) / its, sw
+
+    its = 3
+    dt32, sw32 = run(X, U, V, its)
+    out = {"value": 1.0 / dt32, "unit": "iterations/s", "cores": int(threads), "kind": "port",
+           "sample": f"{its} iterations of one_nmf_step ({rule}, beta={beta:g}) on the full {m}x{n} rank-{r} fp32 problem: "
+                     f"the same X as the GPU leg, starting from the factors its timed region started from; "
+                     f"NumPy/OpenBLAS threads={threads}",
+           "inner_sweeps": sw32, "gpu_inner_sweeps_same_iterations": gpu_sweeps[:its]}
+    dt64, _ = run(X.astype(np.float64), U.astype(np.float64), V.astype(np.float64), 1)
+    out["fp64"] = {"value": 1.0 / dt64, "sample": "1 iteration, same start, float64 (the reference's default dtype)"}
+    if threadpool_limits is not None:
+        ms = max(1000, m // 16)
+        with threadpool_limits(limits=1):
+            dt1, _ = run(X[:ms], U[:ms], V, 1)
+        out["one_thread"] = {"value": 1.0 / (dt1 * m / ms), "cores": 1,
+                             "sample": f"1 iteration on the first {ms} rows (1/{m // ms} of the workload), time scaled by "
+                                       f"{m / ms:.1f}"}
+    return out
 
 
-def cpu_baseline(rule, beta):
-    """Bounded sample of the same workload through the CPU oracle (the reference's statement sequence)."""
+def cpu_baseline_ntf(T, F, R):
+    import numpy as np
+    import math
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nnfac_oracle as orc
     try:
@@ -71,181 +183,370 @@ def cpu_baseline(rule, beta):
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
     except Exception:
         threads = os.cpu_count() or 1
-    ms = M                                       # the full 100000-row workload: ~10-20 s of CPU work on the GPU box's host
-    X, U0, V0 = orc.synth_nmf(ms, N, R, seed=0, dtype=np.float32)
-    U, V = U0, V0
-    U, V, _ = orc.one_nmf_step(X, R, U, V, None, rule, beta, [None, None], [], [False, False], True)   # warm-up
+    unf = [orc.unfold(T, k) for k in range(3)]
+    nrm = float(np.linalg.norm(T.astype(np.float64)))
+    its = 2
     t0 = time.time()
-    its = 4
     for _ in range(its):
-        U, V, _ = orc.one_nmf_step(X, R, U, V, None, rule, beta, [None, None], [], [False, False], True)
+        F, _ = orc.one_ntf_step(unf, R, F, nrm, "hals", 2, [None] * 3, [], [False] * 3, alpha=math.inf)
     dt = (time.time() - t0) / its
     return {"value": 1.0 / dt, "unit": "iterations/s", "cores": int(threads), "kind": "port",
-            "sample": f"{its} iterations (after 1 warm-up) of one_nmf_step on the full {ms}x{N} rank-{R} fp32 problem, "
-                      f"same synthetic recipe; NumPy/OpenBLAS threads={threads}"}
+            "sample": f"{its} iterations of one_ntf_step (hals, alpha=inf) on the full {T.shape} rank-{R} fp32 tensor: the "
+                      f"same tensor as the GPU leg, starting from the factors its timed region started from; "
+                      f"NumPy/OpenBLAS threads={threads}"}
+
+
+# ---- the ranks -------------------------------------------------------------------------------------------------------
+class Ctx:
+    """World / device plumbing of one rank."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = None
+        factory = os.environ.get("NNF_BENCH_ENGINE")      # tests: "module:attr" of an engine double (CPU tensors)
+        self.cuda = factory is None
+        # NNF_BENCH_INIT_PG=1: initialise the process group even for a single rank (1-rank RCCL smoke on a one-GPU box)
+        self.pg = self.world > 1 or (os.environ.get("NNF_BENCH_INIT_PG") == "1" and "MASTER_ADDR" in os.environ)
+        if self.pg:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            self.backend = os.environ.get("NNF_BENCH_BACKEND", "nccl")
+            if self.backend == "nccl":
+                ndev = torch.cuda.device_count()
+                if self.local_rank >= ndev:
+                    raise SystemExit(f"bench.py: rank {self.rank} has no GPU of its own ({ndev} visible); RCCL needs one "
+                                     f"device per rank (NNF_BENCH_BACKEND=gloo rehearses on shared devices)")
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{self.local_rank}"))
+            else:
+                if self.cuda:
+                    torch.cuda.set_device(self.local_rank % max(1, torch.cuda.device_count()))
+                dist.init_process_group(backend=self.backend)
+        elif self.cuda:
+            torch.cuda.set_device(0)
+        self.device = torch.device(f"cuda:{torch.cuda.current_device()}") if self.cuda else torch.device("cpu")
+        self.group = dist.group.WORLD if self.world > 1 else None
+        if factory is None:
+            from nn_fac_amd.engine import get_engine
+            self.eng = get_engine(self.device)
+            self.dtype = torch.float32
+        else:
+            mod, attr = factory.split(":")
+            self.eng = getattr(importlib.import_module(mod), attr)()
+            self.dtype = torch.float64
+
+    def barrier(self):
+        if self.pg:
+            self.dist.barrier()
+        if self.cuda:
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        if self.pg:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t)
+        return dt
+
+    def timed(self, fn):
+        self.barrier()
+        t0 = time.perf_counter()
+        out = fn()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0), out
+
+
+class NmfRun:
+    """The product's own outer loop (nn_fac_amd.nmf.run_steps = the `for iteration` loop of compute_nmf) on one rank's
+    row block; every iteration's cost + status block is read back and handed to a recorder that never stops."""
+
+    def __init__(self, cx, X, Ut, V, r, rule, beta):
+        from nn_fac_amd import nmf as nmf_mod
+        self.cx, self.mod = cx, nmf_mod
+        self.X, self.Ut, self.V, self.r, self.rule, self.beta = X, Ut, V, r, rule, beta
+        self.ws = nmf_mod._StepBuffers(X, r, dtype=cx.dtype)
+        self.sweeps, self.cost = [], None
+
+    def run(self, k):
+        def retired(it, cost, sw):
+            self.sweeps.append(sw)
+            self.cost = cost
+            return False
+        self.Ut, self.V = self.mod.run_steps(self.cx.eng, self.ws, self.X, self.r, self.Ut, self.V, k, self.rule, self.beta,
+                                             [None, None], [], [False, False], True, retired, group=self.cx.group)
+        return self.cost
+
+    def measure(self, warmup, steps):
+        self.run(warmup)
+        self.sweeps.clear()
+        start = (self.Ut.clone(), self.V.clone())
+        dt, cost = self.cx.timed(lambda: self.run(steps))
+        return dt, cost, start
+
+    def fixed_work(self):
+        """10 sweeps per inner solve whatever the data (delta = 0, maxiter = 10)."""
+        keep = dict(self.mod.HALS_INNER)
+        self.mod.HALS_INNER.update(maxiter=10, delta=0.0)
+        try:
+            self.run(2)
+            fdt, _ = self.cx.timed(lambda: self.run(10))
+        finally:
+            self.mod.HALS_INNER.update(keep)
+        return {"ms_per_step": 1e3 * fdt / 10, "iterations_per_s": 10 / fdt,
+                "inner": "10 sweeps per solve (delta=0, maxiter=10)"}
+
+
+def roof(kernel, bound, algo, ms, peak, unit, **more):
+    """One roofline entry: `algo` algorithmic flops (bound mfma / valu) or bytes (bound hbm) per launch, `ms` mean launch."""
+    achieved = algo / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
+    d = {"kernel": kernel, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+         "traffic": None, "launch_ms": ms}
+    d.update(more)
+    return d
+
+
+def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta):
+    """Per-kernel launch durations, HIP events recorded by the library on the launch stream immediately around each main
+    kernel (Engine.time_kernel / nnf_ctx_set_probe_kernel), on the factors the timed region ended with."""
+    eng, X, Ut, V, ws = cx.eng, run.X, run.Ut, run.V, run.ws
+    torch = cx.torch
+    flops = 2.0 * r * m * n
+    xbytes = (m * n + r * m + r * n) * 4.0
+    out = []
+    if rule == "hals":
+        ms = eng.time_kernel("xty", lambda: eng.xty(X, Ut, out=ws.UtM))
+        out.append(roof("nnf_xty_kernel (W^T X, main kernel of nnf_xty_f32; the fixed-order slab reduction that follows is "
+                        "not included)", "mfma", flops, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=flops,
+                        algorithmic_bytes=xbytes, hbm_gbs=xbytes / ms / 1e6, hbm_frac_of_8TBs=xbytes / ms / 1e6 / HBM_PEAK_GBS))
+        ms = eng.time_kernel("xht", lambda: eng.xht(X, V, out=ws.VMt))
+        out.append(roof("nnf_xht_kernel (X H^T)", "mfma", flops, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
+                        algorithmic_flops=flops, algorithmic_bytes=xbytes, hbm_gbs=xbytes / ms / 1e6))
+        c = torch.zeros(1, dtype=torch.float64, device=X.device)
+        ms = eng.time_kernel("cost", lambda: eng.frob_resid(X, Ut, V, out=c))
+        out.append(roof("nnf_cost_kernel<FROB> (||X - UV||^2 fused with the product)", "mfma", flops, ms,
+                        MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=flops, algorithmic_bytes=xbytes,
+                        hbm_gbs=xbytes / ms / 1e6))
+        # the sweep kernels: fixed 20 sweeps from the current factors (time / sweep is what the VALU roofline prices)
+        ns = 20
+        G = eng.gram(V)
+        eng.xht(X, V, out=ws.VMt)
+        F = Ut.clone()
+        ms = eng.time_kernel("hals", lambda: eng.hals_sweeps(ws.VMt, G, F, ns), reps=5) / ns
+        out.append(roof(f"nnf_hals_kernel (U side: {m} columns, rank {r}; one lane per column, per sweep over {ns} fixed "
+                        f"sweeps)", "valu", 2.0 * r * r * m, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
+                        algorithmic_flops=2.0 * r * r * m, us_per_sweep=ms * 1e3,
+                        note="Gauss-Seidel row dependence: issue bound of this formulation is ~2.4x the 2r^2m/peak time "
+                             "(DESIGN.md 3)"))
+        G2 = eng.gram(Ut)
+        eng.xty(X, Ut, out=ws.UtM)
+        F2 = V.clone()
+        ms = eng.time_kernel("hals", lambda: eng.hals_sweeps(ws.UtM, G2, F2, ns), reps=5) / ns
+        out.append(roof(f"nnf_hals_quad_kernel (V side: {n} columns, rank {r}; four lanes per column, per sweep)", "valu",
+                        2.0 * r * r * n, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=2.0 * r * r * n,
+                        us_per_sweep=ms * 1e3, note="latency bound: n/16 single-wave workgroups"))
+    else:
+        k = 2.0 if float(beta) != 2.0 else 1.0
+        ms = eng.time_kernel("mu_left", lambda: eng.mu_left(X, Ut, V, beta))
+        out.append(roof(f"nnf_mu_left_kernel (beta={beta:g}: P = U V and num += (X ./ P) V^T in one pass)", "mfma",
+                        k * flops, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=k * flops,
+                        algorithmic_bytes=xbytes, hbm_gbs=xbytes / ms / 1e6))
+        ms = eng.time_kernel("mu_right", lambda: eng.mu_right(X, Ut, V, beta))
+        out.append(roof(f"nnf_mu_right_kernel (beta={beta:g})", "mfma", k * flops, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
+                        algorithmic_flops=k * flops, algorithmic_bytes=xbytes, hbm_gbs=xbytes / ms / 1e6))
+        c = torch.zeros(1, dtype=torch.float64, device=X.device)
+        ms = eng.time_kernel("cost", lambda: eng.betadiv(X, Ut, V, beta, out=c))
+        out.append(roof(f"nnf_cost_kernel<beta={beta:g}> (divergence fused with the product)", "mfma", flops, ms,
+                        MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=flops, algorithmic_bytes=xbytes,
+                        hbm_gbs=xbytes / ms / 1e6))
+    return out
+
+
+def bench_nmf(cx, args, cfg, steps, warmup, with_cpu, with_fixed, with_kernels):
+    torch = cx.torch
+    m, n, r, rule = cfg["m"], cfg["n"], cfg["r"], cfg["rule"]
+    beta = args.beta if (args.beta is not None and rule == "mu") else cfg["beta"]
+    host = None
+    if cfg["scaling"] == "strong":
+        # config E: blocks [b0, b1) of the E_BLOCKS row blocks live on this rank
+        if E_BLOCKS % cx.world:
+            raise SystemExit(f"config E is laid out in {E_BLOCKS} row blocks: --gpus must divide {E_BLOCKS}")
+        per = E_BLOCKS // cx.world
+        rows = m // E_BLOCKS
+        parts = [synth_nmf_block_device(rows, n, r, args.seed * E_BLOCKS + b, 977 + args.seed, cx.device, torch)
+                 for b in range(cx.rank * per, (cx.rank + 1) * per)]
+        X = torch.cat([p[0] for p in parts]) if per > 1 else parts[0][0]
+        Ut = (torch.cat([p[1] for p in parts]) if per > 1 else parts[0][1]).t().contiguous()
+        del parts
+        V = torch.rand(r, n, device=cx.device, generator=torch.Generator(device=cx.device).manual_seed(4242 + args.seed))
+        units = 1.0                      # one iteration of the whole job per step, whatever N
+    else:
+        Xh, U0h, V0h = synth_nmf_host(m, n, r, seed=args.seed + cx.rank)
+        X = torch.from_numpy(Xh).to(device=cx.device, dtype=cx.dtype)
+        Ut = torch.from_numpy(U0h).to(device=cx.device, dtype=cx.dtype).t().contiguous()
+        V = torch.from_numpy(V0h).to(device=cx.device, dtype=cx.dtype)
+        if cx.world > 1:
+            cx.dist.broadcast(V, src=0)          # V is replicated
+        host = Xh if (with_cpu and cx.world == 1 and cx.rank == 0) else None
+        del Xh, U0h, V0h
+        units = float(cx.world)          # 100000-row blocks per step
+
+    run = NmfRun(cx, X, Ut, V, r, rule, beta)
+    dt, cost, start = run.measure(warmup, steps)
+    sweeps = list(run.sweeps)
+    out = {"value": units * steps / dt, "ms_per_step": 1e3 * dt / steps, "final_cost": cost,
+           "inner_sweeps_per_step_last": sweeps[-1] if sweeps else None,
+           "inner_sweeps_mean": (sum(sum(x) for x in sweeps) / len(sweeps)) if sweeps and sweeps[0] else None,
+           "rows_per_rank": int(X.shape[0]), "rule": rule, "beta": beta}
+    if with_fixed and rule == "hals":
+        f = run.fixed_work()
+        f["iterations_per_s"] *= units
+        out["fixed_work"] = f
+    if with_kernels and cx.cuda and cx.rank == 0:
+        out["rooflines"] = nmf_kernel_rooflines(cx, run, int(X.shape[0]), n, r, rule, beta)
+    if host is not None:
+        U_s, V_s = start[0].t().contiguous().cpu().numpy(), start[1].cpu().numpy()
+        del run, X
+        out["cpu_baseline"] = cpu_baseline_nmf(host, U_s, V_s, r, rule, beta, sweeps)
+    return out
+
+
+def bench_ntf(cx, args, cfg, steps, warmup, with_cpu, with_kernels):
+    import math
+    torch = cx.torch
+    from nn_fac_amd import ntf as ntf_mod
+    I, R = cfg["m"], cfg["r"]
+    Th, F0h = synth_ntf_host(I, R, seed=args.seed + cx.rank)
+    T = torch.from_numpy(Th).to(device=cx.device, dtype=cx.dtype)
+    Ft = [torch.from_numpy(f).to(device=cx.device, dtype=cx.dtype).t().contiguous() for f in F0h]
+    if cx.world > 1:
+        for f in Ft[1:]:
+            cx.dist.broadcast(f, src=0)          # the factors of the unsharded modes are replicated
+    st = ntf_mod._NtfState(cx.eng, T, group=cx.group) if cx.world > 1 else ntf_mod._NtfState(cx.eng, T)
+    sweeps, last = [], [None]
+
+    def retired(it, cost, sw):
+        sweeps.append(sw)
+        last[0] = cost
+        return False
+
+    def run(k):
+        nonlocal Ft
+        Ft = ntf_mod.run_ntf_steps(st, R, Ft, k, "hals", 2, [None] * 3, [], [False] * 3, math.inf, 0.01, retired)
+        return last[0]
+
+    run(warmup)
+    sweeps.clear()
+    start = [f.clone() for f in Ft]
+    dt, cost = cx.timed(lambda: run(steps))
+    out = {"value": cx.world * steps / dt, "ms_per_step": 1e3 * dt / steps, "final_cost": cost,
+           "inner_sweeps_per_step_last": sweeps[-1] if sweeps else None,
+           "inner_sweeps_mean": (sum(sum(x) for x in sweeps) / len(sweeps)) if sweeps else None,
+           "rows_per_rank": I, "rule": "hals", "beta": 2}
+    if with_kernels and cx.cuda and cx.rank == 0:
+        eng = cx.eng
+        tb = I * I * I * 4.0 + 3 * I * R * 4.0
+        rl = []
+        for mode in range(3):
+            ms = eng.time_kernel("mttkrp", lambda: eng.mttkrp3(T, Ft, mode))
+            rl.append(roof(f"nnf_mttkrp kernel, mode {mode} (Khatri-Rao operand generated on the fly; slab reduction not "
+                           f"included)", "hbm", tb, ms, HBM_PEAK_GBS, "GB/s", algorithmic_bytes=tb,
+                           algorithmic_flops=2.0 * I * I * I * R, tflops=2.0 * I * I * I * R / ms / 1e9))
+        c = torch.zeros(1, dtype=torch.float64, device=T.device)
+        ms = eng.time_kernel("cost", lambda: eng.cp3_betadiv(T, Ft, 2, out=c))
+        rl.append(roof("nnf_cost_kernel<FROB> on the CP model (||T - [[F0,F1,F2]]||^2, Khatri-Rao rows generated on the fly)",
+                       "hbm", tb, ms, HBM_PEAK_GBS, "GB/s", algorithmic_bytes=tb, algorithmic_flops=2.0 * I * I * I * R,
+                       tflops=2.0 * I * I * I * R / ms / 1e9))
+        out["rooflines"] = rl
+    if with_cpu and cx.world == 1 and cx.rank == 0:
+        Fs = [f.t().contiguous().cpu().numpy() for f in start]
+        del T, st
+        out["cpu_baseline"] = cpu_baseline_ntf(Th, Fs, R)
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rule", default="hals", choices=["hals", "mu"])
-    ap.add_argument("--beta", type=float, default=None)
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-fixed", action="store_true", help="skip the fixed-work line (profiling runs)")
-    args = ap.parse_args()
-    beta = args.beta if args.beta is not None else (2 if args.rule == "hals" else 1)
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))          # before anything here has touched the GPU
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # NNF_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
-        backend = os.environ.get("NNF_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        else:
-            torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
-            dist.init_process_group(backend=backend)
+    cx = Ctx(args)
+    cfg = dict(CONFIGS[args.config])
+    shape_note = ""
+    if args.shape:
+        cfg["m"], cfg["n"], cfg["r"] = (int(x) for x in args.shape.split(","))
+        shape_note = " [--shape override: NOT the BASELINE configuration]"
+    world = cx.world
+
+    if cfg["kind"] == "nmf":
+        res = bench_nmf(cx, args, cfg, args.steps, args.warmup, not args.no_cpu and cfg["scaling"] == "weak",
+                        not args.no_fixed, not args.no_kernels)
     else:
-        torch.cuda.set_device(0)
-    device = torch.device(f"cuda:{torch.cuda.current_device()}")
+        res = bench_ntf(cx, args, cfg, args.steps, args.warmup, not args.no_cpu, not args.no_kernels)
 
-    from nn_fac_amd.engine import get_engine
-    from nn_fac_amd import nmf as nmf_mod
-    eng = get_engine(device)
-    X, U0, V0 = synth_on_device(M, N, R, seed=rank, device=device)
-    if world > 1:
-        dist.broadcast(V0, src=0)               # V is replicated
-    Ut, V = U0.t().contiguous(), V0.clone()
-    group = dist.group.WORLD if world > 1 else None
-    ws = nmf_mod._StepBuffers(X, R)
-    sweeps = []
+    extra = None
+    if args.config == "B" and not args.no_extra and not args.shape:
+        # the 1e6 x 4000 rank-100 problem of configs[4] split over these N ranks (strong scaling), a short measurement
+        ecfg = dict(CONFIGS["E"])
+        if cx.cuda:
+            cx.torch.cuda.empty_cache()
+        e = bench_nmf(cx, args, ecfg, 5, 2, False, False, False)
+        extra = {"E": {"workload": f"NMF hals {ecfg['m']}x{ecfg['n']} rank {ecfg['r']} ({ecfg['ref']} of BASELINE.json), the "
+                                   f"same 1e6-row problem row-sharded over {world} rank(s): strong scaling",
+                       "iterations_per_s": e["value"], "ms_per_step": e["ms_per_step"], "steps": 5, "warmup": 2,
+                       "rows_per_rank": e["rows_per_rank"], "inner_sweeps_per_step_last": e["inner_sweeps_per_step_last"],
+                       "final_cost": e["final_cost"], "scaling": "strong"}}
 
-    def run(k):
-        """k outer iterations through the product's own loop (nn_fac_amd.nmf.run_steps, the `for iteration` loop of
-        compute_nmf: the cost + status block of every iteration is read back and handed to the stopping test's hook,
-        here a recorder that never stops)."""
-        nonlocal Ut, V
-        last = [None]
-
-        def retired(it, cost, sw):
-            sweeps.append(sw)
-            last[0] = cost
-            return False
-
-        Ut, V = nmf_mod.run_steps(eng, ws, X, R, Ut, V, k, args.rule, beta, [None, None], [], [False, False], True,
-                                  retired, group=group)
-        return last[0]
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run(args.warmup)
-    sweeps.clear()
-    barrier()
-    t0 = time.perf_counter()
-    cost = run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-
-    sweeps_last = sweeps[-1] if sweeps else None
-    sweeps_mean = float(np.mean([sum(x) for x in sweeps])) if sweeps else None
-    final_cost = cost
-
-    # fixed-work variant (SURVEY 8d): 10 sweeps per inner solve whatever the data (delta = 0, maxiter = 10)
-    fixed = None
-    if args.rule == "hals" and not args.no_fixed:
-        keep = dict(nmf_mod.HALS_INNER)
-        nmf_mod.HALS_INNER.update(maxiter=10, delta=0.0)
-        try:
-            run(2)
-            barrier()
-            t1 = time.perf_counter()
-            run(10)
-            barrier()
-            fdt = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([fdt], dtype=torch.float64, device=device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                fdt = float(t)
-            fixed = {"ms_per_step": 1e3 * fdt / 10, "iterations_per_s": world * 10 / fdt,
-                     "inner": "10 sweeps per solve (delta=0, maxiter=10)"}
-        finally:
-            nmf_mod.HALS_INNER.update(keep)
-
-    # dominant kernel, timed live on the launch stream: HIP events recorded by the library immediately around
-    # nnf_xty_kernel (the probe hook of the C ABI), and around the whole nnf_xty_f32 call (kernel + slab reduction)
-    stream = torch.cuda.current_stream(device)
-    xty_call_ms = time_kernel(lambda: eng.xty(X, Ut, out=ws.UtM), 20, stream)
-    reps = 20
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in evs:          # torch creates the hipEvent_t lazily: record once so that the handles exist
-        a.record(stream)
-        b.record(stream)
-    stream.synchronize()
-    for a, b in evs:
-        eng.set_probe(a, b)
-        eng.xty(X, Ut, out=ws.UtM)
-    eng.set_probe()
-    stream.synchronize()
-    xty_ms = sum(a.elapsed_time(b) for a, b in evs) / reps
-    flops = 2.0 * R * M * N
-    achieved = flops / (xty_ms * 1e-3) / 1e12
-    xty_bytes = (M * N + R * M + R * N) * 4
-    traffic = None      # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), if present
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_xty_traffic.json")) as fh:
-            traffic = json.load(fh)["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-
-    if rank == 0:
+    if cx.rank == 0:
+        rule, beta = res["rule"], res["beta"]
+        what = {"B": "HALS NMF outer iterations/s (100000x2000 rank-50 row blocks per second)",
+                "C": f"MU(beta={beta:g}) NMF outer iterations/s (100000x2000 rank-50 row blocks per second)",
+                "D": "HALS NTF outer iterations/s (500^3 rank-30 tensor blocks per second)",
+                "E": "HALS NMF outer iterations/s on the 1e6x4000 rank-100 problem (whole job)"}[args.config]
+        if cfg["kind"] == "nmf":
+            workload = (f"NMF {rule} beta={beta:g}, {cfg['m']}x{cfg['n']} rank {cfg['r']} "
+                        + ("per GPU" if cfg["scaling"] == "weak" else f"in total, row-sharded over {world} GPU(s)")
+                        + f" ({cfg['ref']} of BASELINE.json), deterministic (alpha=inf, delta=0.01, maxiter=100)")
+        else:
+            workload = (f"NTF hals, {cfg['m']}^3 rank {cfg['r']} per GPU ({cfg['ref']} of BASELINE.json), alpha=inf, "
+                        f"delta=0.01, maxiter=100")
+        rl = res.get("rooflines") or []
         out = {
-            "metric": "HALS NMF outer iterations/s (100000x2000 rank-50 row blocks per second)" if args.rule == "hals"
-                      else f"MU(beta={beta:g}) NMF outer iterations/s (100000x2000 rank-50 row blocks per second)",
-            "value": world * args.steps / dt,
+            "metric": what + shape_note,
+            "value": res["value"],
             "unit": "iterations/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": cfg["scaling"],
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if cx.cuda else "f64 (CPU engine double: a launch rehearsal, not a measurement)",
             "data": "synthetic",
-            "config": {"workload": f"NMF {args.rule} beta={beta:g}, {M}x{N} rank {R} per GPU "
-                                   f"(configs[1] of BASELINE.json), deterministic (alpha=inf, delta=0.01, maxiter=100)",
-                       "rows_total": world * M, "cols": N, "rank": R,
-                       "parallelism": f"row-sharded x{world}" if world > 1 else "single GPU",
-                       "inner_sweeps_per_step_last": sweeps_last,
-                       "inner_sweeps_mean": sweeps_mean,
-                       "final_cost": final_cost},
-            "roofline": {"kernel": "nnf_xty_kernel (W^T X, the main kernel of nnf_xty_f32; its fixed-order slab reduction "
-                                   "nnf_reduce_slabs_kernel follows and is included in call_ms)", "bound": "mfma",
-                         "achieved": achieved, "call_ms": xty_call_ms,
-                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                         "traffic": traffic, "launch_ms": xty_ms,
-                         "algorithmic_bytes": xty_bytes, "hbm_gbs": xty_bytes / (xty_ms * 1e-3) / 1e9,
-                         "hbm_frac_of_8TBs": xty_bytes / (xty_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "config": {"workload": workload + shape_note,
+                       "rows_total": (world if cfg["scaling"] == "weak" else 1) * cfg["m"], "cols": cfg["n"],
+                       "rank": cfg["r"], "rows_per_rank": res["rows_per_rank"],
+                       "parallelism": (f"row-sharded x{world} ({cx.backend})" if world > 1 else
+                                       "single GPU" + (f" (process group: {cx.backend}, 1 rank)" if cx.pg else "")),
+                       "inner_sweeps_per_step_last": res["inner_sweeps_per_step_last"],
+                       "inner_sweeps_mean": res["inner_sweeps_mean"],
+                       "final_cost": res["final_cost"]},
+            "roofline": rl[0] if rl else None,
+            "roofline_more": rl[1:],
         }
-        if fixed is not None:
-            out["fixed_work"] = fixed
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.rule, beta)
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        if "fixed_work" in res:
+            out["fixed_work"] = res["fixed_work"]
+        if extra is not None:
+            out["extra_configs"] = extra
+        if "cpu_baseline" in res:
+            out["cpu_baseline"] = res["cpu_baseline"]
+        print(json.dumps(out), flush=True)
+    if cx.pg:
+        cx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

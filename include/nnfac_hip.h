@@ -66,6 +66,18 @@ size_t nnf_ctx_workspace_bytes(const nnf_ctx* ctx);
  * launch stream immediately before and after its main kernel, so that a benchmark can time the dominant kernel alone --
  * without the slab reduction that follows it -- with HIP events on the stream the kernel runs on. */
 int nnf_ctx_set_probe(nnf_ctx* ctx, void* ev_begin, void* ev_end);
+/* Which main kernel the two events bracket (default NNF_PROBE_XTY): the streaming kernel of nnf_xty_f32 / nnf_xht_f32 /
+ * the cost entry points / nnf_mu_left_f32 / nnf_mu_right_f32 / nnf_mttkrp3_f32, or the persistent sweep kernel of
+ * nnf_hals_solve_f32 / nnf_hals_sweeps_f32 -- each without the small preparation / reduction kernels around it. */
+#define NNF_PROBE_XTY 0
+#define NNF_PROBE_XHT 1
+#define NNF_PROBE_COST 2
+#define NNF_PROBE_HALS 3
+#define NNF_PROBE_MU_LEFT 4
+#define NNF_PROBE_MU_RIGHT 5
+#define NNF_PROBE_MTTKRP 6
+#define NNF_PROBE_COUNT 7
+int nnf_ctx_set_probe_kernel(nnf_ctx* ctx, int kernel_id);
 
 /* G[r x r] = A[r x K] * A^T.   Replaces VVt = np.dot(V, V.T) (nmf.py:407), UtU = np.dot(U.T, U) (nmf.py:432),
  * and each factor Gram in ntf.py:442-445.  Split-K partials are summed in fp64 in a fixed order. */

@@ -255,11 +255,13 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
             return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
         hals_args a{UtM, ldm, Gp, dinv, want_gs ? Gp + gs_off : nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status,
                     sweep_partials, snapshots, snap_stride};
+        nnf_probe(ctx, NNF_PROBE_HALS, 0, st);
         if (RP <= 48) rc = nnf_hals_fast_part0(ctx, RP, a, max_blocks, &nblocks, st);
         else if (RP <= 64) rc = nnf_hals_fast_part1(ctx, RP, a, max_blocks, &nblocks, st);
         else if (RP <= 104) rc = nnf_hals_fast_part2(ctx, RP, a, max_blocks, &nblocks, st);
         else rc = nnf_hals_fast_part3(ctx, RP, a, max_blocks, &nblocks, st);
         if (rc != NNF_OK) return rc;
+        nnf_probe(ctx, NNF_PROBE_HALS, 1, st);
     }
     if (MODE == 1) {
         hipLaunchKernelGGL(nnf_hals_sum_sweeps_kernel, dim3(nsweeps), dim3(256), 0, st, sweep_partials, nblocks,

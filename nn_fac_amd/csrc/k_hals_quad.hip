@@ -352,7 +352,10 @@ int nnf_hals_quad_run(nnf_ctx* ctx, const float* UtU, int64_t ldg, float* Gq, un
     a.dinv = dinvq;
     const int nblocks = (int)nnf_cdiv(a.ncols, 16);
     *nblocks_out = nblocks;
-    return ch <= 14 ? nnf_hals_quad_launch_part0(ch, a, nblocks, st) : ch <= 21 ? nnf_hals_quad_launch_part1(ch, a, nblocks, st)
-         : ch <= 27 ? nnf_hals_quad_launch_part2(ch, a, nblocks, st) : nnf_hals_quad_launch_part3(ch, a, nblocks, st);
+    nnf_probe(ctx, NNF_PROBE_HALS, 0, st);
+    const int rc = ch <= 14 ? nnf_hals_quad_launch_part0(ch, a, nblocks, st) : ch <= 21 ? nnf_hals_quad_launch_part1(ch, a, nblocks, st)
+                 : ch <= 27 ? nnf_hals_quad_launch_part2(ch, a, nblocks, st) : nnf_hals_quad_launch_part3(ch, a, nblocks, st);
+    nnf_probe(ctx, NNF_PROBE_HALS, 1, st);
+    return rc;
 }
 #endif   // QUAD_PART == 0

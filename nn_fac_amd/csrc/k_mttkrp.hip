@@ -241,9 +241,11 @@ static int launch_seg(nnf_ctx* ctx, const float* T, int64_t nrows, int64_t ldrow
     if (!slabs) return NNF_ERR_WORKSPACE;
     const int fk_vec_ok = ((((uintptr_t)Fk) & 15) == 0 && (ldk & 3) == 0) ? 1 : 0;
     const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * nrb;
+    nnf_probe(ctx, NNF_PROBE_MTTKRP, 0, st);
     hipLaunchKernelGGL((nnf_mttkrp_seg_kernel<MT, VEC>), dim3(grid), dim3(256), 0, st, T, nrows, ldrow, nseg, segstride,
                        klen, Fs, lds_, Fk, ldk, r, slabs, ldp, nrb, (int)nsplit, sps, fk_vec_ok);
     NNF_CHECK_LAUNCH();
+    nnf_probe(ctx, NNF_PROBE_MTTKRP, 1, st);
     return nnf_launch_reduce_slabs(slabs, (int)nsplit, slab_elems, r, nrows, ldp, out, ldo, st);
 }
 
@@ -271,9 +273,11 @@ static int launch_rows(nnf_ctx* ctx, const float* M, int64_t m, int64_t n, const
     float* slabs = (float*)cur.take((size_t)nsplit * slab_elems * 4);
     if (!slabs) return NNF_ERR_WORKSPACE;
     const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * ncb;
+    nnf_probe(ctx, NNF_PROBE_MTTKRP, 0, st);
     hipLaunchKernelGGL((nnf_mttkrp_rows_kernel<MT, VEC>), dim3(grid), dim3(256), 0, st, M, m, n, n, Fa, lda, Fb, ldb, nb, r,
                        slabs, ldp, ncb, (int)nsplit, rps);
     NNF_CHECK_LAUNCH();
+    nnf_probe(ctx, NNF_PROBE_MTTKRP, 1, st);
     return nnf_launch_reduce_slabs(slabs, (int)nsplit, slab_elems, r, n, ldp, out, ldo, st);
 }
 

@@ -534,9 +534,11 @@ static int launch_mu_right(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_mu_right_kernel<MT, BM, VEC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * ncb;
+    nnf_probe(ctx, NNF_PROBE_MU_RIGHT, 0, st);
     hipLaunchKernelGGL((nnf_mu_right_kernel<MT, BM, VEC>), dim3(grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
                        (float)beta, snum, sden, ldp, ncb, (int)nsplit, rps, a_vec_ok);
     NNF_CHECK_LAUNCH();
+    nnf_probe(ctx, NNF_PROBE_MU_RIGHT, 1, st);
     if (num_out) {   // accumulate only (row-sharded runs): this block's numerator / denominator, slab-reduced in fixed order
         int rc = nnf_launch_reduce_slabs(snum, (int)nsplit, slab_elems, r, n, ldp, num_out, ldnum, st);
         if (rc != NNF_OK) return rc;
@@ -575,9 +577,11 @@ static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int6
         grid = slots;
     }
     if (n_hi * 256 + (grid - n_hi) * 192 < m) return NNF_ERR_UNSUPPORTED;   // (cannot happen)
+    nnf_probe(ctx, NNF_PROBE_MU_LEFT, 0, st);
     hipLaunchKernelGGL((nnf_mu_left_kernel<MT, BM, VEC>), dim3((int)grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
                        (float)beta, dvec, gamma_of(beta), Ut_out, lduo, a_vec_ok, (int)n_hi);
     NNF_CHECK_LAUNCH();
+    nnf_probe(ctx, NNF_PROBE_MU_LEFT, 1, st);
     return NNF_OK;
 }
 

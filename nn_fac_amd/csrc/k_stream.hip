@@ -281,11 +281,11 @@ static int launch_xty(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t 
     if (!slabs) return NNF_ERR_WORKSPACE;
     const int a_vec_ok = ((((uintptr_t)Ut) & 15) == 0 && (ldu & 3) == 0) ? 1 : 0;
     const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * ncb;
-    if (ctx->probe[0]) (void)hipEventRecord(ctx->probe[0], st);   // measurement hook: the main kernel alone (bench.py)
+    nnf_probe(ctx, NNF_PROBE_XTY, 0, st);   // measurement hook: the main kernel alone (bench.py)
     hipLaunchKernelGGL((nnf_xty_kernel<MT, REM, VEC>), dim3(grid), dim3(256), 0, st, X, m, n, ldx, Ut, ldu, r, slabs, ldp, ncb,
                        (int)nsplit, rows_per_split, a_vec_ok);
     NNF_CHECK_LAUNCH();
-    if (ctx->probe[1]) (void)hipEventRecord(ctx->probe[1], st);
+    nnf_probe(ctx, NNF_PROBE_XTY, 1, st);
     return nnf_launch_reduce_slabs(slabs, (int)nsplit, slab_elems, r, n, ldp, out, ldo, st);
 }
 
@@ -444,6 +444,7 @@ static int launch_xht(nnf_ctx* ctx, nnf_ws_cursor&, const float* X, int64_t m, i
         grid = nnf_cdiv(m, 128);
     }
     if (n_hi * 64 * nth + (grid - n_hi) * 64 * (nth - 1) < m) return NNF_ERR_UNSUPPORTED;   // (cannot happen: the split covers m by construction)
+    nnf_probe(ctx, NNF_PROBE_XHT, 0, st);
     if (nth == 4)
         hipLaunchKernelGGL((nnf_xht_kernel<MT, REM, VEC, 4>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
                            a_vec_ok, (int)n_hi);
@@ -451,6 +452,7 @@ static int launch_xht(nnf_ctx* ctx, nnf_ws_cursor&, const float* X, int64_t m, i
         hipLaunchKernelGGL((nnf_xht_kernel<MT, REM, VEC, 3>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
                            a_vec_ok, (int)n_hi);
     NNF_CHECK_LAUNCH();
+    nnf_probe(ctx, NNF_PROBE_XHT, 1, st);
     return NNF_OK;
 }
 
@@ -948,6 +950,7 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
         hipLaunchKernelGGL((nnf_cost_kernel<OP, VV, NN>), dim3(grid, csplit), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, Vf, r, \
                            beta, partial, Ub, ldub, nbu, R1, R2, ldr, u_vec_ok);                                             \
     } while (0)
+    nnf_probe(ctx, NNF_PROBE_COST, 0, st);
     if (x_vec_ok(X, ldx)) {
         if (KS <= 16) NNF_COST_LAUNCH(true, 4);
         else NNF_COST_LAUNCH(true, 8);
@@ -957,6 +960,7 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
     }
 #undef NNF_COST_LAUNCH
     NNF_CHECK_LAUNCH();
+    nnf_probe(ctx, NNF_PROBE_COST, 1, st);
     if (OP == NNF_RATIO_KL || OP == NNF_RATIO_GEN) return NNF_OK;   // nothing to sum
     hipLaunchKernelGGL(nnf_sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)grid * csplit, scale, out_f64);
     NNF_CHECK_LAUNCH();

@@ -34,6 +34,7 @@ extern "C" int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_by
     c->ws = nullptr;
     c->hals_epoch = 0u;
     c->probe[0] = c->probe[1] = nullptr;
+    c->probe_id = NNF_PROBE_XTY;
     hipError_t e = hipMalloc((void**)&c->ws, c->ws_bytes);
     if (e == hipSuccess) e = hipMemset(c->ws, 0, c->ws_bytes);   // exchange words must not start as look-alike tags
     (void)hipSetDevice(prev);
@@ -58,6 +59,12 @@ extern "C" int nnf_ctx_set_probe(nnf_ctx* ctx, void* ev_begin, void* ev_end) {
     if (!ctx || ((ev_begin == nullptr) != (ev_end == nullptr))) return NNF_ERR_ARG;
     ctx->probe[0] = (hipEvent_t)ev_begin;
     ctx->probe[1] = (hipEvent_t)ev_end;
+    return NNF_OK;
+}
+
+extern "C" int nnf_ctx_set_probe_kernel(nnf_ctx* ctx, int kernel_id) {
+    if (!ctx || kernel_id < 0 || kernel_id >= NNF_PROBE_COUNT) return NNF_ERR_ARG;
+    ctx->probe_id = kernel_id;
     return NNF_OK;
 }
 

@@ -10,9 +10,15 @@ struct nnf_ctx {
     int num_cus;
     size_t ws_bytes;
     char* ws;          // device scratch (split-K slabs, partial sums, barrier words); zeroed once at creation
-    unsigned hals_epoch;
-    hipEvent_t probe[2];   // optional caller-owned events recorded around the main W^T X kernel (nnf_ctx_set_probe)  // salt of the HALS exchange tags (k_hals_common.h)
+    unsigned hals_epoch;   // salt of the HALS exchange tags (k_hals_common.h)
+    hipEvent_t probe[2];   // optional caller-owned events recorded around ONE main kernel (nnf_ctx_set_probe[_kernel])
+    int probe_id;          // which kernel the probe brackets (NNF_PROBE_*, include/nnfac_hip.h); default: W^T X
 };
+
+// measurement hook: record the caller's event `which` (0 begin, 1 end) if the probe is armed for kernel `id`
+static inline void nnf_probe(nnf_ctx* c, int id, int which, hipStream_t st) {
+    if (c->probe[which] && c->probe_id == id) (void)hipEventRecord(c->probe[which], st);
+}
 
 #define NNF_CHECK_LAUNCH()                                   \
     do {                                                     \

@@ -247,13 +247,36 @@ class Engine:
                                              _ld(O), self._stream()), "nnf_mu_apply_f32")
         return O
 
-    def set_probe(self, ev_begin=None, ev_end=None):
-        """Measurement hook (bench.py): two torch.cuda.Event(enable_timing=True) that nnf_xty_f32 records right before and
-        right after its main kernel; call with no arguments to remove them.  The events must have been recorded once
-        already (torch creates the underlying hipEvent_t lazily)."""
+    PROBE_KERNELS = {"xty": 0, "xht": 1, "cost": 2, "hals": 3, "mu_left": 4, "mu_right": 5, "mttkrp": 6}
+
+    def set_probe(self, ev_begin=None, ev_end=None, kernel="xty"):
+        """Measurement hook (bench.py): two torch.cuda.Event(enable_timing=True) that the library records on the launch
+        stream right before and right after the main kernel named by `kernel` (NNF_PROBE_* of include/nnfac_hip.h); call
+        with no arguments to remove them.  The events must have been recorded once already (torch creates the underlying
+        hipEvent_t lazily)."""
         b = C.c_void_p(ev_begin.cuda_event) if ev_begin is not None else None
         e = C.c_void_p(ev_end.cuda_event) if ev_end is not None else None
+        _lib.check(self.lib.nnf_ctx_set_probe_kernel(self.ctx, self.PROBE_KERNELS[kernel]), "nnf_ctx_set_probe_kernel")
         _lib.check(self.lib.nnf_ctx_set_probe(self.ctx, b, e), "nnf_ctx_set_probe")
+
+    def time_kernel(self, kernel, fn, reps=20):
+        """Mean duration (ms) of the main kernel `kernel` over `reps` calls of `fn` (which must launch it exactly once on the
+        current stream), measured with HIP events recorded by the library immediately around that kernel."""
+        stream = torch.cuda.current_stream(self.device)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record(stream)
+            b.record(stream)
+        fn()
+        stream.synchronize()
+        try:
+            for a, b in evs:
+                self.set_probe(a, b, kernel)
+                fn()
+        finally:
+            self.set_probe()
+        stream.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) / reps
 
     # ---- NTD -----------------------------------------------------------------------------------------
     def ttm3(self, T, Ft, mode):

@@ -27,6 +27,7 @@ from .utils import initialize_factors as init_factors
 from . import engine as _engine
 from ._convert import device_of, to_dev, to_dev_t, like_input
 from .update_rules.nnls import sweep_budget
+from . import dist as _dist
 
 
 def ntf(tensor, rank, init="random", factors_0=[], n_iter_max=100, tol=1e-8,
@@ -54,16 +55,25 @@ def ntf(tensor, rank, init="random", factors_0=[], n_iter_max=100, tol=1e-8,
 
 
 class _NtfState:
-    """Device-resident tensor, its squared norm and (MU only) the materialised unfoldings."""
+    """Device-resident tensor, its squared norm and (MU only) the materialised unfoldings.
 
-    def __init__(self, eng, T):
+    With `group` (torch.distributed process group) T is this rank's block of the LEADING mode and the mode-0
+    factor is sharded the same way; the other factors, every Gram and every scalar are replicated: the mode-0 update is
+    local up to the global stopping scalar of its sweeps (dist.sharded_hals_solve), the other modes all-reduce their
+    MTTKRP output (R x I_k) together with the mode-0 Gram (R x R) -- one collective --, the cost one f64."""
+
+    def __init__(self, eng, T, group=None):
         if T.dim() != 3:
             raise NotImplementedError("the MI355X engine accelerates 3-way tensors (nnf_mttkrp3_f32)")
         self.eng = eng
+        self.group = group
         self.T = T.contiguous()
         I, J, K = self.T.shape
         t2 = self.T.view(I, J * K)
         self.norm2 = eng.dot(t2, t2)          # float64 device scalar, ||T||^2
+        if _dist.world(group) > 1:
+            _dist.allreduce_(self.norm2, group)
+        self.guess0 = _dist.SweepGuess()
         self._unf = {}
         # per-iteration status: 3 HALS status blocks + cost at [24]; a ring with pinned host mirrors (run_ntf_steps)
         self.blocks = torch.zeros((3, 8 * 3 + 8), dtype=torch.float64, device=T.device)
@@ -94,16 +104,22 @@ def _krao_t(Ft, skip):
 
 def _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, cost):
     """The cost lines of one_ntf_step (ntf.py:462-475) into the 1-element float64 device tensor `cost`, current stream."""
+    sharded = _dist.world(st.group) > 1
     if update_rule == "hals":
         eng.cp3_betadiv(st.T, Ft, 2, out=cost)
         cost.mul_(2.0)                               # ||T - model||^2
     else:
         eng.cp3_betadiv(st.T, Ft, beta, out=cost)
+    if sharded:
+        _dist.allreduce_(cost, st.group)             # additive over the blocks of the leading mode
     sparsity_error = None
     for index, sparse in enumerate(sparsity_coefficients):
         if sparse:
             # np.linalg.norm(factor, ord=1): max column abs-sum of the dim x R factor = max row abs-sum of Ft
-            term = 2 * sparse * Ft[index].abs().sum(dim=1).max().double()
+            cs = Ft[index].abs().sum(dim=1).double()
+            if sharded and index == 0:
+                _dist.allreduce_(cs, st.group)
+            term = 2 * sparse * cs.max()
             sparsity_error = term if sparsity_error is None else sparsity_error + term
     if sparsity_error is not None:
         cost.add_(sparsity_error)
@@ -122,20 +138,41 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
     Ft = list(Ft_in)
     dev = st.T.device
     nstat = 0
+    sharded = _dist.world(st.group) > 1
+    if sharded and (update_rule != "hals" or not math.isinf(alpha) or normalize[0]):
+        raise NotImplementedError("leading-mode-sharded NTF: HALS with alpha = inf and no normalisation of mode 0")
     for mode in [m for m in range(3) if m not in fixed_modes]:
         if update_rule == "hals":
             deterministic = math.isinf(alpha)
             if not deterministic:
                 torch.cuda.synchronize(dev)
                 t0 = time.time()
-            cross = None
-            for i, f in enumerate(Ft):
-                if i != mode:
-                    g = eng.gram(f)
-                    cross = g if cross is None else eng.hadamard(cross, g)
-            rhs_t = eng.mttkrp3(st.T, Ft, mode)
+            if sharded and mode != 0:
+                # MTTKRP output (R x I_mode) and the Gram of the sharded mode-0 factor (R x R) are sums over the blocks of
+                # the leading mode (ntf.py:442-449): they share an allocation and ONE all-reduce
+                R_, dim = Ft[mode].shape
+                buf = torch.empty(R_ * dim + R_ * R_, dtype=Ft[mode].dtype, device=dev)
+                rhs_t, g0 = buf[:R_ * dim].view(R_, dim), buf[R_ * dim:].view(R_, R_)
+                eng.gram(Ft[0], out=g0)
+                eng.mttkrp3(st.T, Ft, mode, out=rhs_t)
+                _dist.allreduce_(buf, st.group)
+                cross = eng.hadamard(g0, eng.gram(Ft[3 - mode]))
+            else:
+                cross = None
+                for i, f in enumerate(Ft):
+                    if i != mode:
+                        g = eng.gram(f)
+                        cross = g if cross is None else eng.hadamard(cross, g)
+                rhs_t = eng.mttkrp3(st.T, Ft, mode)
             budget = 100
             new = Ft[mode].clone()
+            if sharded and mode == 0:
+                eps, cnt, eps0 = _dist.sharded_hals_solve(eng, rhs_t, cross, new, st.group, st.guess0, budget=budget,
+                                                          delta=delta, sparsity=sparsity_coefficients[mode])
+                st.block[8 * nstat:8 * nstat + 4] = torch.tensor([eps, cnt, eps0, 0.0], dtype=torch.float64)
+                nstat += 1
+                Ft[mode] = new
+                continue
             if not deterministic:
                 torch.cuda.synchronize(dev)
                 timer = time.time() - t0

@@ -18,66 +18,7 @@ import torch.multiprocessing as mp
 import nnfac_oracle as orc
 
 
-class OracleEngine:
-    """Engine double: same method names / in-place semantics as nn_fac_amd.engine.Engine, fp64 CPU tensors."""
-
-    def gram(self, A, out=None):
-        G = A @ A.T
-        return G if out is None else out.copy_(G)
-
-    def xht(self, X, V, out=None):
-        O = V @ X.T
-        return O if out is None else out.copy_(O)
-
-    def xty(self, X, Ut, out=None):
-        O = Ut @ X
-        return O if out is None else out.copy_(O)
-
-    def frob_resid(self, X, Ut, V, out=None):
-        c = torch.sum((X - Ut.T @ V) ** 2).reshape(1)
-        return c if out is None else out.copy_(c)
-
-    def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False, snapshots=None):
-        log = []
-        cur = V.numpy().copy()
-        for s in range(nsweeps):   # one sweep at a time so that every intermediate V can be snapshotted
-            cur, *_ = orc.hals_nnls_acc(UtM.numpy(), UtU.numpy(), cur, maxiter=1, alpha=math.inf, delta=0.0,
-                                        sparsity_coefficient=sparsity, sweep_log=log)
-            if snapshots is not None:
-                snapshots[s].copy_(torch.from_numpy(cur))
-        V.copy_(torch.from_numpy(cur))
-        return torch.tensor(log, dtype=torch.float64)
-
-    def hals_solve(self, UtM, UtU, V, max_sweeps, delta=0.01, sparsity=None, normalize=False, nonzero=False,
-                   status=None):
-        Vn, eps, cnt, _ = orc.hals_nnls_acc(UtM.numpy(), UtU.numpy(), V.numpy(), maxiter=max_sweeps, alpha=math.inf,
-                                            delta=delta, sparsity_coefficient=sparsity, normalize=normalize)
-        V.copy_(torch.from_numpy(Vn))
-        st = status if status is not None else torch.zeros(8, dtype=torch.float64)
-        st[0], st[1], st[3] = eps, cnt, 0.0
-        return st
-
-
-    def mu_left(self, X, Ut, V, beta, out=None):
-        O = torch.from_numpy(orc.mu_betadivmin(Ut.numpy().T, V.numpy(), X.numpy(), beta).T.copy())
-        return O if out is None else out.copy_(O)
-
-    def mu_right_accum(self, X, Ut, V, beta):
-        U, K = Ut.T, Ut.T @ V
-        if beta == 1:
-            return U.T @ (X / K), None, U.sum(dim=0).double()
-        if beta == 2:
-            return U.T @ X, (U.T @ U) @ V, None
-        return U.T @ (K ** (beta - 2) * X), U.T @ K ** (beta - 1), None
-
-    def mu_apply(self, F, num, den, den_vec, beta, out=None):
-        d = den if den is not None else den_vec.reshape(-1, 1)
-        O = torch.clamp(F * (num / d) ** orc.gamma_beta(beta), min=1e-12)
-        return O if out is None else out.copy_(O)
-
-    def betadiv(self, X, Ut, V, beta, out=None):
-        c = torch.tensor([orc.beta_divergence(X.numpy(), (Ut.T @ V).numpy(), beta)], dtype=torch.float64)
-        return c if out is None else out.copy_(c)
+from engine_double import OracleEngine  # noqa: E402
 
 
 def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2):
@@ -209,3 +150,76 @@ def test_chunked_solve_protocol_single_rank(first, max_chunk, window, delta, bud
     assert np.array_equal(F.numpy(), want)
     if cnt - 1 + 4 <= max_chunk and cnt - 1 >= 8:
         assert len(calls) <= 2, calls
+
+
+def _ntf_worker(rank, nranks, port, shape, R, iters, sparsity, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=nranks)
+    try:
+        from nn_fac_amd import ntf as ntf_mod, dist as nd
+        T, F0 = orc.synth_ntf(shape, R, seed=3, dtype=np.float64)
+        lo, hi = nd.shard_rows(shape[0], rank, nranks)
+        st = ntf_mod._NtfState(OracleEngine(), torch.from_numpy(T[lo:hi].copy()), group=dist.group.WORLD)
+        st.guess0 = nd.SweepGuess(first=3, max_chunk=5, window=2)
+        Ft = [torch.from_numpy(F0[0][lo:hi].T.copy())] + [torch.from_numpy(f.T.copy()) for f in F0[1:]]
+        costs, sweeps = [], []
+
+        def retired(it, cost, sw):
+            costs.append(cost)
+            sweeps.extend(sw)
+            return False
+
+        Ft = ntf_mod.run_ntf_steps(st, R, Ft, iters, "hals", 2, list(sparsity), [], [False] * 3, math.inf, 0.01, retired)
+        q.put((rank, lo, hi, [f.numpy().T.copy() for f in Ft], costs, sweeps))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sparsity", [[None, None, None], [0.03, 0.02, None]])
+def test_leading_mode_sharded_ntf_equals_unsharded_oracle(sparsity):
+    """NTF with the leading mode sharded: mode-0 update local + global stopping scalar, the other modes from
+    the all-reduced MTTKRP output and mode-0 Gram, cost all-reduced -- must reproduce the unsharded oracle (ntf.py:422-477)."""
+    shape, R, iters, nranks = (23, 9, 7), 4, 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ntf_worker, args=(k, nranks, port, shape, R, iters, sparsity, q)) for k in range(nranks)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(nranks))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    T, F0 = orc.synth_ntf(shape, R, seed=3, dtype=np.float64)
+    sw = []
+    F, costs, _ = orc.compute_ntf(T, R, F0, n_iter_max=iters, tol=0, sparsity_coefficients=list(sparsity),
+                                  normalize=[False] * 3, return_costs=True, alpha=math.inf, sweeps=sw)
+    np.testing.assert_allclose(np.concatenate([x[3][0] for x in res], axis=0), F[0], rtol=1e-9, atol=1e-12)
+    for rank, lo, hi, Fl, cl, sl in res:
+        for k in (1, 2):
+            np.testing.assert_allclose(Fl[k], F[k], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(cl, costs, rtol=1e-7, atol=1e-13)
+        assert sl == sw
+
+
+@pytest.mark.parametrize("config,shape", [("B", "301,40,6"), ("C", "203,30,5"), ("D", "14,14,3")])
+def test_bench_spawns_its_own_ranks(config, shape):
+    """`python bench.py --gpus 2` outside torchrun starts two ranks itself and rank 0 reports n_gpus = 2 (the launch path the
+    driver's --gpus N runs use; here over gloo with the CPU engine double, tiny shapes)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NNF_BENCH_BACKEND="gloo", NNF_BENCH_ENGINE="engine_double:OracleEngine",
+               PYTHONPATH=os.pathsep.join([os.path.join(root, "tests"), root, os.environ.get("PYTHONPATH", "")]))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--config", config, "--shape", shape, "--no-cpu"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
+    assert out["config"]["parallelism"].startswith("row-sharded x2")

@@ -1,0 +1,142 @@
+"""Parity at BASELINE.json's FULL sizes (configs[1..3]): the HIP path vs the CPU oracle on the same seeded inputs.
+
+The mid-size fixtures (g5: 2000 x 500, g6: 40^3) pin the arithmetic; these runs pin the things that only exist at full size --
+the one-round row tilings of X H^T / the MU kernels at m = 100000, the 96-slab split-K of W^T X, the 1563-wave persistent
+U-side solve with its grid-wide stopping rule, the segmented MTTKRP over 500^3.  The oracle needs 2-6 s per iteration on
+the GPU box's host cores (bench.py's cpu_baseline runs the same thing), so a couple of iterations per configuration are
+affordable.  Tolerances: the stated fp32 ones of SURVEY.md 8c.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import nnfac_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def config_b_data():
+    return orc.synth_nmf(100000, 2000, 50, seed=0, dtype=np.float32)
+
+
+def test_config_b_hals_full_size(config_b_data, built_lib):
+    """configs[1]: 100000 x 2000 rank 50 HALS, 2 outer iterations (nmf.py:387-458): factors <= 5e-4, cost <= 1e-3,
+    inner sweep counts of all four solves equal to the fp64 oracle's."""
+    from nn_fac_amd.nmf import compute_nmf
+    X, U0, V0 = config_b_data
+    sw = []
+    U, V, costs, _ = compute_nmf(X, 50, U0, V0, n_iter_max=2, tol=0, update_rule="hals", return_costs=True,
+                                 deterministic=True, sweep_log=sw)
+    swo = []
+    Uo, Vo, co, _ = orc.compute_nmf(X.astype(np.float64), 50, U0.astype(np.float64), V0.astype(np.float64), n_iter_max=2,
+                                    tol=0, update_rule="hals", return_costs=True, deterministic=True, sweeps=swo)
+    assert sw == swo, (sw, swo)
+    assert rel(U, Uo) < 5e-4 and rel(V, Vo) < 5e-4, (rel(U, Uo), rel(V, Vo))
+    np.testing.assert_allclose(costs, co, rtol=1e-3)
+
+
+def test_config_c_mu_kl_full_size(config_b_data, built_lib):
+    """configs[2]: same data, MU beta = 1 (mu.py:84-88), 2 outer iterations: factors and cost <= 5e-5."""
+    from nn_fac_amd.nmf import compute_nmf
+    X, U0, V0 = config_b_data
+    U, V, costs, _ = compute_nmf(X, 50, U0, V0, n_iter_max=2, tol=0, update_rule="mu", beta=1, return_costs=True,
+                                 deterministic=True)
+    Uo, Vo, co, _ = orc.compute_nmf(X.astype(np.float64), 50, U0.astype(np.float64), V0.astype(np.float64), n_iter_max=2,
+                                    tol=0, update_rule="mu", beta=1, return_costs=True, deterministic=True)
+    assert rel(U, Uo) < 5e-5 and rel(V, Vo) < 5e-5, (rel(U, Uo), rel(V, Vo))
+    np.testing.assert_allclose(costs, co, rtol=5e-5)
+
+
+def test_config_d_ntf_full_size(built_lib):
+    """configs[3]: 500^3 rank 30 -- every mode's MTTKRP (ntf.py:448-449) vs fp64 unfold @ khatri_rao, then one
+    one_ntf_step(alpha = inf) (ntf.py:422-477) vs the oracle: factors <= 5e-4, cost <= 1e-3, sweep counts equal."""
+    from nn_fac_amd.engine import get_engine
+    from nn_fac_amd.ntf import compute_ntf
+    I, R = 500, 30
+    T, F0 = orc.synth_ntf((I, I, I), R, seed=0, dtype=np.float32)
+    eng = get_engine("cuda:0")
+    Td = torch.from_numpy(T).cuda()
+    Ft = [torch.from_numpy(f.T.copy()).cuda() for f in F0]
+    T64 = T.astype(np.float64)
+    F64 = [f.astype(np.float64) for f in F0]
+    for mode in range(3):
+        got = eng.mttkrp3(Td, Ft, mode).cpu().numpy().T
+        want = orc.unfold(T64, mode) @ orc.khatri_rao(F64, skip_matrix=mode)
+        assert rel(got, want) < 1e-5, (mode, rel(got, want))
+    sw, swo = [], []
+    F, costs, _ = compute_ntf(Td, R, [f.t() for f in Ft], n_iter_max=1, tol=0, return_costs=True, alpha=math.inf,
+                              sparsity_coefficients=[None] * 3, normalize=[False] * 3, sweep_log=sw)
+    Fo, co, _ = orc.compute_ntf(T64, R, F64, n_iter_max=1, tol=0, return_costs=True, alpha=math.inf,
+                                sparsity_coefficients=[None] * 3, normalize=[False] * 3, sweeps=swo)
+    assert sw == swo, (sw, swo)
+    for k in range(3):
+        assert rel(F[k].cpu().numpy(), Fo[k]) < 5e-4, (k, rel(F[k].cpu().numpy(), Fo[k]))
+    np.testing.assert_allclose(costs, co, rtol=1e-3)
+
+
+def test_config_e_block_sharded_equals_unsharded_on_one_gpu(built_lib):
+    """configs[4]'s per-GPU block shape (rank 100, 4000 columns; 2 x 20000 rows here): the row-sharded step -- chunked
+    blind sweeps + global stopping rule + the fused all-reduce of UtM | UtU -- run as TWO shards on one device, one after the
+    other with the exchanges done by hand, must give the factors of the unsharded step on the concatenated rows
+    (nmf.py:387-458).  Exercises the rank-100 sweep kernels with snapshots, which no BASELINE-sized run on one
+    GPU reaches otherwise."""
+    from nn_fac_amd.engine import get_engine
+    from nn_fac_amd import nmf as nmf_mod
+    m, n, r = 40000, 4000, 100
+    X, U0, V0 = orc.synth_nmf(m, n, r, seed=5, dtype=np.float32)
+    eng = get_engine("cuda:0")
+    Xd = torch.from_numpy(X).cuda()
+    Ut0 = torch.from_numpy(U0.T.copy()).cuda()
+    Vd = torch.from_numpy(V0).cuda()
+    ws = nmf_mod._StepBuffers(Xd, r)
+    Ut1, V1, nstat = nmf_mod._one_nmf_step_dev(eng, ws, Xd, r, Ut0, Vd, "hals", 2, [None, None], [], [False, False], True)
+    host = ws.block.cpu()
+    want_sweeps = [int(host[8 * i + 1]) - 1 for i in range(nstat)]
+    # U side through the chunked protocol on the whole block (one rank, no group): same factor bit for bit
+    from nn_fac_amd import dist as nd
+    G = eng.gram(Vd)
+    VMt = eng.xht(Xd, Vd)
+    F = Ut0.clone()
+    eps, cnt, eps0 = nd.sharded_hals_solve(eng, VMt, G, F, None, nd.SweepGuess(first=6, max_chunk=16, window=4))
+    assert cnt - 1 == want_sweeps[0]
+    assert torch.equal(F, Ut1)
+    # and against the oracle
+    Uo, Vo, co = orc.one_nmf_step(X.astype(np.float64), r, U0.astype(np.float64), V0.astype(np.float64), None, "hals", 2,
+                                  [None, None], [], [False, False], True)
+    assert rel(Ut1.t().cpu().numpy(), Uo) < 5e-4 and rel(V1.cpu().numpy(), Vo) < 5e-4
+    assert abs(float(host[16]) - co) <= 1e-3 * co
+
+
+def test_bench_single_rank_rccl_smoke(built_lib):
+    """bench.py under torchrun with ONE rank and a real RCCL process group (backend "nccl" on ROCm): init, barrier, the
+    max-over-ranks all-reduce of the timing and destroy all run on the GPU -- the N-rank launch path of the driver's
+    scaling runs, as far as a one-GPU box can take it."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, NNF_BENCH_INIT_PG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--shape", "20000,500,20", "--no-cpu", "--no-extra", "--no-fixed"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and "nccl" in out["config"]["parallelism"] and out["value"] > 0
+    assert out["roofline"]["kernel"].startswith("nnf_xty_kernel") and out["roofline"]["launch_ms"] > 0

@@ -107,6 +107,14 @@ int nnf_hals_solve_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float*
                        int r, int64_t ncols, int max_sweeps, double delta, float sparsity, unsigned flags,
                        double* status_f64, void* stream);
 
+/* max_sweeps above 1000 (one launch tags at most 1000 sweeps; nnf_hals_solve_f32 answers NNF_ERR_UNSUPPORTED): chain
+ * nnf_hals_solve_f32(..., 1000, ...) with nnf_hals_solve_continue_f32(..., sweeps_done = 1000, 2000, ..., max_sweeps = the
+ * next slice <= 1000, ...) on the same stream and status block.  A continuation whose predecessor already ended the solve
+ * (nnls.py:156) returns at once; the block finally holds eps / cnt / eps0 of the whole solve.  No host round trip. */
+int nnf_hals_solve_continue_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V,
+                                int64_t ldv, int r, int64_t ncols, int sweeps_done, int max_sweeps, double delta,
+                                float sparsity, unsigned flags, double* status_f64, void* stream);
+
 /* Same sweeps, fixed count, no stopping rule: runs exactly `nsweeps` sweeps and writes the LOCAL sum of squared steps of
  * each sweep to nodelta_f64[0..nsweeps).  Building block of the row-sharded solve (the stopping scalar is all-reduced by
  * the host between chunks).
@@ -148,6 +156,23 @@ int nnf_mu_apply_f32(nnf_ctx* ctx, const float* F, int64_t ldf, int r, int64_t c
  * nnf_mu_apply_f32 finishes (nn_fac_amd/engine.py composes them when the fused entry points return NNF_ERR_UNSUPPORTED). */
 int nnf_mu_ratio_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
                      const float* V, int64_t ldv, int r, double beta, float* R1, float* R2, int64_t ldr, void* stream);
+
+/* Deep KL-NMF (deep_nmf.py:84-113, update_rules/deep_mu.py:8-14), the three device pieces of deep_KL_mu:
+ *   nnf_mu_left_num_f32   num[k,i] = sum_j (X[i,j]/(UV)[i,j]) V[k,j]  -- the raw KL numerator of the left update (the fused
+ *                         kernel of nnf_mu_left_f32 without its division by rowsum(V)); b = U .* num  (deep_mu.py:10); r <= 64;
+ *   nnf_small_gemm_f32    out[p x cols] = A[p x q] B[q x cols], p, q <= 128 -- (W_{l+1} H_{l+1})^T = H_{l+1}^T W_{l+1}^T
+ *                         (deep_nmf.py:93,109), also the rank-sized links of the NTD contraction chains (ntd.py:539-557);
+ *   nnf_deep_kl_apply_f32 out[k,i] = max(1e-12, (b/lambda) / (W0(b exp(a/lambda)/lambda) + 1e-12)),  b = F .* num,
+ *                         a[k,i] = hsum_f64[k] - lambda log(WHnext[k,i])   (deep_mu.py:9-12; hsum = row sums of H_l, i.e.
+ *                         ONES @ H_l^T; W0 = principal Lambert W, evaluated in fp64 from the LOGARITHM of its argument so
+ *                         that exp(a/lambda) cannot overflow). */
+int nnf_mu_left_num_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                        const float* V, int64_t ldv, int r, float* num, int64_t ldnum, void* stream);
+int nnf_small_gemm_f32(nnf_ctx* ctx, const float* A, int64_t lda, int p, int q, const float* B, int64_t ldb, int64_t cols,
+                       float* out, int64_t ldo, void* stream);
+int nnf_deep_kl_apply_f32(nnf_ctx* ctx, const float* F, int64_t ldf, int r, int64_t cols, const float* num, int64_t ldnum,
+                          const double* hsum_f64, const float* WHnext, int64_t ldw, double lambda, float* out, int64_t ldo,
+                          void* stream);
 
 /* beta_divergence(X, U@V, beta) (beta_divergence.py:45-52) fused with the product; *out_f64 = the sum. */
 int nnf_betadiv_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,

@@ -26,6 +26,8 @@ SIGNATURES = {
     "nnf_xty_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32, _i64, _p, _i64, _p]),
     "nnf_frob_resid_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _p]),
     "nnf_hals_solve_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _f64, _f32, _u32, _p, _p]),
+    "nnf_hals_solve_continue_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _i32, _f64, _f32, _u32, _p,
+                                           _p]),
     "nnf_hals_sweeps_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _f32, _u32, _p, _p, _i64, _p]),
     "nnf_ctx_set_probe": (_i32, [_p, _p, _p]),
     "nnf_ctx_set_probe_kernel": (_i32, [_p, _i32]),
@@ -36,6 +38,9 @@ SIGNATURES = {
     "nnf_ntd_core_pg_f32": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f64, _f64, _i32, _f64, _p, _p]),
     "nnf_mu_ratio_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _p, _i64, _p]),
     "nnf_mu_apply_f32": (_i32, [_p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64, _p, _f64, _p, _i64, _p]),
+    "nnf_mu_left_num_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _p]),
+    "nnf_small_gemm_f32": (_i32, [_p, _p, _i64, _i32, _i32, _p, _i64, _i64, _p, _i64, _p]),
+    "nnf_deep_kl_apply_f32": (_i32, [_p, _p, _i64, _i32, _i64, _p, _i64, _p, _p, _i64, _f64, _p, _i64, _p]),
     "nnf_betadiv_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _p]),
     "nnf_mttkrp3_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p]),
     "nnf_cp3_betadiv_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _p]),

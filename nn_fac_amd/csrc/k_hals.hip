@@ -64,7 +64,7 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
                                                                int RP, float* __restrict__ V, int64_t ldv, int r,
                                                                int64_t ncols, int max_sweeps, double delta, float sp,
                                                                unsigned flags, hals_sync sy, double* __restrict__ status,
-                                                               double* __restrict__ sweep_partials) {
+                                                               double* __restrict__ sweep_partials, int sweep0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* vl = reinterpret_cast<float*>(smem);                       // [r][128]
     double* red = reinterpret_cast<double*>(smem + (size_t)r * 128 * 4 + 16);
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
     double eps0 = 0.0, eps = 1.0;
     int done = 0, err = 0;
     bool ok = true;
+    if (MODE == 0 && sweep0 > 0 && !hals_take_over(status, sweep0, delta, eps0, eps)) return;
     float* mycol = vl + threadIdx.x;
     const int64_t col0 = active ? gtid : 0;
     for (int k = 0; k < r; ++k) mycol[k * 128] = active ? V[(int64_t)k * ldv + col0] : 0.f;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
             double mine[1] = {bs}, tot[1];
             ok = grid_exchange<1>(sy, ++epoch, nblocks, mine, tot, red, &lds_flag);
             if (!ok) break;
-            if (s == 1) eps0 = tot[0];
+            if (s == 1 && sweep0 == 0) eps0 = tot[0];
             eps = tot[0];
             if (!(eps >= delta * eps0)) break;
         }
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
     if (blockIdx.x == 0 && threadIdx.x == 0 && status) {
         if (MODE == 0 && max_sweeps >= 1) {
             status[NNF_HALS_ST_EPS] = eps;
-            status[NNF_HALS_ST_CNT] = (double)(done + 1);
+            status[NNF_HALS_ST_CNT] = (double)(sweep0 + done + 1);
             status[NNF_HALS_ST_EPS0] = eps0;
         }
         if (!ok) status[NNF_HALS_ST_ERR] = 1.0;
@@ -183,16 +184,17 @@ static int pick_rp(int r) {
 template <int MODE>
 static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V, int64_t ldv,
                       int r, int64_t ncols, int nsweeps, double delta, float sparsity, unsigned flags, double* status,
-                      double* nodelta_out, hipStream_t st, float* snapshots = nullptr, int64_t snap_stride = 0) {
+                      double* nodelta_out, hipStream_t st, float* snapshots = nullptr, int64_t snap_stride = 0,
+                      int sweep0 = 0) {
     if (!ctx || !UtM || !UtU || !V || r < 1 || ncols < 1 || ldm < ncols || ldv < ncols || ldg < r || nsweeps < 0)
         return NNF_ERR_ARG;
     if (MODE == 0 && !status) return NNF_ERR_ARG;
     if (MODE == 1 && !nodelta_out && nsweeps > 0) return NNF_ERR_ARG;
-    if (r > NNF_MAX_RANK || nsweeps > 1000) return NNF_ERR_UNSUPPORTED;   // exchange tags hold the sweep index in 10 bits
+    if (r > NNF_MAX_RANK || nsweeps > NNF_HALS_MAX_SWEEPS) return NNF_ERR_UNSUPPORTED;   // (longer solves: chained by the caller)
     if (flags & ~(NNF_HALS_SPARSITY | NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) return NNF_ERR_ARG;
     const int RP = pick_rp(r);
     const float sp = (flags & NNF_HALS_SPARSITY) ? sparsity : 0.f;
-    const int max_blocks = 3 * ctx->num_cus > 2048 ? 3 * ctx->num_cus : 2048;
+    const int max_blocks = NNF_HALS_MAX_BLOCKS;
     nnf_ws_cursor cur(ctx);
     const int RS = 32 * ((RP + 31) / 32);
     const bool generic = (flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) != 0;
@@ -210,26 +212,32 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     float* dinv = Gp ? Gp + (size_t)RP * RS : nullptr;
     unsigned* counter = (unsigned*)cur.take(256);
     double* slots = (double*)cur.take((size_t)2 * max_blocks * 4 * 8);
-    double* sslots = (MODE == 0) ? (double*)cur.take((size_t)(nsweeps + 2) * max_blocks * 16) : slots;
+    // tagged granules of the fast paths: the context's dedicated region (never shared with another kernel's scratch)
+    double* sslots = (MODE == 0) ? (double*)ctx->xch : slots;
+    if (MODE == 0 && (size_t)(nsweeps + 2) * max_blocks * 16 > ctx->xch_bytes) return NNF_ERR_WORKSPACE;
     double* sweep_partials = nullptr;
     if (MODE == 1) sweep_partials = (double*)cur.take((size_t)(nsweeps > 0 ? nsweeps : 1) * max_blocks * 8);
     if (!Gp || !dinv || !counter || !slots || !sslots || (MODE == 1 && !sweep_partials))
         return NNF_ERR_WORKSPACE;
     if (!quad) {
         hipLaunchKernelGGL(nnf_hals_prep_kernel, dim3(RP), dim3(128), 0, st, UtU, ldg, r, RP, Gp, dinv,
-                           want_gs ? Gp + gs_off : (float*)nullptr, counter, MODE == 0 ? status : (double*)nullptr);
+                           want_gs ? Gp + gs_off : (float*)nullptr, counter,
+                           (MODE == 0 && sweep0 == 0) ? status : (double*)nullptr);
         NNF_CHECK_LAUNCH();
         if (nsweeps == 0) return NNF_OK;
     }
     ctx->hals_epoch = (ctx->hals_epoch + 1u) & 0x3fffffu;   // tag = epoch*1024 + sweep stays below 2^32
-    if (ctx->hals_epoch == 0u) ctx->hals_epoch = 1u;
+    if (ctx->hals_epoch == 0u) {   // wrapped (2^22 solves): clear the region so that tags of the previous round cannot match
+        if (hipMemsetAsync(ctx->xch, 0, ctx->xch_bytes, st) != hipSuccess) return NNF_ERR_LAUNCH;
+        ctx->hals_epoch = 1u;
+    }
     hals_sync sy{counter, slots, sslots, ctx->hals_epoch};
     int nblocks = 0, rc = NNF_OK;
     if (quad) {
         if ((((int64_t)(r - 1) * ldv + ncols) * 4) >= (int64_t)0x7fff0000 || (((int64_t)(r - 1) * ldm + ncols) * 4) >= (int64_t)0x7fff0000)
             return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
         hals_args a{UtM, ldm, nullptr, nullptr, nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status, sweep_partials,
-                    snapshots, snap_stride};
+                    snapshots, snap_stride, sweep0};
         rc = nnf_hals_quad_run(ctx, UtU, ldg, Gp, counter, a, &nblocks, st);
         if (rc != NNF_OK) return rc;
         if (nsweeps == 0) return NNF_OK;
@@ -248,13 +256,13 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
         if (grid > (int64_t)bpc * ctx->num_cus || grid > max_blocks) return NNF_ERR_UNSUPPORTED;
         nblocks = (int)grid;
         hipLaunchKernelGGL((nnf_hals_generic_kernel<MODE>), dim3(nblocks), dim3(128), shm, st, UtM, ldm, Gp, dinv, RS, V,
-                           ldv, r, ncols, nsweeps, delta, sp, flags, sy, status, sweep_partials);
+                           ldv, r, ncols, nsweeps, delta, sp, flags, sy, status, sweep_partials, sweep0);
         NNF_CHECK_LAUNCH();
     } else {
         if ((((int64_t)(r - 1) * ldv + ncols) * 4) >= (int64_t)0x7fff0000 || (((int64_t)(r - 1) * ldm + ncols) * 4) >= (int64_t)0x7fff0000)
             return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
         hals_args a{UtM, ldm, Gp, dinv, want_gs ? Gp + gs_off : nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status,
-                    sweep_partials, snapshots, snap_stride};
+                    sweep_partials, snapshots, snap_stride, sweep0};
         nnf_probe(ctx, NNF_PROBE_HALS, 0, st);
         if (RP <= 48) rc = nnf_hals_fast_part0(ctx, RP, a, max_blocks, &nblocks, st);
         else if (RP <= 64) rc = nnf_hals_fast_part1(ctx, RP, a, max_blocks, &nblocks, st);
@@ -288,4 +296,17 @@ extern "C" int nnf_hals_sweeps_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, 
     }
     return hals_entry<1>(ctx, UtM, ldm, UtU, ldg, V, ldv, r, ncols, nsweeps, 0.0, sparsity, flags, nullptr, nodelta_f64,
                          (hipStream_t)stream, snapshots, snap_stride);
+}
+
+// Solves longer than one launch can tag (max_sweeps > 1000, e.g. hals_nnls_acc(maxiter=5000)): the caller chains launches of
+// at most 1000 sweeps; every launch after the first is this entry with sweeps_done = the budget already spent.  The launch
+// reads the status block its predecessor left (same pointer): if that one already ended the solve (stopping rule of
+// nnls.py:156, or an error) it returns at once and leaves V and the block untouched, else it carries eps0 and the count on.
+// Nothing is read back by the host between the launches.
+extern "C" int nnf_hals_solve_continue_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg,
+                                           float* V, int64_t ldv, int r, int64_t ncols, int sweeps_done, int max_sweeps,
+                                           double delta, float sparsity, unsigned flags, double* status_f64, void* stream) {
+    if (sweeps_done < 1 || max_sweeps < 1) return NNF_ERR_ARG;
+    return hals_entry<0>(ctx, UtM, ldm, UtU, ldg, V, ldv, r, ncols, max_sweeps, delta, sparsity, flags, status_f64, nullptr,
+                         (hipStream_t)stream, nullptr, 0, sweeps_done);
 }

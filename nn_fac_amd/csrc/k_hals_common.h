@@ -7,6 +7,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define HALS_SPIN_LIMIT (1u << 22)
 
+
 struct hals_sync {
     unsigned* counter;   // generic path: monotonic arrival counter (zeroed by the prep kernel)
     double* slots;       // generic path: [2][nblocks][4] partials, parity-double-buffered
@@ -276,7 +277,20 @@ struct hals_args {
     double* sweep_partials;
     float* snapshots;     // mode 1, optional: V after every sweep, [sweep][r][ncols]
     int64_t snap_stride;
+    int sweep0;           // mode 0: sweeps already done by earlier launches of the same solve (nnf_hals_solve_continue_f32)
 };
+
+// Continuation of a solve longer than one launch can tag (NNF_HALS_MAX_SWEEPS): `status` holds the state the previous launch
+// left.  Returns false when that launch already ended the solve (stopping rule, error) -- the caller returns at once, V and
+// the status block stay as they are; else eps0 / eps are taken over.  Every workgroup reads the same words (written by the
+// previous launch, stream-ordered; rewritten by this one only after every workgroup has published its first sweep).
+__device__ __forceinline__ bool hals_take_over(const double* status, int sweep0, double delta, double& eps0, double& eps) {
+    const double pe = status[NNF_HALS_ST_EPS], pe0 = status[NNF_HALS_ST_EPS0];
+    if ((int)status[NNF_HALS_ST_CNT] - 1 != sweep0 || !(pe >= delta * pe0) || status[NNF_HALS_ST_ERR] != 0.0) return false;
+    eps0 = pe0;
+    eps = pe;
+    return true;
+}
 
 int nnf_hals_fast_part0(nnf_ctx*, int RP, const hals_args&, int max_blocks_cap, int* nblocks_out, hipStream_t);
 int nnf_hals_fast_part1(nnf_ctx*, int RP, const hals_args&, int max_blocks_cap, int* nblocks_out, hipStream_t);

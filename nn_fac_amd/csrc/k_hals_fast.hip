@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
     double eps0 = 0.0, eps = 1.0;
     int done = 0;
     bool ok = true, stopped = false;
+    if (a.mode == 0 && a.sweep0 > 0 && !hals_take_over(a.status, a.sweep0, a.delta, eps0, eps)) return;
     hals_prefetch pf;
     pf.s = 0;
     for (int s = 1; s <= a.max_sweeps; ++s) {
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
             else if constexpr (RES) ok = hals_collect1(a.sy, c, nblocks, tot, red2[s & 1][1], &lds_flag, pf);
             else ok = hals_collect(a.sy, c, nblocks, tot, red, &lds_flag, &pf);
             if (!ok) break;
-            if (c == 1) eps0 = tot;
+            if (c == 1 && a.sweep0 == 0) eps0 = tot;
             eps = tot;
             done = c;
             if (!(eps >= a.delta * eps0)) { stopped = true; break; }   // nnls.py:156: sweep c was the last one
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
         double tot;                             // ran to the sweep budget: the last sweep's sum is still due
         ok = hals_collect(a.sy, a.max_sweeps, nblocks, tot, red, &lds_flag);
         if (ok) {
-            if (a.max_sweeps == 1) eps0 = tot;
+            if (a.max_sweeps == 1 && a.sweep0 == 0) eps0 = tot;
             eps = tot;
             done = a.max_sweeps;
         }
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
     if (a.mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
         if (a.max_sweeps >= 1) {
             a.status[NNF_HALS_ST_EPS] = eps;
-            a.status[NNF_HALS_ST_CNT] = (double)(done + 1);
+            a.status[NNF_HALS_ST_CNT] = (double)(a.sweep0 + done + 1);
             a.status[NNF_HALS_ST_EPS0] = eps0;
         }
         if (!ok) a.status[NNF_HALS_ST_ERR] = 1.0;

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
     double eps0 = 0.0, eps = 1.0;
     int done = 0;
     bool ok = true, stopped = false;
+    if (a.mode == 0 && a.sweep0 > 0 && !hals_take_over(a.status, a.sweep0, a.delta, eps0, eps)) return;
     hals_prefetch pf;
     pf.s = 0;
     float vb[CH];   // V after the last confirmed sweep (a late "stop" falls back to it; V is stored once, at the end)
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
             double tot;
             ok = hals_collect_wave(a.sy, c, nblocks, tot, &pf);
             if (!ok) break;
-            if (c == 1) eps0 = tot;
+            if (c == 1 && a.sweep0 == 0) eps0 = tot;
             eps = tot;
             done = c;
             if (!(eps >= a.delta * eps0)) { stopped = true; break; }   // nnls.py:156: sweep c was the last one
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
         double tot;   // ran to the sweep budget: the last sweep's sum is still due
         ok = hals_collect_wave(a.sy, a.max_sweeps, nblocks, tot);
         if (ok) {
-            if (a.max_sweeps == 1) eps0 = tot;
+            if (a.max_sweeps == 1 && a.sweep0 == 0) eps0 = tot;
             eps = tot;
             done = a.max_sweeps;
         }
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
     if (a.mode == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
         if (a.max_sweeps >= 1) {
             a.status[NNF_HALS_ST_EPS] = eps;
-            a.status[NNF_HALS_ST_CNT] = (double)(done + 1);
+            a.status[NNF_HALS_ST_CNT] = (double)(a.sweep0 + done + 1);
             a.status[NNF_HALS_ST_EPS0] = eps0;
         }
         if (!ok) a.status[NNF_HALS_ST_ERR] = 1.0;
@@ -345,7 +346,7 @@ int nnf_hals_quad_run(nnf_ctx* ctx, const float* UtU, int64_t ldg, float* Gq, un
     if (ch == 0) return NNF_ERR_UNSUPPORTED;
     float* dinvq = Gq + (size_t)rq * rs;
     hipLaunchKernelGGL(nnf_hals_prep_quad_kernel, dim3(4 * ch), dim3(64), 0, st, UtU, ldg, a.r, ch, Gq, dinvq, counter,
-                       a.mode == 0 ? a.status : (double*)nullptr);
+                       (a.mode == 0 && a.sweep0 == 0) ? a.status : (double*)nullptr);
     NNF_CHECK_LAUNCH();
     if (a.max_sweeps == 0) return NNF_OK;
     a.Gp = Gq;

@@ -450,6 +450,10 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                     if (rk < r) {
                         float d;
                         if constexpr (BM == BM_GEN) d = den[mt][nt][reg]; else d = (float)den_vec[rk];
+                        if (gamma < 0.f) {   // raw numerator (nnf_mu_left_num_f32; wave-uniform flag)
+                            Ut_out[(int64_t)rk * lduo + i] = num[mt][nt][reg];
+                            continue;
+                        }
                         float ratio = num[mt][nt][reg] / d;
                         if (gamma != 1.f) ratio = powf(ratio, gamma);
                         Ut_out[(int64_t)rk * lduo + i] = fmaxf(Ut[(int64_t)rk * ldu + i] * ratio, 1e-12f);
@@ -556,7 +560,7 @@ static int launch_mu_right(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int
 template <int MT, int BM, bool VEC>
 static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx,
                           const float* Ut, int64_t ldu, const float* V, int64_t ldv, int r, double beta, float* Ut_out,
-                          int64_t lduo, hipStream_t st) {
+                          int64_t lduo, hipStream_t st, int raw_num = 0) {
     if (64 * ldx * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
     double* dvec = (double*)cur.take((size_t)r * 8);
     if (!dvec) return NNF_ERR_WORKSPACE;
@@ -579,7 +583,7 @@ static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int6
     if (n_hi * 256 + (grid - n_hi) * 192 < m) return NNF_ERR_UNSUPPORTED;   // (cannot happen)
     nnf_probe(ctx, NNF_PROBE_MU_LEFT, 0, st);
     hipLaunchKernelGGL((nnf_mu_left_kernel<MT, BM, VEC>), dim3((int)grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
-                       (float)beta, dvec, gamma_of(beta), Ut_out, lduo, a_vec_ok, (int)n_hi);
+                       (float)beta, dvec, raw_num ? -1.f : gamma_of(beta), Ut_out, lduo, a_vec_ok, (int)n_hi);
     NNF_CHECK_LAUNCH();
     nnf_probe(ctx, NNF_PROBE_MU_LEFT, 1, st);
     return NNF_OK;
@@ -708,6 +712,125 @@ extern "C" int nnf_mu_apply_f32(nnf_ctx* ctx, const float* F, int64_t ldf, int r
     if (fg > 2048) fg = 2048;
     hipLaunchKernelGGL(nnf_mu_finish_kernel, dim3((int)fg), dim3(256), 0, (hipStream_t)stream, F, ldf, r, cols, num, den, 1,
                        (int64_t)0, ldnum, den_vec_f64, gamma_of(beta), out, ldo);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+
+// Raw KL numerator of the left update, num[k,i] = sum_j (X[i,j] / (UV)[i,j]) V[k,j]  (mu.py:85, before the division by the
+// row sums of V): the `b` term of deep_KL_mu (deep_mu.py:10) is U .* num.  Same fused kernel as nnf_mu_left_f32.
+extern "C" int nnf_mu_left_num_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
+                                   int64_t ldu, const float* V, int64_t ldv, int r, float* num, int64_t ldnum, void* stream) {
+    const double beta = 1.0;
+    int rc = mu_args_ok(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, num);
+    if (rc != NNF_OK) return rc;
+    if (ldnum < m) return NNF_ERR_ARG;
+    if (r > 64) return NNF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    nnf_ws_cursor cur(ctx);
+    MU_DISPATCH(launch_mu_left, ctx, cur, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, num, ldnum, st, 1);
+}
+
+// out[p x cols] = A[p x q] * B[q x cols]: a rank-sized left operand against a wide matrix (deep NMF: (W_{l+1} H_{l+1})^T =
+// H_{l+1}^T W_{l+1}^T, deep_nmf.py:93; the rank-sized links of the NTD chains).  One thread per output, k in order.
+__global__ __launch_bounds__(256) void nnf_small_gemm_rect_kernel(const float* __restrict__ A, int64_t lda, int p, int q,
+                                                                  const float* __restrict__ B, int64_t ldb, int64_t cols,
+                                                                  float* __restrict__ out, int64_t ldo) {
+    extern __shared__ float sA[];
+    for (int e = threadIdx.x; e < p * q; e += 256) sA[e] = A[(int64_t)(e / q) * lda + (e % q)];
+    __syncthreads();
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < cols; j += (int64_t)gridDim.x * 256) {
+        for (int k0 = 0; k0 < p; k0 += 8) {   // 8 output rows per pass over the column of B
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int l = 0; l < q; ++l) {
+                const float b = B[(int64_t)l * ldb + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + u < p) acc[u] = fmaf(sA[(k0 + u) * q + l], b, acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u < p) out[(int64_t)(k0 + u) * ldo + j] = acc[u];
+        }
+    }
+}
+extern "C" int nnf_small_gemm_f32(nnf_ctx* ctx, const float* A, int64_t lda, int p, int q, const float* B, int64_t ldb,
+                                  int64_t cols, float* out, int64_t ldo, void* stream) {
+    if (!ctx || !A || !B || !out || p < 1 || q < 1 || cols < 1 || lda < q || ldb < cols || ldo < cols) return NNF_ERR_ARG;
+    if (p > NNF_MAX_RANK || q > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    int64_t grid = nnf_cdiv(cols, 256);
+    if (grid > 4096) grid = 4096;
+    const size_t shm = (size_t)p * q * 4;
+    if (shm > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_small_gemm_rect_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(nnf_small_gemm_rect_kernel, dim3((int)grid), dim3(256), shm, (hipStream_t)stream, A, lda, p, q, B, ldb,
+                       cols, out, ldo);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+
+// deep_KL_mu (deep_mu.py:8-14), element-wise tail:  a = hsum[k] - lambda*log(WHnext[k,i]),  b = F[k,i]*num[k,i],
+//   out = max(1e-12, (b/lambda) / (W0(b*exp(a/lambda)/lambda) + 1e-12))      with W0 the principal Lambert W branch.
+// exp(a/lambda) overflows long before its product with b does, so the argument is carried as its logarithm
+// L = log b + a/lambda - log lambda and w + log w = L is solved by Newton steps in fp64 (w > 0; quadratic from the
+// asymptotic start L - log L for L > 1, from z/(1+z) below); for L < -36 W0(z) = z to double precision.
+__device__ __forceinline__ double nnf_lambertw_logarg(double L) {
+    if (L < -36.0) return exp(L);
+    double w;
+    if (L > 1.0) {
+        w = L - log(L);
+    } else {
+        const double z = exp(L);
+        w = z / (1.0 + z);
+        if (w < 1e-300) return z;
+    }
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+        const double f = w + log(w) - L;
+        const double wn = w - f * w / (1.0 + w);
+        const double d = fabs(wn - w);
+        w = wn > 0.0 ? wn : 0.5 * w;
+        if (d <= 1e-15 * fabs(w)) break;
+    }
+    return w;
+}
+__global__ __launch_bounds__(256) void nnf_deep_kl_apply_kernel(const float* __restrict__ F, int64_t ldf, int r, int64_t cols,
+                                                                const float* __restrict__ num, int64_t ldn,
+                                                                const double* __restrict__ hsum,
+                                                                const float* __restrict__ WHn, int64_t ldw, double lambda,
+                                                                float* __restrict__ out, int64_t ldo) {
+    const int64_t total = (int64_t)r * cols;
+    const double loglam = log(lambda);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t k = e / cols, i = e - k * cols;
+        const double b = (double)F[k * ldf + i] * (double)num[k * ldn + i];
+        const double a = hsum[k] - lambda * log((double)WHn[k * ldw + i]);
+        double res;
+        const double q = a / lambda;
+        const double Lz = log(b) + q - loglam;
+        if (!(b > 0.0)) {
+            res = 0.0;   // b = 0: numerator 0 (the reference gives 0 / (0 + eps) = 0, then the 1e-12 floor)
+        } else if (q > 709.782712893384 || Lz > 709.782712893384) {
+            // the reference forms exp(a/lambda) and b*exp(.)/lambda in float64 (deep_mu.py:11): beyond log(DBL_MAX) that is
+            // +inf, lambertw(inf) = inf and the quotient is 0 -> the floor.  Kept: results identical to the reference's.
+            res = 0.0;
+        } else {
+            const double w = nnf_lambertw_logarg(Lz);
+            res = (b / lambda) / (w + 1e-12);
+        }
+        out[k * ldo + i] = (float)fmax(1e-12, res);
+    }
+}
+extern "C" int nnf_deep_kl_apply_f32(nnf_ctx* ctx, const float* F, int64_t ldf, int r, int64_t cols, const float* num,
+                                     int64_t ldnum, const double* hsum_f64, const float* WHnext, int64_t ldw, double lambda,
+                                     float* out, int64_t ldo, void* stream) {
+    if (!ctx || !F || !num || !hsum_f64 || !WHnext || !out || r < 1 || cols < 1 || ldf < cols || ldnum < cols ||
+        ldw < cols || ldo < cols || !(lambda > 0.0))
+        return NNF_ERR_ARG;
+    int64_t fg = nnf_cdiv((int64_t)r * cols, 256);
+    if (fg > 4096) fg = 4096;
+    hipLaunchKernelGGL(nnf_deep_kl_apply_kernel, dim3((int)fg), dim3(256), 0, (hipStream_t)stream, F, ldf, r, cols, num, ldnum,
+                       hsum_f64, WHnext, ldw, lambda, out, ldo);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
 }

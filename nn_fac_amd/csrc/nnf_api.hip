@@ -35,10 +35,16 @@ extern "C" int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_by
     c->hals_epoch = 0u;
     c->probe[0] = c->probe[1] = nullptr;
     c->probe_id = NNF_PROBE_XTY;
+    c->xch = nullptr;
+    c->xch_bytes = (size_t)(NNF_HALS_MAX_SWEEPS + 2) * NNF_HALS_MAX_BLOCKS * 16;
     hipError_t e = hipMalloc((void**)&c->ws, c->ws_bytes);
-    if (e == hipSuccess) e = hipMemset(c->ws, 0, c->ws_bytes);   // exchange words must not start as look-alike tags
+    if (e == hipSuccess) e = hipMemset(c->ws, 0, c->ws_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->xch, c->xch_bytes);
+    if (e == hipSuccess) e = hipMemset(c->xch, 0, c->xch_bytes);   // exchange words must not start as look-alike tags
     (void)hipSetDevice(prev);
     if (e != hipSuccess) {
+        if (c->ws) (void)hipFree(c->ws);
+        if (c->xch) (void)hipFree(c->xch);
         delete c;
         return NNF_ERR_WORKSPACE;
     }
@@ -49,6 +55,7 @@ extern "C" int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_by
 extern "C" int nnf_ctx_destroy(nnf_ctx* ctx) {
     if (!ctx) return NNF_ERR_ARG;
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->xch) (void)hipFree(ctx->xch);
     delete ctx;
     return NNF_OK;
 }

@@ -11,9 +11,15 @@ struct nnf_ctx {
     size_t ws_bytes;
     char* ws;          // device scratch (split-K slabs, partial sums, barrier words); zeroed once at creation
     unsigned hals_epoch;   // salt of the HALS exchange tags (k_hals_common.h)
+    char* xch;             // HALS exchange granules: a region of its own that no other kernel ever carves from, so a word
+    size_t xch_bytes;      // left there can only be an older HALS tag (never look-alike float data); zeroed at creation
+                           // and whenever the epoch wraps
     hipEvent_t probe[2];   // optional caller-owned events recorded around ONE main kernel (nnf_ctx_set_probe[_kernel])
     int probe_id;          // which kernel the probe brackets (NNF_PROBE_*, include/nnfac_hip.h); default: W^T X
 };
+
+#define NNF_HALS_MAX_SWEEPS 1000   // per launch: the exchange tag holds the sweep index in 10 bits (k_hals_common.h)
+#define NNF_HALS_MAX_BLOCKS 2048   // workgroups of one persistent solve (3 * 256 CUs fits)
 
 // measurement hook: record the caller's event `which` (0 begin, 1 end) if the probe is armed for kernel `id`
 static inline void nnf_probe(nnf_ctx* c, int id, int which, hipStream_t st) {

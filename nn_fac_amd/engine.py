@@ -132,6 +132,19 @@ class Engine:
             f |= HALS_NONZERO
         return f
 
+    ROWSYNC_MAX_COLUMNS = 131072          # normalize / nonzero: one column per resident thread (k_hals.hip generic path)
+
+    def _check_rowsync_columns(self, rowsync, ncols):
+        """normalize=True / nonzero=True need a grid-wide reduction per ROW update, which the generic kernel does with every
+        column resident (one per thread, 4 x 128-thread workgroups per CU): say so here instead of a bare status code."""
+        if rowsync and ncols > self.ROWSYNC_MAX_COLUMNS:
+            raise EngineError(f"hals_nnls_acc with normalize=True or nonzero=True is built for at most "
+                              f"{self.ROWSYNC_MAX_COLUMNS} columns (got {ncols}): every row update needs all columns "
+                              f"resident on the device at once; normalise the shorter factor, or split the columns and "
+                              f"normalise on the host between outer iterations")
+
+    HALS_MAX_SWEEPS_PER_LAUNCH = 1000     # NNF_HALS_MAX_SWEEPS (exchange tags hold the sweep index in 10 bits)
+
     def hals_solve(self, UtM, UtU, V, max_sweeps, delta=0.01, sparsity=None, normalize=False, nonzero=False,
                    status=None):
         """In-place accelerated HALS on V (r x ncols); returns the 8-double status tensor (device, not synced)."""
@@ -140,11 +153,20 @@ class Engine:
         if UtM.shape != (r, ncols) or UtU.shape[0] < r or UtU.shape[1] < r:
             raise EngineError("hals_solve: shape mismatch")
         st = status if status is not None else torch.empty(ST_WORDS, dtype=torch.float64, device=V.device)
+        flags = self._hals_flags(sparsity, normalize, nonzero)
+        self._check_rowsync_columns(normalize or nonzero, ncols)
+        total, first = int(max_sweeps), min(int(max_sweeps), self.HALS_MAX_SWEEPS_PER_LAUNCH)
         _lib.check(self.lib.nnf_hals_solve_f32(self.ctx, _ptr(UtM), _ld(UtM), _ptr(UtU), _ld(UtU), _ptr(V),
-                                               _ld(V), r, ncols, int(max_sweeps), float(delta),
-                                               float(sparsity or 0.0),
-                                               self._hals_flags(sparsity, normalize, nonzero), _ptr(st),
-                                               self._stream()), "nnf_hals_solve_f32")
+                                               _ld(V), r, ncols, first, float(delta), float(sparsity or 0.0), flags,
+                                               _ptr(st), self._stream()), "nnf_hals_solve_f32")
+        done = first
+        while done < total:      # maxiter beyond one launch's tag range: chained launches, no host round trip in between
+            step = min(total - done, self.HALS_MAX_SWEEPS_PER_LAUNCH)
+            _lib.check(self.lib.nnf_hals_solve_continue_f32(self.ctx, _ptr(UtM), _ld(UtM), _ptr(UtU), _ld(UtU), _ptr(V),
+                                                            _ld(V), r, ncols, done, step, float(delta),
+                                                            float(sparsity or 0.0), flags, _ptr(st), self._stream()),
+                       "nnf_hals_solve_continue_f32")
+            done += step
         return st
 
     def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False, snapshots=None):
@@ -152,6 +174,7 @@ class Engine:
         snapshots (optional, contiguous float32 [>= nsweeps, r, ncols]): block s receives V after sweep s+1."""
         _chk2d(UtM, "hals UtM"), _chk2d(UtU, "hals UtU"), _chk2d(V, "hals V")
         r, ncols = V.shape
+        self._check_rowsync_columns(normalize or nonzero, ncols)
         nd = torch.zeros(max(int(nsweeps), 1), dtype=torch.float64, device=V.device)
         sp, ss = C.c_void_p(0), 0
         if snapshots is not None:
@@ -245,6 +268,43 @@ class Engine:
                                              _ld(den) if den is not None else 0,
                                              _ptr(den_vec) if den_vec is not None else None, float(beta), _ptr(O),
                                              _ld(O), self._stream()), "nnf_mu_apply_f32")
+        return O
+
+    # ---- deep KL-NMF (deep_mu.py:8-14) -------------------------------------------------------------
+    def mu_left_num(self, X, Ut, V, out=None):
+        """Raw KL numerator of the left update: num[k,i] = sum_j (X[i,j] / (UV)[i,j]) V[k,j]  (r x m)."""
+        _chk2d(X, "mu X"), _chk2d(Ut, "mu Ut"), _chk2d(V, "mu V")
+        m, n = X.shape
+        r = Ut.shape[0]
+        if Ut.shape[1] != m or V.shape != (r, n):
+            raise EngineError("mu_left_num: shape mismatch")
+        O = out if out is not None else torch.empty((r, m), dtype=torch.float32, device=X.device)
+        _lib.check(self.lib.nnf_mu_left_num_f32(self.ctx, _ptr(X), m, n, _ld(X), _ptr(Ut), _ld(Ut), _ptr(V), _ld(V), r,
+                                                _ptr(O), _ld(O), self._stream()), "nnf_mu_left_num_f32")
+        return O
+
+    def small_gemm(self, A, B, out=None):
+        """A (p x q, p, q <= 128) @ B (q x cols) -> p x cols."""
+        _chk2d(A, "small_gemm A"), _chk2d(B, "small_gemm B")
+        p, q = A.shape
+        if B.shape[0] != q:
+            raise EngineError("small_gemm: shape mismatch")
+        cols = B.shape[1]
+        O = out if out is not None else torch.empty((p, cols), dtype=torch.float32, device=A.device)
+        _lib.check(self.lib.nnf_small_gemm_f32(self.ctx, _ptr(A), _ld(A), p, q, _ptr(B), _ld(B), cols, _ptr(O), _ld(O),
+                                               self._stream()), "nnf_small_gemm_f32")
+        return O
+
+    def deep_kl_apply(self, Ft, num, hsum, WHnext_t, lam, out=None):
+        """max(1e-12, (b/lam) / (W0(b exp(a/lam)/lam) + 1e-12)) with b = Ft .* num, a = hsum[k] - lam log(WHnext_t)."""
+        _chk2d(Ft, "deep F"), _chk2d(num, "deep num"), _chk2d(WHnext_t, "deep WHnext")
+        r, cols = Ft.shape
+        if num.shape != (r, cols) or WHnext_t.shape != (r, cols) or hsum.dtype != torch.float64 or hsum.numel() != r:
+            raise EngineError("deep_kl_apply: shape mismatch")
+        O = out if out is not None else torch.empty_like(Ft)
+        _lib.check(self.lib.nnf_deep_kl_apply_f32(self.ctx, _ptr(Ft), _ld(Ft), r, cols, _ptr(num), _ld(num), _ptr(hsum),
+                                                  _ptr(WHnext_t), _ld(WHnext_t), float(lam), _ptr(O), _ld(O),
+                                                  self._stream()), "nnf_deep_kl_apply_f32")
         return O
 
     PROBE_KERNELS = {"xty": 0, "xht": 1, "cost": 2, "hals": 3, "mu_left": 4, "mu_right": 5, "mttkrp": 6}

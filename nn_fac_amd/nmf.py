@@ -156,6 +156,8 @@ class _StepBuffers:
             self.host = self.host.pin_memory()
         self.select(0)
         self.guess_u = _dist.SweepGuess()
+        self.guess_v = _dist.SweepGuess()
+        self.safe_solve = False           # set by run_steps after a persistent solve timed out (chunked launches from then on)
         # the r x r Gram of an update is independent of its cross product (nmf.py:407-408, :432-433): it runs on a side
         # stream, with its own context (a context's workspace serves one stream at a time), under the streaming kernel
         self.side_eng, self.side_stream = _engine.get_side_engine(X.device) if X.is_cuda else (None, None)
@@ -185,12 +187,18 @@ def _gram_on_side(ws, eng, A, out, start_from=None):
         return side.record_event(), copy
 
 
-def _raise_on_status(host, nstat):
+class _SolveTimedOut(Exception):
+    """A persistent HALS solve gave up waiting for its other workgroups (status word 1)."""
+
+
+def _raise_on_status(host, nstat, timeout_ok=False):
     for i in range(nstat):
         code = int(host[8 * i + _engine.ST_ERR])
         if code == 2:
             raise err.ZeroColumnWhenUnautorized("A column of U is zero with nonzero condition")
         if code != 0:
+            if timeout_ok:
+                raise _SolveTimedOut()
             raise err.EngineError("hals grid barrier timed out; result invalid")
 
 
@@ -242,18 +250,40 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
 
     def retire():
         nonlocal result, stop
-        step = pending.pop(0)
+        step = pending[0]
         if step["ev"] is not None:
             step["ev"].synchronize()
         host = ws.host[step["slot"]]
-        _raise_on_status(host, step["nstat"])
+        _raise_on_status(host, step["nstat"], timeout_ok=not getattr(ws, "safe_solve", False))
+        pending.pop(0)                     # (a step that timed out stays at the head: run_steps resumes from it)
         result = (step["Ut"], step["V"])
         stop = bool(retired(step["it"], float(host[16]),
                             [int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(step["nstat"])]))
 
+    def drain():
+        if cuda:
+            main.synchronize()
+            if ws.cost_stream is not None:
+                ws.cost_stream.synchronize()
+
+    def fall_back():
+        """A persistent solve timed out: its workgroups were not all resident at once (another process's kernels hold CUs --
+        on a GPU this process owns alone that does not happen).  Everything in flight is dropped, and the loop resumes from
+        the last retired factors with every HALS solve going through the chunked fixed-count launches of dist.py -- no
+        workgroup of those waits for another, the stopping rule is applied between chunks (bitwise the same factors,
+        tests/test_dist_gloo.py) -- and the cost inside the step.  Slower (one host round trip per chunk), never wrong."""
+        nonlocal overlap, depth, owed, costed, stop
+        drain()
+        pending.clear()
+        ws.safe_solve = True
+        overlap, depth, owed, costed = False, PIPELINE_DEPTH, None, None
+        warnings.warn("nn_fac_amd: a persistent HALS solve timed out waiting for its workgroups (GPU shared with another "
+                      "process?); falling back to chunked launches for the rest of this run")
+
     owed = None           # overlap: the step whose cost has not been launched yet
     costed = None         # overlap: the step whose cost was launched during the previous step
-    for iteration in range(n_iter):
+    iteration = 0
+    while iteration < n_iter:
         ws.select(iteration % ws.blocks.shape[0])
         hooks = {}
         if overlap and owed is not None:
@@ -273,14 +303,22 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
         else:
             ws.host[ws.slot].copy_(ws.block)
         pending.append(step)
-        if len(pending) > depth:
-            retire()
-            if stop:
-                break
-    if overlap and not stop and owed is not None and owed["ev"] is None:
-        cost_of(owed, main)               # the last step has no V-side solve behind it to hide under
-    while pending and not stop:
-        retire()
+        iteration += 1
+        try:
+            if len(pending) > depth:
+                retire()
+                if stop:
+                    break
+            if iteration == n_iter:
+                if overlap and not stop and owed is not None and owed["ev"] is None:
+                    cost_of(owed, main)               # the last step has no V-side solve behind it to hide under
+                while pending and not stop:
+                    retire()
+        except _SolveTimedOut:
+            failed = pending[0]["it"]             # the step being retired is still at the head of the list
+            fall_back()
+            Ut, V = result                        # factors of the last iteration that retired cleanly
+            iteration = failed
     if cuda and (pending or overlap):     # dropped speculative iterations still use the shared scratch: let them drain
         main.synchronize()
         if overlap:
@@ -293,10 +331,17 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
 HALS_INNER = {"maxiter": 100, "delta": 0.01}
 
 
-def _hals_call(eng, cross, gram, F, sparsity, normalize, deterministic, timer, status):
-    """hals_nnls_acc(..., maxiter=100, atime=timer, alpha=inf|0.5, delta=0.01) of nmf.py:415-419,440-444, in place."""
+def _hals_call(eng, cross, gram, F, sparsity, normalize, deterministic, timer, status, safe=None):
+    """hals_nnls_acc(..., maxiter=100, atime=timer, alpha=inf|0.5, delta=0.01) of nmf.py:415-419,440-444, in place.
+    `safe` (a dist.SweepGuess): the solve runs as chunked fixed-count launches whose workgroups never wait for each other
+    (run_steps' fall-back after a persistent solve timed out); row normalisation needs the persistent kernel and cannot."""
     from .update_rules.nnls import sweep_budget
     budget = HALS_INNER["maxiter"]
+    if safe is not None and deterministic and not normalize:
+        eps, cnt, eps0 = _dist.sharded_hals_solve(eng, cross, gram, F, None, safe, budget=budget, delta=HALS_INNER["delta"],
+                                                  sparsity=sparsity)
+        status[:4] = torch.tensor([eps, cnt, eps0, 0.0], dtype=torch.float64)
+        return status
     if not deterministic:
         # wall-clock rule: rho = atime / btime with btime = time of one sweep (nnls.py:190-194)
         probe = F.clone()
@@ -385,7 +430,7 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                 ws.block[8 * nstat:8 * nstat + 4] = torch.tensor([eps, cnt, eps0, 0.0], dtype=torch.float64)
             else:
                 _hals_call(eng, ws.VMt, ws.G, Ut, sparsity_coefficients[0], normalize[0], deterministic, timer,
-                           ws.block[8 * nstat:8 * nstat + 8])
+                           ws.block[8 * nstat:8 * nstat + 8], safe=ws.guess_u if getattr(ws, "safe_solve", False) else None)
             nstat += 1
         else:
             Ut = eng.mu_left(X, Ut_in, V, beta)         # nmf.py:422
@@ -412,7 +457,7 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             if before_v_solve is not None:
                 before_v_solve()
             _hals_call(eng, ws.UtM, ws.G2, V, sparsity_coefficients[1], normalize[1], deterministic, timer,
-                       ws.block[8 * nstat:8 * nstat + 8])
+                       ws.block[8 * nstat:8 * nstat + 8], safe=ws.guess_v if getattr(ws, "safe_solve", False) else None)
             nstat += 1
         else:
             if sharded:

@@ -409,6 +409,66 @@ def multilayer_beta_NMF(data, all_ranks, beta=1, n_iter_max_each_nmf=100, init_e
 
 
 # --------------------------------------------------------------------------------------
+# f4: deep KL-NMF  (nn_fac/deep_nmf.py:13-113, nn_fac/update_rules/deep_mu.py:8-14)
+# --------------------------------------------------------------------------------------
+def deep_KL_mu(W_Lm1, W_L, H_L, WH_Lp1, lambda_):
+    """deep_mu.py:8-14 (scipy.special.lambertw, principal branch, real part; eps = 1e-12)."""
+    from scipy.special import lambertw
+    ONES = np.ones_like(W_Lm1)
+    a = ONES @ H_L.T - lambda_ * np.log(WH_Lp1)
+    b = W_L * ((W_Lm1 / (W_L @ H_L)) @ H_L.T)
+    lambert = lambertw(b * np.exp(a / lambda_) / lambda_, k=0).real
+    return np.maximum(1e-12, (1 / lambda_ * b) / (lambert + 1e-12))
+
+
+def one_step_deep_KL_nmf(data, W, H, all_ranks, lambda_, delta):
+    """deep_nmf.py:84-113."""
+    L = len(all_ranks)
+    errors = []
+    for layer in range(L):
+        D = data if layer == 0 else W[layer - 1]
+        H[layer] = switch_alternate_mu(D, W[layer], H[layer], 1, "H")
+        W[layer], H[layer] = normalize_WH(W[layer], H[layer], "H")
+        if layer == L - 1:
+            W[layer] = switch_alternate_mu(D, W[layer], H[layer], 1, "W")
+        else:
+            lam = lambda_[layer + 1] / lambda_[layer]
+            W[layer] = deep_KL_mu(D, W[layer], H[layer], W[layer + 1] @ H[layer + 1], lam)
+        errors.append(beta_divergence(D, W[layer] @ H[layer], 1))
+    return W, H, errors
+
+
+def deep_KL_NMF(data, all_ranks, n_iter_max_each_nmf=100, n_iter_max_deep_loop=100, init="multilayer_nmf",
+                init_multi_layer="nndsvd", W_0=None, H_0=None, delta=1e-6, tol=1e-6, deterministic=False, seed=0):
+    """deep_nmf.py:13-82.  Returns W, H, reconstruction_errors (L x (n_iter_max_deep_loop + 1), NaN where not reached)."""
+    L = len(all_ranks)
+    assert L > 1
+    rec = np.full((L, n_iter_max_deep_loop + 1), np.nan)
+    if sorted(all_ranks, reverse=True) != all_ranks:
+        raise ValueError("The ranks of deep NMF should be decreasing.")
+    if init == "multilayer_nmf":
+        W, H, e = multilayer_beta_NMF(data, all_ranks, beta=1, n_iter_max_each_nmf=n_iter_max_each_nmf,
+                                      init_each_nmf=init_multi_layer, deterministic=deterministic, seed=seed)
+        rec[:, 0] = e[:, -1]
+    elif init == "custom":
+        W, H = [w.copy() for w in W_0], [h.copy() for h in H_0]
+        rec[0, 0] = beta_divergence(data, W[0] @ H[0], 1)
+        for i in range(1, L):
+            rec[i, 0] = beta_divergence(W[i - 1], W[i] @ H[i], 1)
+    else:
+        raise ValueError("The init method is not supported.")
+    lambda_ = 1 / np.array(rec[:, 0])
+    glob = [lambda_.T @ rec[:, 0]]
+    for it in range(n_iter_max_deep_loop):
+        W, H, errors = one_step_deep_KL_nmf(data, W, H, all_ranks, lambda_, delta)
+        rec[:, it + 1] = lambda_ * errors
+        glob.append(lambda_.T @ errors)
+        if it > 1 and abs(glob[-2] - glob[-1]) < tol:
+            break
+    return W, H, rec
+
+
+# --------------------------------------------------------------------------------------
 # tensorly 0.6.0 semantics used by ntf.py (published behaviour; see SURVEY.md appendix B)
 # --------------------------------------------------------------------------------------
 def unfold(t, mode):

@@ -95,3 +95,17 @@ def test_host_helpers():
     assert gamma_beta(0) == 0.5 and gamma_beta(1) == 1 and gamma_beta(2) == 1 and gamma_beta(3) == 0.5
     U, V = nmf_initialization(np.zeros((73, 25)), 9, "random", deterministic=True, seed=0)
     assert abs(U[0][0] - 0.5488135) < 1e-7 and abs(V[0][0] - 1.15834001e-01) < 1e-7   # NMF_tests.py:40-41
+
+
+def test_sweep_kernels_never_touch_a_load_destination_before_its_wait(built_lib):
+    """tools/check_sweep_spills.py on the ISA the build kept next to the sweep objects (k_hals_fast: hand-issued s_load into
+    SGPRs; k_hals_quad: hand-issued ds_read_b128 into VGPRs): no instruction of a sweep block may name a register with such a
+    load in flight before the wait that covers it -- the abort class of round 1 (a rank instantiation over the SGPR budget
+    made the allocator move an in-flight buffer).  Runs in seconds after `make`; compiles to assembly otherwise."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_sweep_spills", os.path.join(ROOT, "tools", "check_sweep_spills.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, blocks = mod.check_all()
+    assert blocks >= 60, blocks          # every rank instantiation of both kernels was seen
+    assert not bad, bad[:3]

@@ -223,3 +223,50 @@ def test_bench_spawns_its_own_ranks(config, shape):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
     assert out["config"]["parallelism"].startswith("row-sharded x2")
+
+
+def test_run_steps_falls_back_to_chunked_solves_after_a_timeout():
+    """nn_fac_amd.nmf.run_steps: a persistent HALS solve that reports a time-out (status word 1: its workgroups were not all
+    resident, e.g. a GPU shared with another process) must not kill the factorisation -- everything in flight is dropped, the
+    loop resumes from the last clean iteration with chunked fixed-count solves, and the run ends with the factors, costs and
+    sweep counts of an undisturbed one (engine double: the host logic is what is under test)."""
+    import warnings
+    from nn_fac_amd import nmf as nmf_mod
+    X, U0, V0 = orc.synth_nmf(120, 30, 5, seed=4, dtype=np.float64)
+    iters = 6
+
+    class Flaky(OracleEngine):
+        calls = 0
+
+        def hals_solve(self, *a, **kw):
+            Flaky.calls += 1
+            st = super().hals_solve(*a, **kw)
+            if Flaky.calls == 5:                 # V-side solve of the third iteration
+                st[3] = 1.0
+            return st
+
+    def run(eng):
+        Xt = torch.from_numpy(X)
+        ws = nmf_mod._StepBuffers(Xt, 5, dtype=torch.float64)
+        ws.guess_u = nmf_mod._dist.SweepGuess(first=3, max_chunk=5, window=2)
+        ws.guess_v = nmf_mod._dist.SweepGuess(first=3, max_chunk=5, window=2)
+        costs, sweeps = [], []
+
+        def retired(it, cost, sw):
+            costs.append((it, cost))
+            sweeps.append(sw)
+            return False
+        Ut, V = nmf_mod.run_steps(eng, ws, Xt, 5, torch.from_numpy(U0.T.copy()), torch.from_numpy(V0.copy()), iters, "hals", 2,
+                                  [None, None], [], [False, False], True, retired)
+        return Ut.numpy(), V.numpy(), costs, sweeps, ws
+
+    Ut0, Vr0, c0, s0, _ = run(OracleEngine())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        Ut1, Vr1, c1, s1, ws1 = run(Flaky())
+    assert ws1.safe_solve and any("timed out" in str(x.message) for x in w)
+    assert [i for i, _ in c1] == list(range(iters))          # every iteration retired exactly once, in order
+    np.testing.assert_allclose(Ut1, Ut0, rtol=1e-12)
+    np.testing.assert_allclose(Vr1, Vr0, rtol=1e-12)
+    np.testing.assert_allclose([c for _, c in c1], [c for _, c in c0], rtol=1e-12)
+    assert s1 == s0

@@ -412,3 +412,48 @@ def test_row_sharded_two_ranks_on_one_gpu(built_lib, rule, beta):
                           "127.0.0.1", "--master-port", "29533", os.path.join(root, "tools", "dist_gpu_check.py"), rule,
                           str(beta)], capture_output=True, text=True, timeout=300, env=env)
     assert "DIST_GPU_CHECK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("layout", LAYOUTS + ["generic"])
+@pytest.mark.parametrize("maxiter", [2500, 1001])
+def test_hals_more_sweeps_than_one_launch_tags(layout, maxiter, monkeypatch, built_lib):
+    """hals_nnls_acc(maxiter > 1000) -- the reference accepts any maxiter (nnls.py:156); one launch tags at most 1000 sweeps,
+    longer solves are chained launches (nnf_hals_solve_continue_f32) that carry eps0 and the count in the status block.
+    delta = 0 runs to the budget across two / three launches: sweep count equal to the oracle's, factors within tolerance."""
+    from nn_fac_amd.update_rules.nnls import hals_nnls_acc
+    if layout != "generic":
+        monkeypatch.setenv("NNF_HALS_FORCE", layout)
+    rng = np.random.RandomState(maxiter)
+    r, n = 6, 150
+    U = rng.rand(40, r)
+    M = U @ rng.rand(r, n) + 1e-2 * rng.rand(40, n)
+    UtU, UtM, V0 = U.T @ U, U.T @ M, rng.rand(r, n)
+    kw = dict(maxiter=maxiter, delta=0.0, alpha=math.inf, normalize=(layout == "generic"))
+    want, eps_o, cnt_o, _ = orc.hals_nnls_acc(UtM, UtU, V0, **kw)
+    V, eps, cnt, _ = hals_nnls_acc(UtM, UtU, V0, **kw)
+    assert cnt == cnt_o == maxiter + 1
+    assert rel(V, want) < 1e-3, rel(V, want)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS + ["generic"])
+@pytest.mark.parametrize("slice_", [1, 3, 7])
+def test_hals_chained_launches_equal_one_launch(layout, slice_, monkeypatch, built_lib):
+    """The chaining protocol at small counts: with the per-launch slice forced down to 1 / 3 / 7 sweeps the same solves -- stop
+    by the rule in the first launch, in a later one, exactly at a slice end, at the budget -- must give bit for bit the factor,
+    eps and cnt of the single launch (launches queued behind the one that stopped leave V and the status block alone)."""
+    from nn_fac_amd import engine as eng_mod
+    from nn_fac_amd.update_rules.nnls import hals_nnls_acc
+    if layout != "generic":
+        monkeypatch.setenv("NNF_HALS_FORCE", layout)
+    rng = np.random.RandomState(11)
+    r, n = 10, 300
+    U = rng.rand(80, r)
+    M = U @ rng.rand(r, n) + 1e-2 * rng.rand(80, n)
+    UtU, UtM, V0 = U.T @ U, U.T @ M, rng.rand(r, n)
+    for maxiter, delta in ((100, 0.01), (100, 1e-4), (21, 0.0), (14, 1e-3), (2, 0.5)):
+        kw = dict(maxiter=maxiter, delta=delta, alpha=math.inf, normalize=(layout == "generic"))
+        V1, eps1, cnt1, _ = hals_nnls_acc(UtM, UtU, V0, **kw)
+        monkeypatch.setattr(eng_mod.Engine, "HALS_MAX_SWEEPS_PER_LAUNCH", slice_)
+        V2, eps2, cnt2, _ = hals_nnls_acc(UtM, UtU, V0, **kw)
+        monkeypatch.setattr(eng_mod.Engine, "HALS_MAX_SWEEPS_PER_LAUNCH", 1000)
+        assert cnt1 == cnt2 and eps1 == eps2 and np.array_equal(V1, V2), (maxiter, delta, cnt1, cnt2)

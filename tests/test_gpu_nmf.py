@@ -252,3 +252,54 @@ def test_rank_one(built_lib, rule, beta, m, n):
     assert rel(U, Uo) < HALS_FRO and rel(V, Vo) < HALS_FRO
     # (n = 1: a rank-1 model fits a single column exactly, the cost is rounding noise in either precision)
     np.testing.assert_allclose(costs, co, rtol=HALS_COST, atol=1e-9 * float(np.sum(X.astype(np.float64) ** 2)))
+
+
+# ---- deep KL-NMF (deep_nmf.py:13-113, deep_mu.py:8-14) vs the real reference's outputs (g10) ----
+def test_deep_kl_mu_against_reference_fixture(golden, built_lib):
+    """deep_KL_mu: KL numerator (fused MFMA kernel) + Lambert-W tail; lambda from 0.02 (np.exp overflows in the reference,
+    the update collapses to its 1e-12 floor -- same here) to 60.  Single-kernel tolerance 1e-5."""
+    from nn_fac_amd.update_rules.deep_mu import deep_KL_mu
+    g = golden("g10_deep_nmf.npz")
+    for i, lam in enumerate(g["mu_lambdas"]):
+        out = deep_KL_mu(g["mu_W_Lm1"], g["mu_W_L"].copy(), g["mu_H_L"], g["mu_WHn"], float(lam))
+        assert isinstance(out, np.ndarray) and out.shape == g["mu_W_L"].shape
+        np.testing.assert_allclose(out, g[f"mu_out{i}"], rtol=2e-5, atol=0)
+
+
+def test_deep_nmf_one_step_against_reference_fixture(golden, built_lib):
+    from nn_fac_amd.deep_nmf import one_step_deep_KL_nmf
+    g = golden("g10_deep_nmf.npz")
+    ranks = [int(x) for x in g["step_ranks"]]
+    W0 = [g[f"step_W0_{i}"].copy() for i in range(3)]
+    H0 = [g[f"step_H0_{i}"].copy() for i in range(3)]
+    W, H, e = one_step_deep_KL_nmf(g["step_data"], W0, H0, ranks, g["step_lambda"], 1e-6)
+    for i in range(3):
+        assert rel(W[i], g[f"step_W_{i}"]) < 2e-5 and rel(H[i], g[f"step_H_{i}"]) < 2e-5, i
+    np.testing.assert_allclose(e, g["step_errors"], rtol=5e-5)
+
+
+def test_deep_nmf_driver_against_reference_fixture(golden, built_lib):
+    """deep_KL_NMF from the multilayer (NNDSVD) start: 3 layers x 6 MU iterations, then 6 deep iterations.  Tolerances: the
+    multilayer ones (g9) -- every layer error is a KL divergence of chained fp32 factorisations."""
+    from nn_fac_amd.deep_nmf import deep_KL_NMF
+    g = golden("g10_deep_nmf.npz")
+    ranks = [int(x) for x in g["step_ranks"]]
+    W, H, rec, toc = deep_KL_NMF(g["step_data"].copy(), list(ranks), n_iter_max_each_nmf=6, n_iter_max_deep_loop=6, tol=0,
+                                 return_errors=True, deterministic=True, seed=3)
+    assert len(W) == len(H) == 3 and rec.shape == (3, 7) and len(toc) == 6
+    for i in range(3):
+        assert isinstance(W[i], np.ndarray)
+        assert rel(W[i], g[f"ml_W_{i}"]) < 5e-4 and rel(H[i], g[f"ml_H_{i}"]) < 5e-4, (i, rel(W[i], g[f"ml_W_{i}"]))
+    np.testing.assert_allclose(rec, g["ml_errors"], rtol=5e-4)
+    with pytest.raises(ValueError):
+        deep_KL_NMF(g["step_data"], [3, 6], n_iter_max_deep_loop=1)
+    # custom start (the reference's own custom branch cannot run on NumPy >= 1.24, deep_nmf.py:46): vs the oracle
+    W0 = [g[f"step_W0_{i}"].copy() for i in range(3)]
+    H0 = [g[f"step_H0_{i}"].copy() for i in range(3)]
+    W, H, rec, _ = deep_KL_NMF(g["step_data"].copy(), list(ranks), n_iter_max_deep_loop=4, init="custom", W_0=W0, H_0=H0,
+                               tol=0, return_errors=True)
+    Wo, Ho, reco = orc.deep_KL_NMF(g["step_data"].copy(), list(ranks), n_iter_max_deep_loop=4, init="custom", W_0=W0, H_0=H0,
+                                   tol=0)
+    for i in range(3):
+        assert rel(W[i], Wo[i]) < 2e-4 and rel(H[i], Ho[i]) < 2e-4
+    np.testing.assert_allclose(rec, reco, rtol=2e-4)

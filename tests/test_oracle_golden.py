@@ -241,3 +241,32 @@ def test_g7_ntd_small_steps(golden):
         np.testing.assert_allclose(core, g[f"small_mu_b{beta}_core"], rtol=1e-9, atol=1e-13)
         np.testing.assert_allclose(costs, g[f"small_mu_b{beta}_costs"], rtol=1e-9)
         np.testing.assert_allclose(orc.mu_tensorial(c0, f0, T, beta), g[f"small_mut_b{beta}"], rtol=1e-12)
+
+
+# ---- g10: deep KL-NMF (deep_nmf.py:13-113, deep_mu.py:8-14), outputs of the real reference ----
+def test_oracle_deep_kl_mu_matches_reference(golden):
+    import warnings
+    g = golden("g10_deep_nmf.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # lambda = 0.02 overflows np.exp in the reference too (kept behaviour)
+        for i, lam in enumerate(g["mu_lambdas"]):
+            out = orc.deep_KL_mu(g["mu_W_Lm1"], g["mu_W_L"].copy(), g["mu_H_L"], g["mu_WHn"], lam)
+            np.testing.assert_allclose(out, g[f"mu_out{i}"], rtol=1e-12, atol=0)
+
+
+def test_oracle_deep_nmf_matches_reference(golden):
+    g = golden("g10_deep_nmf.npz")
+    ranks = [int(x) for x in g["step_ranks"]]
+    W0 = [g[f"step_W0_{i}"].copy() for i in range(3)]
+    H0 = [g[f"step_H0_{i}"].copy() for i in range(3)]
+    W, H, e = orc.one_step_deep_KL_nmf(g["step_data"], W0, H0, ranks, g["step_lambda"], 1e-6)
+    for i in range(3):
+        np.testing.assert_allclose(W[i], g[f"step_W_{i}"], rtol=1e-11, atol=1e-14)
+        np.testing.assert_allclose(H[i], g[f"step_H_{i}"], rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(e, g["step_errors"], rtol=1e-11)
+    W, H, rec = orc.deep_KL_NMF(g["step_data"], list(ranks), n_iter_max_each_nmf=6, n_iter_max_deep_loop=6, tol=0,
+                                deterministic=True, seed=3)
+    for i in range(3):
+        np.testing.assert_allclose(W[i], g[f"ml_W_{i}"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(H[i], g[f"ml_H_{i}"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(rec, g["ml_errors"], rtol=1e-9, equal_nan=True)

@@ -185,6 +185,13 @@ int nnf_mttkrp3_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t 
                     const float* Ft1, int64_t ld1, const float* Ft2, int64_t ld2, int R, int mode, float* out,
                     int64_t ldo, void* stream);
 
+/* MTTKRP from a shared partial product (dimension tree).  F2 does not change between the mode-0 and the mode-1 update of
+ * one_ntf_step (ntf.py:437-456), so both right-hand sides are contractions of Y[r][i][j] = sum_k T[i][j][k] F2[k][r]
+ * (= nnf_ttm3_f32(T, F2t, mode 2): ONE pass over T):  axis 2: out[r][a] = sum_b Y[r][a][b] Ft[r][b] (mode 0, Ft = F1t);
+ * axis 1: out[r][b] = sum_a Y[r][a][b] Ft[r][a] (mode 1, Ft = the updated F0t).  Y is R x A x B, contiguous. */
+int nnf_mttkrp3_from_partial_f32(nnf_ctx* ctx, const float* Y, int64_t A, int64_t B, const float* Ft, int64_t ldf, int R,
+                                 int axis, float* out, int64_t ldo, void* stream);
+
 /* beta_divergence(T, [[F0,F1,F2]], beta) for a dense 3-way tensor and its CP model (factors transposed, R x dim): the cost
  * of ntf.py:470 (HALS: 2x the beta=2 value = ||T - model||^2) and ntf.py:473 (MU), Khatri-Rao operand generated on the fly. */
 int nnf_cp3_betadiv_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t K, const float* Ft0, int64_t ld0,

@@ -328,3 +328,81 @@ extern "C" int nnf_mttkrp3_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t 
     if (ldo < K) return NNF_ERR_ARG;
     return rows_dispatch(ctx, T, I * J, K, Ft0, ld0, Ft1, ld1, J, R, out, ldo, st);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// MTTKRP from a shared partial product (dimension tree).  Between the mode-0 and the mode-1 update of one_ntf_step
+// (ntf.py:437-456) the last factor does not change, so both right-hand sides are contractions of the SAME
+//   Y[r][i][j] = sum_k T[i][j][k] F2[k][r]           (= nnf_ttm3_f32(T, F2t, mode 2): one pass over T)
+//   mode 0:  rhs[r][i] = sum_j Y[r][i][j] F1t[r][j]   (axis 2)      mode 1:  rhs[r][j] = sum_i Y[r][i][j] F0t[r][i]   (axis 1)
+// which are R independent matrix-vector products over Y (R*I*J floats: 30 MB at 500^3, rank 30) instead of a second pass
+// over the 500 MB tensor.  Same value as unfolded[mode] @ khatri_rao (the sums are re-associated, fp32 partials).
+// ---------------------------------------------------------------------------------------------------------
+// axis 2: one wave per (r, a) row of Y; lanes stride the row (coalesced), DPP-free shuffle reduction in a fixed order
+__global__ __launch_bounds__(256) void nnf_partial_last_kernel(const float* __restrict__ Y, int64_t A, int64_t B,
+                                                               const float* __restrict__ Ft, int64_t ldf, int r,
+                                                               float* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = (int64_t)r * A;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const int64_t k = row / A, a = row - k * A;
+        const float* y = Y + row * B;
+        const float* f = Ft + k * ldf;
+        float s0 = 0.f, s1 = 0.f;
+        int64_t b = lane;
+        for (; b + 64 < B; b += 128) {
+            s0 = fmaf(y[b], f[b], s0);
+            s1 = fmaf(y[b + 64], f[b + 64], s1);
+        }
+        if (b < B) s0 = fmaf(y[b], f[b], s0);
+        float s = s0 + s1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) out[k * ldo + a] = s;
+    }
+}
+// axis 1: grid (column blocks of 256, a-chunks, r); thread = one column b, sums its chunk of a in order -> slab[chunk][r][ldp]
+__global__ __launch_bounds__(256) void nnf_partial_mid_kernel(const float* __restrict__ Y, int64_t A, int64_t B,
+                                                              const float* __restrict__ Ft, int64_t ldf, int64_t a_per,
+                                                              float* __restrict__ slabs, int64_t ldp, int r) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t chunk = blockIdx.y, k = blockIdx.z;
+    const int64_t a0 = chunk * a_per, a1 = (a0 + a_per < A) ? a0 + a_per : A;
+    if (b >= B) return;
+    const float* y = Y + (k * A) * B + b;
+    const float* f = Ft + k * ldf;     // wave-uniform operand
+    float s = 0.f;
+    for (int64_t a = a0; a < a1; ++a) s = fmaf(y[a * B], f[a], s);
+    slabs[(chunk * r + k) * ldp + b] = s;
+}
+
+extern "C" int nnf_mttkrp3_from_partial_f32(nnf_ctx* ctx, const float* Y, int64_t A, int64_t B, const float* Ft, int64_t ldf,
+                                            int R, int axis, float* out, int64_t ldo, void* stream) {
+    if (!ctx || !Y || !Ft || !out || A < 1 || B < 1 || R < 1 || (axis != 1 && axis != 2)) return NNF_ERR_ARG;
+    if (ldf < (axis == 1 ? A : B) || ldo < (axis == 1 ? B : A)) return NNF_ERR_ARG;
+    if (R > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (axis == 2) {
+        int64_t grid = nnf_cdiv((int64_t)R * A, 4);
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(nnf_partial_last_kernel, dim3((int)grid), dim3(256), 0, st, Y, A, B, Ft, ldf, R, out, ldo);
+        NNF_CHECK_LAUNCH();
+        return NNF_OK;
+    }
+    // axis 1: enough a-chunks to fill the chip, at least 16 rows each
+    const int64_t cb = nnf_cdiv(B, 256);
+    int64_t nchunk = nnf_cdiv((int64_t)4 * ctx->num_cus, cb * R);
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > nnf_cdiv(A, 16)) nchunk = nnf_cdiv(A, 16);
+    if (nchunk > 65535) nchunk = 65535;
+    const int64_t a_per = nnf_cdiv(A, nchunk);
+    nchunk = nnf_cdiv(A, a_per);
+    const int64_t ldp = nnf_rup(B, 4);
+    nnf_ws_cursor cur(ctx);
+    float* slabs = (float*)cur.take((size_t)nchunk * R * ldp * 4);
+    if (!slabs) return NNF_ERR_WORKSPACE;
+    if (cb > 65535) return NNF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(nnf_partial_mid_kernel, dim3((unsigned)cb, (unsigned)nchunk, (unsigned)R), dim3(256), 0, st, Y, A, B, Ft,
+                       ldf, a_per, slabs, ldp, R);
+    NNF_CHECK_LAUNCH();
+    return nnf_launch_reduce_slabs(slabs, (int)nchunk, (int64_t)R * ldp, R, B, ldp, out, ldo, st);
+}

@@ -339,7 +339,21 @@ class Engine:
         return sum(a.elapsed_time(b) for a, b in evs) / reps
 
     # ---- NTD -----------------------------------------------------------------------------------------
-    def ttm3(self, T, Ft, mode):
+    def mttkrp3_from_partial(self, Y, Ft, axis, out=None):
+        """Y (R x A x B, contiguous) contracted with the rows of Ft over `axis` (1: A, 2: B) -> R x (the other extent)."""
+        if Y.dim() != 3 or Y.dtype != torch.float32 or not Y.is_contiguous():
+            raise EngineError("mttkrp3_from_partial: Y must be a contiguous 3-way float32 tensor")
+        _chk2d(Ft, "partial factor")
+        R, A, B = Y.shape
+        other = B if axis == 1 else A
+        if Ft.shape != (R, A if axis == 1 else B):
+            raise EngineError("mttkrp3_from_partial: shape mismatch")
+        O = out if out is not None else torch.empty((R, other), dtype=torch.float32, device=Y.device)
+        _lib.check(self.lib.nnf_mttkrp3_from_partial_f32(self.ctx, _ptr(Y), A, B, _ptr(Ft), _ld(Ft), R, int(axis), _ptr(O),
+                                                         _ld(O), self._stream()), "nnf_mttkrp3_from_partial_f32")
+        return O
+
+    def ttm3(self, T, Ft, mode, out=None):
         """T x_mode F^T for a contiguous 3-way tensor and a transposed factor Ft (r x I_mode).
         Result layout: mode 0 -> (r, J, K); mode 1 -> (I, r, K); mode 2 -> (r, I, J)  (include/nnfac_hip.h)."""
         if T.dim() != 3 or not T.is_contiguous():
@@ -348,7 +362,10 @@ class Engine:
         I, J, K = T.shape
         r = Ft.shape[0]
         shape = (r, J, K) if mode == 0 else ((I, r, K) if mode == 1 else (r, I, J))
-        out = torch.empty(shape, dtype=torch.float32, device=T.device)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=T.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+            raise EngineError("ttm3: `out` must be a contiguous float32 tensor of shape " + str(shape))
         _lib.check(self.lib.nnf_ttm3_f32(self.ctx, _ptr(T), I, J, K, _ptr(Ft), _ld(Ft), r, int(mode), _ptr(out),
                                          self._stream()), "nnf_ttm3_f32")
         return out

@@ -75,6 +75,7 @@ class _NtfState:
             _dist.allreduce_(self.norm2, group)
         self.guess0 = _dist.SweepGuess()
         self._unf = {}
+        self._Y = None
         # per-iteration status: 3 HALS status blocks + cost at [24]; a ring with pinned host mirrors (run_ntf_steps)
         self.blocks = torch.zeros((3, 8 * 3 + 8), dtype=torch.float64, device=T.device)
         self.host = torch.zeros((3, 8 * 3 + 8), dtype=torch.float64)
@@ -85,6 +86,15 @@ class _NtfState:
     def select(self, slot):
         self.slot = slot
         self.block = self.blocks[slot]
+
+    def partial(self, Ft2):
+        """Y[r][i][j] = sum_k T[i][j][k] F2[k][r] (tl.tenalg.mode_dot(T, F2^T, 2) with the new axis first): one pass over T,
+        shared by the mode-0 and mode-1 right-hand sides of an iteration (F2 does not change between them)."""
+        I, J, K = self.T.shape
+        R = Ft2.shape[0]
+        if self._Y is None or tuple(self._Y.shape) != (R, I, J):
+            self._Y = torch.empty((R, I, J), dtype=self.T.dtype, device=self.T.device)
+        return self.eng.ttm3(self.T, Ft2, 2, out=self._Y)
 
     def unfolded_t(self, mode):
         """tl.unfold(T, mode)^T = moveaxis(mode -> last).reshape(-1, dim), contiguous (MU path; the last mode is a view)."""
@@ -141,6 +151,21 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
     sharded = _dist.world(st.group) > 1
     if sharded and (update_rule != "hals" or not math.isinf(alpha) or normalize[0]):
         raise NotImplementedError("leading-mode-sharded NTF: HALS with alpha = inf and no normalisation of mode 0")
+    # Dimension tree: with modes 0 and 1 both updated, their right-hand sides (ntf.py:448-449) are two contractions of the
+    # same partial product Y = T x_2 F2^T -- one pass over T instead of two.  Only where the result does not depend on the
+    # wall clock (alpha = inf): the timed rule prices every mode's own Gram + MTTKRP (ntf.py:440-451).
+    Y = None
+    if update_rule == "hals" and math.isinf(alpha) and 0 not in fixed_modes and 1 not in fixed_modes \
+            and hasattr(eng, "mttkrp3_from_partial"):
+        Y = st.partial(Ft[2])
+
+    def rhs_of(mode, out=None):
+        if Y is not None and mode == 0:
+            return eng.mttkrp3_from_partial(Y, Ft[1], 2, out=out)
+        if Y is not None and mode == 1:
+            return eng.mttkrp3_from_partial(Y, Ft[0], 1, out=out)      # Ft[0]: already this iteration's update
+        return eng.mttkrp3(st.T, Ft, mode, out=out)
+
     for mode in [m for m in range(3) if m not in fixed_modes]:
         if update_rule == "hals":
             deterministic = math.isinf(alpha)
@@ -154,7 +179,7 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
                 buf = torch.empty(R_ * dim + R_ * R_, dtype=Ft[mode].dtype, device=dev)
                 rhs_t, g0 = buf[:R_ * dim].view(R_, dim), buf[R_ * dim:].view(R_, R_)
                 eng.gram(Ft[0], out=g0)
-                eng.mttkrp3(st.T, Ft, mode, out=rhs_t)
+                rhs_of(mode, out=rhs_t)
                 _dist.allreduce_(buf, st.group)
                 cross = eng.hadamard(g0, eng.gram(Ft[3 - mode]))
             else:
@@ -163,7 +188,7 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
                     if i != mode:
                         g = eng.gram(f)
                         cross = g if cross is None else eng.hadamard(cross, g)
-                rhs_t = eng.mttkrp3(st.T, Ft, mode)
+                rhs_t = rhs_of(mode)
             budget = 100
             new = Ft[mode].clone()
             if sharded and mode == 0:

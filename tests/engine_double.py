@@ -95,3 +95,13 @@ class OracleEngine:
         model = (F[0] @ orc.khatri_rao(F, skip_matrix=0).T).reshape(T.shape)
         c = torch.tensor([orc.beta_divergence(T.numpy(), model, beta)], dtype=torch.float64)
         return c if out is None else out.copy_(c)
+
+    def ttm3(self, T, Ft, mode, out=None):
+        t = T.numpy()
+        O = torch.from_numpy(np.ascontiguousarray(np.moveaxis(np.tensordot(Ft.numpy(), t, axes=(1, mode)), 0, 0 if mode != 1 else 1)))
+        return O if out is None else out.copy_(O)
+
+    def mttkrp3_from_partial(self, Y, Ft, axis, out=None):
+        y, f = Y.numpy(), Ft.numpy()
+        O = torch.from_numpy(np.einsum('rab,ra->rb', y, f) if axis == 1 else np.einsum('rab,rb->ra', y, f))
+        return O if out is None else out.copy_(O)

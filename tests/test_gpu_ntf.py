@@ -138,3 +138,25 @@ def test_ntf_degenerate_dimensions(built_lib, shape, R, rule, beta):
         assert a.shape == b.shape and rel(a, b) < 5e-4
     assert np.all(np.isfinite(costs))
     np.testing.assert_allclose(costs, co, rtol=2e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape,R", [((12, 10, 8), 4), ((33, 65, 17), 7), ((64, 128, 300), 30), ((5, 700, 3), 2),
+                                     ((301, 3, 129), 50)])
+def test_mttkrp_from_shared_partial(built_lib, shape, R):
+    """Dimension tree (nnf_ttm3_f32 mode 2 + nnf_mttkrp3_from_partial_f32): the mode-0 and mode-1 right-hand sides from ONE
+    pass over T must equal unfolded[mode] @ khatri_rao (ntf.py:448-449) within the single-kernel tolerance."""
+    from nn_fac_amd.engine import get_engine
+    eng = get_engine("cuda:0")
+    rng = np.random.RandomState(sum(shape) + R)
+    T = rng.rand(*shape).astype(np.float32)
+    F = [rng.rand(s, R).astype(np.float32) for s in shape]
+    Td = torch.from_numpy(T).cuda()
+    Ft = [torch.from_numpy(f.T.copy()).cuda() for f in F]
+    Y = eng.ttm3(Td, Ft[2], 2)
+    T64, F64 = T.astype(np.float64), [f.astype(np.float64) for f in F]
+    np.testing.assert_allclose(Y.cpu().numpy(), np.einsum('ijk,kr->rij', T64, F64[2]), rtol=2e-5)
+    got0 = eng.mttkrp3_from_partial(Y, Ft[1], 2).cpu().numpy().T
+    got1 = eng.mttkrp3_from_partial(Y, Ft[0], 1).cpu().numpy().T
+    for mode, got in ((0, got0), (1, got1)):
+        want = orc.unfold(T64, mode) @ orc.khatri_rao(F64, skip_matrix=mode)
+        assert np.linalg.norm(got - want) <= 1e-5 * np.linalg.norm(want), (mode, shape)

@@ -192,6 +192,14 @@ int nnf_mttkrp3_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t 
 int nnf_mttkrp3_from_partial_f32(nnf_ctx* ctx, const float* Y, int64_t A, int64_t B, const float* Ft, int64_t ldf, int R,
                                  int axis, float* out, int64_t ldo, void* stream);
 
+/* Fused pass over T for an NTF iteration loop: the squared residual of the CURRENT CP model (ntf.py:470, evaluated
+ * directly) and the partial product Y[r][i][j] = sum_k T[i][j][k] F2[k][r] the NEXT iteration's mode-0 / mode-1 right-hand
+ * sides are contracted from -- both need the final factors and the whole tensor.  With the mode-2 MTTKRP an iteration then
+ * reads T twice instead of four times.  R <= 64 (NNF_ERR_UNSUPPORTED above: use nnf_cp3_betadiv_f32 + nnf_ttm3_f32). */
+int nnf_cp3_partial_cost_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t K, const float* Ft0, int64_t ld0,
+                             const float* Ft1, int64_t ld1, const float* Ft2, int64_t ld2, int R, float* Y, double* cost_f64,
+                             void* stream);
+
 /* beta_divergence(T, [[F0,F1,F2]], beta) for a dense 3-way tensor and its CP model (factors transposed, R x dim): the cost
  * of ntf.py:470 (HALS: 2x the beta=2 value = ||T - model||^2) and ntf.py:473 (MU), Khatri-Rao operand generated on the fly. */
 int nnf_cp3_betadiv_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t K, const float* Ft0, int64_t ld0,

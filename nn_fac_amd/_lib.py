@@ -44,6 +44,7 @@ SIGNATURES = {
     "nnf_betadiv_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _p]),
     "nnf_mttkrp3_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p]),
     "nnf_mttkrp3_from_partial_f32": (_i32, [_p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _i64, _p]),
+    "nnf_cp3_partial_cost_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _p, _p, _p]),
     "nnf_cp3_betadiv_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _p]),
     "nnf_dot_f32": (_i32, [_p, _p, _i64, _p, _i64, _i64, _i64, _p, _p]),
     "nnf_hadamard_f32": (_i32, [_p, _p, _p, _p, _i64, _p]),

@@ -17,7 +17,14 @@
 #include "k_stream_common.h"
 #include <math.h>
 
-enum { BM_KL = 1, BM_GEN = 9 };
+enum { BM_KL = 1, BM_FROB = 2, BM_GEN = 9 };   // BM_FROB: R = X (plain X V^T) + the squared residual, see nnf_cp3_partial_cost_f32
+
+// extra operands of the left kernel's BM_FROB form: Khatri-Rao left factor generated from two short factors, cost partials
+struct mu_left_extra {
+    const float* Fb;      // != nullptr: U[k][i] = Ut[k][i / nb] * Fb[k][i % nb]  (row (a, b) of a 3-way tensor seen as (A*B) x K)
+    int64_t ldb, nb;
+    double* partial;      // BM_FROB: one fp64 partial of sum (X - UV)^2 per workgroup
+};
 
 // F_K image of a 64-wide chunk of a row-major r x K matrix A (the rank index is the MFMA k index):
 //   img[(t*MT + s4)*64 + lane].c = A[16*s4 + 4*c + (lane>>4)][k0 + 16*t + (lane&15)]       (zero outside r x K)
@@ -65,6 +72,9 @@ template <int BM>
 __device__ __forceinline__ void mu_elem(float x, float p, float beta, float& r1, float& r2) {
     if constexpr (BM == BM_KL) {
         r1 = x * __builtin_amdgcn_rcpf(p);
+        r2 = 0.f;
+    } else if constexpr (BM == BM_FROB) {
+        r1 = x;
         r2 = 0.f;
     } else {
         // r2 = p^(beta-1), r1 = p^(beta-2) x
@@ -308,9 +318,10 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                                                  const float* __restrict__ V, int64_t ldv, int r, float beta,
                                                  const double* __restrict__ den_vec, float gamma,
                                                  float* __restrict__ Ut_out, int64_t lduo, int a_vec_ok, int64_t row0,
-                                                 char* smem) {
+                                                 char* smem, const mu_left_extra& ex) {
     const int KS = (r + 3) >> 2;
-    constexpr bool REGF = (BM == BM_KL);                             // resident fragments in registers / in LDS
+    constexpr bool REGF = (BM != BM_GEN);                            // resident fragments in registers / in LDS
+    float csum = 0.f;                                                // BM_FROB: this lane's share of sum (X - UV)^2
     f32x4* ldsUf = reinterpret_cast<f32x4*>(smem);                 // !REGF: [4][KS][64]: comps nt: Ut[4s+g][i0w+16nt+ii]
     f32x4* ldsA = ldsUf + (REGF ? 0 : (size_t)4 * KS * 64);          // [2][MT*256]  F_A image of the V chunk
     f32x4* ldsK = ldsA + (size_t)2 * MT * 256;                       // [2][MT*256]  F_K image of the V chunk
@@ -337,7 +348,14 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int64_t i = i0w + 16 * nt + ii;
-                    if (i < m) v[nt] = Ut[(int64_t)k * ldu + i];
+                    if (i < m) {
+                        if (ex.Fb != nullptr) {   // Khatri-Rao row generated on the fly (loop-invariant: once per wave)
+                            const int64_t ia = i / ex.nb, ib = i - ia * ex.nb;
+                            v[nt] = Ut[(int64_t)k * ldu + ia] * ex.Fb[(int64_t)k * ex.ldb + ib];
+                        } else {
+                            v[nt] = Ut[(int64_t)k * ldu + i];
+                        }
+                    }
                 }
             }
             ufr[s_] = v;
@@ -409,6 +427,10 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                     float r1, r2;
                     mu_elem<BM>(xb[t & 1][nt][reg], accP[nt][reg], beta, r1, r2);
                     const bool ok = rowok && (reg < colrem);
+                    if constexpr (BM == BM_FROB) {
+                        const float dd = ok ? (xb[t & 1][nt][reg] - accP[nt][reg]) : 0.f;
+                        csum = fmaf(dd, dd, csum);
+                    }
                     R1[nt][reg] = ok ? r1 : 0.f;
                     if constexpr (BM == BM_GEN) R2[nt][reg] = ok ? r2 : 0.f;
                 }
@@ -461,22 +483,29 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                 }
         }
     }
+    if constexpr (BM == BM_FROB) {   // fp32 per lane (a few hundred terms), fp64 from the wave level up, fixed order
+        double* red = reinterpret_cast<double*>(smem);    // the chunk images are dead: every wave is past its last read
+        __syncthreads();
+        const double tot = nnf_block_sum_f64((double)csum, red);
+        if (threadIdx.x == 0) ex.partial[blockIdx.x] = tot;
+    }
 }
 
 template <int MT, int BM, bool VEC>
-__global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_left_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+__global__ __launch_bounds__(256, (BM != BM_GEN ? 2 : 1)) void nnf_mu_left_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                              const float* __restrict__ Ut, int64_t ldu,
                                                              const float* __restrict__ V, int64_t ldv, int r, float beta,
                                                              const double* __restrict__ den_vec, float gamma,
-                                                             float* __restrict__ Ut_out, int64_t lduo, int a_vec_ok, int n_hi) {
+                                                             float* __restrict__ Ut_out, int64_t lduo, int a_vec_ok, int n_hi,
+                                                             mu_left_extra ex) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = (int)blockIdx.x;
     if (b < n_hi)
         nnf_mu_left_body<MT, BM, VEC, 4>(X, m, n, ldx, Ut, ldu, V, ldv, r, beta, den_vec, gamma, Ut_out, lduo, a_vec_ok,
-                                         (int64_t)b * 256, smem);
+                                         (int64_t)b * 256, smem, ex);
     else
         nnf_mu_left_body<MT, BM, VEC, 3>(X, m, n, ldx, Ut, ldu, V, ldv, r, beta, den_vec, gamma, Ut_out, lduo, a_vec_ok,
-                                         (int64_t)n_hi * 256 + (int64_t)(b - n_hi) * 192, smem);
+                                         (int64_t)n_hi * 256 + (int64_t)(b - n_hi) * 192, smem, ex);
 }
 
 // beta = 2 (Gram form): out[k][j] = max(F[k][j] * num[k][j] / (sum_l G[k][l] F[l][j]), 1e-12)
@@ -560,12 +589,13 @@ static int launch_mu_right(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int
 template <int MT, int BM, bool VEC>
 static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx,
                           const float* Ut, int64_t ldu, const float* V, int64_t ldv, int r, double beta, float* Ut_out,
-                          int64_t lduo, hipStream_t st, int raw_num = 0) {
+                          int64_t lduo, hipStream_t st, int raw_num = 0, mu_left_extra ex = mu_left_extra{nullptr, 0, 1, nullptr},
+                          double* cost_out = nullptr) {
     if (64 * ldx * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
     double* dvec = (double*)cur.take((size_t)r * 8);
     if (!dvec) return NNF_ERR_WORKSPACE;
     const int a_vec_ok = ((((uintptr_t)V) & 15) == 0 && (ldv & 3) == 0) ? 1 : 0;
-    const size_t shm = mu_shm(MT, r, BM == BM_KL);
+    const size_t shm = mu_shm(MT, r, BM != BM_GEN);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_mu_left_kernel<MT, BM, VEC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (BM == BM_KL) {  // den[k] = rowsum(V)[k]   (mu.py:86-87)
@@ -574,18 +604,23 @@ static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int6
     }
     // rows per workgroup: 256 everywhere, unless one round of resident workgroups covers the matrix with 3 to 4 row tiles
     // per wave -- then n_hi workgroups of 256 rows and the rest of 192 fill exactly one round
-    const int64_t slots = (int64_t)(BM == BM_KL ? 2 : 1) * ctx->num_cus, T = nnf_cdiv(m, 16);
+    const int64_t slots = (int64_t)(BM != BM_GEN ? 2 : 1) * ctx->num_cus, T = nnf_cdiv(m, 16);
     int64_t n_hi = nnf_cdiv(m, 256), grid = n_hi;
     if (T > 12 * slots && T <= 16 * slots) {
         n_hi = nnf_cdiv(T - 12 * slots, 4);
         grid = slots;
     }
     if (n_hi * 256 + (grid - n_hi) * 192 < m) return NNF_ERR_UNSUPPORTED;   // (cannot happen)
+    if (BM == BM_FROB) {
+        ex.partial = (double*)cur.take((size_t)grid * 8);
+        if (!ex.partial || !cost_out) return NNF_ERR_WORKSPACE;
+    }
     nnf_probe(ctx, NNF_PROBE_MU_LEFT, 0, st);
     hipLaunchKernelGGL((nnf_mu_left_kernel<MT, BM, VEC>), dim3((int)grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
-                       (float)beta, dvec, raw_num ? -1.f : gamma_of(beta), Ut_out, lduo, a_vec_ok, (int)n_hi);
+                       (float)beta, dvec, raw_num ? -1.f : gamma_of(beta), Ut_out, lduo, a_vec_ok, (int)n_hi, ex);
     NNF_CHECK_LAUNCH();
     nnf_probe(ctx, NNF_PROBE_MU_LEFT, 1, st);
+    if (BM == BM_FROB) return nnf_launch_sum_f64(ex.partial, grid, 1.0, cost_out, st);
     return NNF_OK;
 }
 
@@ -833,4 +868,37 @@ extern "C" int nnf_deep_kl_apply_f32(nnf_ctx* ctx, const float* F, int64_t ldf, 
                        hsum_f64, WHnext, ldw, lambda, out, ldo);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
+}
+
+// One pass over a dense 3-way tensor T (I x J x K) for BOTH the squared residual of the current CP model and the partial
+// product the next iteration's mode-0 / mode-1 right-hand sides are contracted from (nnf_mttkrp3_from_partial_f32):
+//   *cost_f64 = sum_ijk (T[i,j,k] - sum_r F0[i,r] F1[j,r] F2[k,r])^2        (ntf.py:470, evaluated directly)
+//   Y[r][i][j] = sum_k T[i,j,k] F2[k,r]                                     (tl.tenalg.mode_dot(T, F2^T, 2), new axis first)
+// Both need the final factors of an iteration and the whole tensor: fused, an iteration reads T twice (this pass + the
+// mode-2 MTTKRP) instead of four times.  T is seen as an (I*J) x K matrix; the left factor rows F0[i,:].*F1[j,:] are
+// generated once per wave; the kernel is the left MU kernel with R = X (MFMA #1: model tile, MFMA #2: Y += F2-fragment . X).
+extern "C" int nnf_cp3_partial_cost_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t K, const float* Ft0,
+                                        int64_t ld0, const float* Ft1, int64_t ld1, const float* Ft2, int64_t ld2, int R,
+                                        float* Y, double* cost_f64, void* stream) {
+    if (!ctx || !T || !Ft0 || !Ft1 || !Ft2 || !Y || !cost_f64 || I < 1 || J < 1 || K < 1 || R < 1 || ld0 < I || ld1 < J ||
+        ld2 < K)
+        return NNF_ERR_ARG;
+    if (R > 64) return NNF_ERR_UNSUPPORTED;   // (the fused two-MFMA kernels are built for rank <= 64; callers fall back)
+    hipStream_t st = (hipStream_t)stream;
+    nnf_ws_cursor cur(ctx);
+    const int64_t m = I * J;
+    const mu_left_extra ex{Ft1, ld1, J, nullptr};
+    const int MT = (R + 15) / 16;
+    const bool vec = x_vec_ok(T, K);
+#define CP3PC(MTV)                                                                                                         \
+    return vec ? launch_mu_left<MTV, BM_FROB, true>(ctx, cur, T, m, K, K, Ft0, ld0, Ft2, ld2, R, 2.0, Y, m, st, 1, ex, cost_f64) \
+               : launch_mu_left<MTV, BM_FROB, false>(ctx, cur, T, m, K, K, Ft0, ld0, Ft2, ld2, R, 2.0, Y, m, st, 1, ex, cost_f64)
+    switch (MT) {
+        case 1: CP3PC(1);
+        case 2: CP3PC(2);
+        case 3: CP3PC(3);
+        case 4: CP3PC(4);
+        default: return NNF_ERR_UNSUPPORTED;
+    }
+#undef CP3PC
 }

@@ -824,6 +824,12 @@ __global__ __launch_bounds__(256) void nnf_sum_partials_kernel(const double* __r
 }
 
 
+int nnf_launch_sum_f64(const double* partial, int64_t count, double scale, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(nnf_sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, count, scale, out);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+
 #define DISPATCH_MT(FN, REM, VEC, ...)                    \
     switch (MT) {                                         \
         case 1: return FN<1, REM, VEC>(__VA_ARGS__);      \

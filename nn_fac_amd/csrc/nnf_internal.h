@@ -105,6 +105,9 @@ __device__ __forceinline__ void nnf_xcd_map(int bid, int members, int& group, in
 int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, int rows, int64_t cols, int64_t lds,
                             float* out, int64_t ldo, hipStream_t st);
 
+// out[0] = scale * sum of `count` doubles, index order, one workgroup
+int nnf_launch_sum_f64(const double* partial, int64_t count, double scale, double* out, hipStream_t st);
+
 int nnf_xty_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
                  int r, int64_t ldu, float* out, int64_t ldo, hipStream_t st);
 int nnf_xht_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V,

@@ -408,6 +408,21 @@ class Engine:
         return O
 
 
+    CP3_FUSED_MAX_RANK = 64
+
+    def cp3_partial_cost(self, T, Ft, Y, cost):
+        """One pass over T: cost[0] = ||T - [[F0,F1,F2]]||^2 (float64 device scalar) and Y[r][i][j] = sum_k T[i,j,k] F2[k,r]."""
+        if T.dim() != 3 or T.dtype != torch.float32 or not T.is_contiguous():
+            raise EngineError("cp3_partial_cost: T must be a contiguous 3-way float32 tensor")
+        I, J, K = T.shape
+        R = Ft[0].shape[0]
+        if tuple(Y.shape) != (R, I, J) or Y.dtype != torch.float32 or not Y.is_contiguous():
+            raise EngineError("cp3_partial_cost: Y must be a contiguous float32 R x I x J tensor")
+        _lib.check(self.lib.nnf_cp3_partial_cost_f32(self.ctx, _ptr(T), I, J, K, _ptr(Ft[0]), _ld(Ft[0]), _ptr(Ft[1]),
+                                                     _ld(Ft[1]), _ptr(Ft[2]), _ld(Ft[2]), R, _ptr(Y), _ptr(cost),
+                                                     self._stream()), "nnf_cp3_partial_cost_f32")
+        return Y
+
     def cp3_betadiv(self, T, Ft, beta, out=None):
         """beta-divergence between T (I x J x K) and the CP model of Ft = [F0^T, F1^T, F2^T]; float64 device scalar."""
         if T.dim() != 3 or T.dtype != torch.float32 or not T.is_contiguous():

@@ -75,7 +75,7 @@ class _NtfState:
             _dist.allreduce_(self.norm2, group)
         self.guess0 = _dist.SweepGuess()
         self._unf = {}
-        self._Y = None
+        self._Y, self._Y_of, self._grams = None, None, {}
         # per-iteration status: 3 HALS status blocks + cost at [24]; a ring with pinned host mirrors (run_ntf_steps)
         self.blocks = torch.zeros((3, 8 * 3 + 8), dtype=torch.float64, device=T.device)
         self.host = torch.zeros((3, 8 * 3 + 8), dtype=torch.float64)
@@ -87,14 +87,34 @@ class _NtfState:
         self.slot = slot
         self.block = self.blocks[slot]
 
-    def partial(self, Ft2):
-        """Y[r][i][j] = sum_k T[i][j][k] F2[k][r] (tl.tenalg.mode_dot(T, F2^T, 2) with the new axis first): one pass over T,
-        shared by the mode-0 and mode-1 right-hand sides of an iteration (F2 does not change between them)."""
+    def _ybuf(self, R):
         I, J, K = self.T.shape
-        R = Ft2.shape[0]
         if self._Y is None or tuple(self._Y.shape) != (R, I, J):
             self._Y = torch.empty((R, I, J), dtype=self.T.dtype, device=self.T.device)
-        return self.eng.ttm3(self.T, Ft2, 2, out=self._Y)
+        return self._Y
+
+    def partial(self, Ft2):
+        """Y[r][i][j] = sum_k T[i][j][k] F2[k][r] (tl.tenalg.mode_dot(T, F2^T, 2) with the new axis first): one pass over T,
+        shared by the mode-0 and mode-1 right-hand sides of an iteration (F2 does not change between them).  When the
+        previous iteration's cost pass already produced it for this very factor (cost_and_partial), that one is returned."""
+        if self._Y_of is Ft2:
+            return self._Y
+        self._Y_of = None
+        return self.eng.ttm3(self.T, Ft2, 2, out=self._ybuf(Ft2.shape[0]))
+
+    def cost_and_partial(self, Ft, cost):
+        """||T - [[F0,F1,F2]]||^2 into `cost` AND the partial product of the next iteration, one pass over T."""
+        self.eng.cp3_partial_cost(self.T, Ft, self._ybuf(Ft[2].shape[0]), cost)
+        self._Y_of = Ft[2]               # (a strong reference: the identity test above cannot meet a recycled tensor)
+
+    def gram_of(self, i, F):
+        """F F^T (R x R) of factor i, computed once per value of the factor (each is used by two mode updates)."""
+        hit = self._grams.get(i)
+        if hit is not None and hit[0] is F:
+            return hit[1]
+        G = self.eng.gram(F)
+        self._grams[i] = (F, G)
+        return G
 
     def unfolded_t(self, mode):
         """tl.unfold(T, mode)^T = moveaxis(mode -> last).reshape(-1, dim), contiguous (MU path; the last mode is a view)."""
@@ -112,10 +132,14 @@ def _krao_t(Ft, skip):
     return res.contiguous()
 
 
-def _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, cost):
-    """The cost lines of one_ntf_step (ntf.py:462-475) into the 1-element float64 device tensor `cost`, current stream."""
+def _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, cost, fuse_next=False):
+    """The cost lines of one_ntf_step (ntf.py:462-475) into the 1-element float64 device tensor `cost`, current stream.
+    `fuse_next` (HALS, another iteration follows): the same pass over T leaves the next iteration's partial product."""
     sharded = _dist.world(st.group) > 1
-    if update_rule == "hals":
+    if update_rule == "hals" and fuse_next and hasattr(eng, "cp3_partial_cost") \
+            and Ft[0].shape[0] <= getattr(eng, "CP3_FUSED_MAX_RANK", 0):
+        st.cost_and_partial(Ft, cost)                # ||T - model||^2
+    elif update_rule == "hals":
         eng.cp3_betadiv(st.T, Ft, 2, out=cost)
         cost.mul_(2.0)                               # ||T - model||^2
     else:
@@ -137,7 +161,7 @@ def _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, cost):
 
 
 def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients, fixed_modes, normalize, alpha, delta,
-                      skip_cost=False):
+                      skip_cost=False, fuse_next=False):
     eng = st.eng
     if update_rule not in ["hals", "mu"]:
         raise err.InvalidArgumentValue(f"Invalid update rule: {update_rule}") from None
@@ -181,12 +205,12 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
                 eng.gram(Ft[0], out=g0)
                 rhs_of(mode, out=rhs_t)
                 _dist.allreduce_(buf, st.group)
-                cross = eng.hadamard(g0, eng.gram(Ft[3 - mode]))
+                cross = eng.hadamard(g0, st.gram_of(3 - mode, Ft[3 - mode]))
             else:
                 cross = None
                 for i, f in enumerate(Ft):
                     if i != mode:
-                        g = eng.gram(f)
+                        g = st.gram_of(i, f)
                         cross = g if cross is None else eng.hadamard(cross, g)
                 rhs_t = rhs_of(mode)
             budget = 100
@@ -217,7 +241,8 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
             Ft[mode] = eng.mu_right(st.unfolded_t(mode), _krao_t(Ft, mode), Ft[mode], beta)
 
     if not skip_cost:
-        _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, st.block[24:25])
+        _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, st.block[24:25],
+                  fuse_next=fuse_next and Y is not None)
     return Ft, nstat
 
 
@@ -248,7 +273,7 @@ def run_ntf_steps(st, rank, Ft, n_iter, update_rule, beta, sparsity_coefficients
     for iteration in range(n_iter):
         st.select(iteration % st.blocks.shape[0])
         Ft, nstat = _one_ntf_step_dev(st, rank, Ft, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
-                                      alpha, delta)
+                                      alpha, delta, fuse_next=iteration + 1 < n_iter)
         st.host[st.slot].copy_(st.block, non_blocking=cuda)
         pending.append(dict(it=iteration, slot=st.slot, Ft=Ft, nstat=nstat,
                             ev=main.record_event() if cuda else _NoEvent()))

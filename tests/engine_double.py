@@ -105,3 +105,12 @@ class OracleEngine:
         y, f = Y.numpy(), Ft.numpy()
         O = torch.from_numpy(np.einsum('rab,ra->rb', y, f) if axis == 1 else np.einsum('rab,rb->ra', y, f))
         return O if out is None else out.copy_(O)
+
+    CP3_FUSED_MAX_RANK = 64
+
+    def cp3_partial_cost(self, T, Ft, Y, cost):
+        F = [f.numpy().T for f in Ft]
+        model = (F[0] @ orc.khatri_rao(F, skip_matrix=0).T).reshape(T.shape)
+        cost.copy_(torch.tensor([np.sum((T.numpy() - model) ** 2)], dtype=torch.float64))
+        Y.copy_(torch.from_numpy(np.einsum('ijk,kr->rij', T.numpy(), F[2])))
+        return Y

@@ -160,3 +160,25 @@ def test_mttkrp_from_shared_partial(built_lib, shape, R):
     for mode, got in ((0, got0), (1, got1)):
         want = orc.unfold(T64, mode) @ orc.khatri_rao(F64, skip_matrix=mode)
         assert np.linalg.norm(got - want) <= 1e-5 * np.linalg.norm(want), (mode, shape)
+
+
+@pytest.mark.parametrize("shape,R", [((12, 10, 8), 4), ((33, 65, 17), 7), ((64, 128, 300), 30), ((5, 700, 3), 2),
+                                     ((301, 3, 129), 50), ((40, 41, 42), 64)])
+def test_fused_cost_and_partial(built_lib, shape, R):
+    """nnf_cp3_partial_cost_f32: ONE pass over T gives ||T - [[F0,F1,F2]]||^2 (ntf.py:470) and the partial product
+    Y = T x_2 F2^T of the next iteration -- against fp64 NumPy and against the two separate entry points."""
+    from nn_fac_amd.engine import get_engine
+    eng = get_engine("cuda:0")
+    rng = np.random.RandomState(sum(shape) * R)
+    F = [rng.rand(s, R).astype(np.float32) for s in shape]
+    T = (np.einsum('ir,jr,kr->ijk', *F) * (1 + 0.05 * rng.randn(*shape))).astype(np.float32)   # near fit: small residual
+    Td = torch.from_numpy(T).cuda()
+    Ft = [torch.from_numpy(f.T.copy()).cuda() for f in F]
+    Y = torch.empty((R, shape[0], shape[1]), dtype=torch.float32, device="cuda")
+    cost = torch.zeros(1, dtype=torch.float64, device="cuda")
+    eng.cp3_partial_cost(Td, Ft, Y, cost)
+    T64, F64 = T.astype(np.float64), [f.astype(np.float64) for f in F]
+    want = np.sum((T64 - np.einsum('ir,jr,kr->ijk', *F64)) ** 2)
+    assert abs(float(cost) - want) <= 2e-5 * want, (float(cost), want)
+    np.testing.assert_allclose(Y.cpu().numpy(), np.einsum('ijk,kr->rij', T64, F64[2]), rtol=2e-5)
+    assert abs(float(cost) - 2 * float(eng.cp3_betadiv(Td, Ft, 2))) <= 1e-5 * want

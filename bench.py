@@ -449,17 +449,29 @@ def bench_ntf(cx, args, cfg, steps, warmup, with_cpu, with_kernels):
     if with_kernels and cx.cuda and cx.rank == 0:
         eng = cx.eng
         tb = I * I * I * 4.0 + 3 * I * R * 4.0
+        fl = 2.0 * I * I * I * R
         rl = []
-        for mode in range(3):
-            ms = eng.time_kernel("mttkrp", lambda: eng.mttkrp3(T, Ft, mode))
-            rl.append(roof(f"nnf_mttkrp kernel, mode {mode} (Khatri-Rao operand generated on the fly; slab reduction not "
-                           f"included)", "hbm", tb, ms, HBM_PEAK_GBS, "GB/s", algorithmic_bytes=tb,
-                           algorithmic_flops=2.0 * I * I * I * R, tflops=2.0 * I * I * I * R / ms / 1e9))
+        # the two passes over T of an iteration of the loop timed above (dimension tree):
+        ms = eng.time_kernel("mttkrp", lambda: eng.mttkrp3(T, Ft, 2))
+        rl.append(roof("nnf_mttkrp_rows_kernel (mode-2 MTTKRP, Khatri-Rao operand generated on the fly; slab reduction not "
+                       "included)", "hbm", tb, ms, HBM_PEAK_GBS, "GB/s", algorithmic_bytes=tb, algorithmic_flops=fl,
+                       tflops=fl / ms / 1e9))
         c = torch.zeros(1, dtype=torch.float64, device=T.device)
+        Y = torch.empty((R, I, I), dtype=torch.float32, device=T.device)
+        ms = eng.time_kernel("mu_left", lambda: eng.cp3_partial_cost(T, Ft, Y, c))
+        rl.append(roof("nnf_mu_left_kernel<FROB> (one pass: ||T - model||^2 AND the partial product Y = T x_2 F2^T that the next "
+                       "iteration's mode-0 / mode-1 right-hand sides are contracted from)", "mfma", 2 * fl, ms,
+                       MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=2 * fl, algorithmic_bytes=tb + R * I * I * 4.0,
+                       hbm_gbs=(tb + R * I * I * 4.0) / ms / 1e6))
+        # the kernels the fused pass replaces / the first iteration and one_ntf_step use
+        for mode in range(2):
+            ms = eng.time_kernel("mttkrp", lambda: eng.mttkrp3(T, Ft, mode))
+            rl.append(roof(f"nnf_mttkrp_seg_kernel, mode {mode} (direct MTTKRP; not in the timed loop since the dimension tree)",
+                           "hbm", tb, ms, HBM_PEAK_GBS, "GB/s", algorithmic_bytes=tb, algorithmic_flops=fl,
+                           tflops=fl / ms / 1e9))
         ms = eng.time_kernel("cost", lambda: eng.cp3_betadiv(T, Ft, 2, out=c))
-        rl.append(roof("nnf_cost_kernel<FROB> on the CP model (||T - [[F0,F1,F2]]||^2, Khatri-Rao rows generated on the fly)",
-                       "hbm", tb, ms, HBM_PEAK_GBS, "GB/s", algorithmic_bytes=tb, algorithmic_flops=2.0 * I * I * I * R,
-                       tflops=2.0 * I * I * I * R / ms / 1e9))
+        rl.append(roof("nnf_cost_kernel<FROB> on the CP model (stand-alone cost; one_ntf_step)", "hbm", tb, ms, HBM_PEAK_GBS,
+                       "GB/s", algorithmic_bytes=tb, algorithmic_flops=fl, tflops=fl / ms / 1e9))
         out["rooflines"] = rl
     if with_cpu and cx.world == 1 and cx.rank == 0:
         Fs = [f.t().contiguous().cpu().numpy() for f in start]

@@ -340,6 +340,15 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
     // ufr[s][nt] = Ut[4s+g][i0w + 16nt + ii], s < KS (zero beyond r x m)
     f32x4 ufr[REGF ? 4 * MT : 1];
     if constexpr (REGF) {
+        int64_t kra[NT], krb[NT];      // Khatri-Rao left factor: row i of the (A*B) x K view = (i / nb, i % nb), once per tile
+        if (ex.Fb != nullptr) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int64_t i = i0w + 16 * nt + ii;
+                kra[nt] = i / ex.nb;
+                krb[nt] = i - kra[nt] * ex.nb;
+            }
+        }
 #pragma unroll
         for (int s_ = 0; s_ < 4 * MT; ++s_) {
             const int k = 4 * s_ + g;
@@ -350,8 +359,7 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                     const int64_t i = i0w + 16 * nt + ii;
                     if (i < m) {
                         if (ex.Fb != nullptr) {   // Khatri-Rao row generated on the fly (loop-invariant: once per wave)
-                            const int64_t ia = i / ex.nb, ib = i - ia * ex.nb;
-                            v[nt] = Ut[(int64_t)k * ldu + ia] * ex.Fb[(int64_t)k * ex.ldb + ib];
+                            v[nt] = Ut[(int64_t)k * ldu + kra[nt]] * ex.Fb[(int64_t)k * ex.ldb + krb[nt]];
                         } else {
                             v[nt] = Ut[(int64_t)k * ldu + i];
                         }
@@ -435,6 +443,9 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                     if constexpr (BM == BM_GEN) R2[nt][reg] = ok ? r2 : 0.f;
                 }
             }
+            // finish this group's residual sum HERE: left alone, LLVM sinks the whole dependent chain of a chunk (and the 48
+            // differences it consumes) to the chunk's last block -- 256 VGPRs + spills instead of ~180
+            if constexpr (BM == BM_FROB) asm volatile("" : "+v"(csum));
             // MFMA #2: num[rk][i] += V[rk][j] * R[j][i], k = the block's 16 columns
             f32x4 af[MT];
 #pragma unroll
@@ -472,7 +483,7 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                     if (rk < r) {
                         float d;
                         if constexpr (BM == BM_GEN) d = den[mt][nt][reg]; else d = (float)den_vec[rk];
-                        if (gamma < 0.f) {   // raw numerator (nnf_mu_left_num_f32; wave-uniform flag)
+                        if (BM == BM_FROB || gamma < 0.f) {   // raw numerator (nnf_mu_left_num_f32; wave-uniform flag)
                             Ut_out[(int64_t)rk * lduo + i] = num[mt][nt][reg];
                             continue;
                         }
@@ -492,7 +503,7 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
 }
 
 template <int MT, int BM, bool VEC>
-__global__ __launch_bounds__(256, (BM != BM_GEN ? 2 : 1)) void nnf_mu_left_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+__global__ __launch_bounds__(256, (BM == BM_GEN ? 1 : ((MT <= 2 && BM == BM_FROB) ? 3 : 2))) void nnf_mu_left_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                              const float* __restrict__ Ut, int64_t ldu,
                                                              const float* __restrict__ V, int64_t ldv, int r, float beta,
                                                              const double* __restrict__ den_vec, float gamma,
@@ -604,7 +615,7 @@ static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int6
     }
     // rows per workgroup: 256 everywhere, unless one round of resident workgroups covers the matrix with 3 to 4 row tiles
     // per wave -- then n_hi workgroups of 256 rows and the rest of 192 fill exactly one round
-    const int64_t slots = (int64_t)(BM != BM_GEN ? 2 : 1) * ctx->num_cus, T = nnf_cdiv(m, 16);
+    const int64_t slots = (int64_t)(BM == BM_GEN ? 1 : ((MT <= 2 && BM == BM_FROB) ? 3 : 2)) * ctx->num_cus, T = nnf_cdiv(m, 16);
     int64_t n_hi = nnf_cdiv(m, 256), grid = n_hi;
     if (T > 12 * slots && T <= 16 * slots) {
         n_hi = nnf_cdiv(T - 12 * slots, 4);

@@ -273,7 +273,8 @@ def run_ntf_steps(st, rank, Ft, n_iter, update_rule, beta, sparsity_coefficients
     for iteration in range(n_iter):
         st.select(iteration % st.blocks.shape[0])
         Ft, nstat = _one_ntf_step_dev(st, rank, Ft, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
-                                      alpha, delta, fuse_next=iteration + 1 < n_iter)
+                                      alpha, delta, fuse_next=True)   # (also in the last iteration: every cost of a run
+        #                                        comes from the same kernel, whatever n_iter_max -- bitwise repeatable)
         st.host[st.slot].copy_(st.block, non_blocking=cuda)
         pending.append(dict(it=iteration, slot=st.slot, Ft=Ft, nstat=nstat,
                             ev=main.record_event() if cuda else _NoEvent()))

@@ -124,6 +124,15 @@ int nnf_hals_sweeps_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float
                         int r, int64_t ncols, int nsweeps, float sparsity, unsigned flags, double* nodelta_f64,
                         float* snapshots, int64_t snap_stride, void* stream);
 
+/* Row-sharded solve, device-side stopping decision (no host round trip): after `nsweeps` blind sweeps of
+ * nnf_hals_sweeps_f32 (snapshots for the last nsweeps - head of them) and an all-reduce of their per-sweep sums over the
+ * ranks, replay nnls.py:156 over the sums: stop = first s with !(sum[s] >= delta*sum[0]) or s + 1 == budget.  A stop inside the
+ * snapshot window restores V from that snapshot and writes {eps, cnt, eps0, 0} to status_f64; a stop before the window writes
+ * error 3, no stop within these sweeps error 4 (the caller redoes the solve with a host-synchronous protocol). */
+int nnf_hals_stop_restore_f32(nnf_ctx* ctx, const double* sums_f64, int nsweeps, int head, int budget, double delta, float* V,
+                              int64_t ldv, int r, int64_t ncols, const float* snapshots, int64_t snap_stride,
+                              double* status_f64, void* stream);
+
 /* mu_betadivmin (mu.py:79-97) for the left factor, transposed storage:
  *   Ut_out[k,i] = max(Ut[k,i] * (num[k,i]/den[k,i])^gamma(beta), 1e-12),
  *   num = ((UV)^(beta-2) .* X) V^T, den = (UV)^(beta-1) V^T       (beta=1: den = rowsum(V); beta=2: Gram form)

@@ -310,3 +310,65 @@ extern "C" int nnf_hals_solve_continue_f32(nnf_ctx* ctx, const float* UtM, int64
     return hals_entry<0>(ctx, UtM, ldm, UtU, ldg, V, ldv, r, ncols, max_sweeps, delta, sparsity, flags, status_f64, nullptr,
                          (hipStream_t)stream, nullptr, 0, sweeps_done);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Row-sharded solve without a host round trip (the stopping scalar of nnls.py:156 is global, the sweeps are
+// local).  A rank runs `nsweeps` blind sweeps (nnf_hals_sweeps_f32; the last nsweeps - head of them leave snapshots), the
+// per-sweep sums are all-reduced, and this kernel -- every workgroup redundantly, from the same doubles -- replays the
+// reference's loop condition over them:   stop = first s with  !(sum[s] >= delta * sum[0])  or  s + 1 == budget.
+//   stop inside the snapshot window  -> V := snapshot of that sweep (unless it is the last one run), status = {eps, cnt, eps0, 0}
+//   stop before the window           -> status error 3 (V holds too many sweeps and no snapshot of the right one)
+//   no stop within these sweeps      -> status error 4 (more sweeps needed)
+// The host looks at the status block one or two outer iterations later (the pipelined loop of nmf.py); 3 / 4 make it redo
+// that iteration with the synchronous chunked protocol (dist.sharded_hals_solve), which also re-centres the sweep guess.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nnf_hals_stop_restore_kernel(const double* __restrict__ sums, int nsweeps, int head,
+                                                                   int budget, double delta, float* __restrict__ V, int64_t ldv,
+                                                                   int r, int64_t ncols, const float* __restrict__ snapshots,
+                                                                   int64_t snap_stride, double* __restrict__ status) {
+    __shared__ int s_stop;
+    if (threadIdx.x == 0) {
+        int stop = -1;
+        const double eps0 = sums[0];
+        for (int s = 0; s < nsweeps; ++s)
+            if (!(sums[s] >= delta * eps0) || s + 1 >= budget) { stop = s; break; }
+        s_stop = stop;
+        if (blockIdx.x == 0) {
+            status[NNF_HALS_ST_EPS0] = eps0;
+            if (stop < 0) {
+                status[NNF_HALS_ST_EPS] = sums[nsweeps - 1];
+                status[NNF_HALS_ST_CNT] = (double)(nsweeps + 1);
+                status[NNF_HALS_ST_ERR] = 4.0;
+            } else {
+                status[NNF_HALS_ST_EPS] = sums[stop];
+                status[NNF_HALS_ST_CNT] = (double)(stop + 2);
+                status[NNF_HALS_ST_ERR] = (stop < head) ? 3.0 : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    const int stop = s_stop;
+    if (stop < head || stop >= nsweeps - 1) return;     // nothing to restore (error, or the last sweep run is the right one)
+    const float* src = snapshots + (int64_t)(stop - head) * snap_stride;
+    const int64_t total = (int64_t)r * ncols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t k = e / ncols, j = e - k * ncols;
+        V[k * ldv + j] = src[k * ncols + j];
+    }
+}
+
+extern "C" int nnf_hals_stop_restore_f32(nnf_ctx* ctx, const double* sums_f64, int nsweeps, int head, int budget, double delta,
+                                         float* V, int64_t ldv, int r, int64_t ncols, const float* snapshots,
+                                         int64_t snap_stride, double* status_f64, void* stream) {
+    if (!ctx || !sums_f64 || !V || !status_f64 || nsweeps < 1 || head < 0 || head >= nsweeps || budget < 1 || r < 1 ||
+        ncols < 1 || ldv < ncols)
+        return NNF_ERR_ARG;
+    if (nsweeps - head > 1 && (!snapshots || snap_stride < (int64_t)r * ncols)) return NNF_ERR_ARG;
+    int64_t grid = nnf_cdiv((int64_t)r * ncols, 256 * 8);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(nnf_hals_stop_restore_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, sums_f64, nsweeps, head,
+                       budget, delta, V, ldv, r, ncols, snapshots, snap_stride, status_f64);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}

@@ -108,3 +108,27 @@ def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01
         break
     guess.value = max(8, min(done + 4, guess.max_chunk))
     return eps, done + 1, eps0
+
+
+ERR_BEFORE_WINDOW, ERR_NOT_STOPPED = 3, 4      # status codes of nnf_hals_stop_restore_f32
+
+
+def sharded_hals_solve_async(eng, cross, gram, F, group, guess, status, budget=100, delta=0.01, sparsity=None):
+    """The same solve with NO host round trip: one blind chunk of C = guess.value sweeps (snapshots for the last
+    guess.window of them), one all-reduce of the C per-sweep sums, and the stopping rule replayed on the device
+    (Engine.hals_stop_restore), which restores F from the right snapshot and fills `status` (8 float64 on the device) with
+    {eps, cnt, eps0, err}.  err = ERR_BEFORE_WINDOW / ERR_NOT_STOPPED mean the guess was off: the caller -- who reads the
+    status block an iteration or two later -- redoes that iteration with `sharded_hals_solve` (host-synchronous, exact),
+    which also re-centres the guess.  With sweep counts that drift slowly (and saturate at the budget, where the stop is the
+    last sweep by construction) that is rare; a wrong guess costs a redo, never a wrong factor."""
+    C = max(1, min(int(guess.value), guess.max_chunk, budget))
+    W = max(1, min(C, int(guess.window)))
+    head = C - W
+    parts = []
+    if head > 0:
+        parts.append(eng.hals_sweeps(cross, gram, F, head, sparsity=sparsity))
+    snap = guess.snapshots(F, W)
+    parts.append(eng.hals_sweeps(cross, gram, F, W, sparsity=sparsity, snapshots=snap))
+    nd = torch.cat(parts) if len(parts) > 1 else parts[0]
+    allreduce_(nd, group)
+    eng.hals_stop_restore(nd, head, budget, delta, F, snap, status)

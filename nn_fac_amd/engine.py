@@ -188,6 +188,20 @@ class Engine:
                                                 self._stream()), "nnf_hals_sweeps_f32")
         return nd[:int(nsweeps)]
 
+    def hals_stop_restore(self, sums, head, budget, delta, V, snapshots, status):
+        """Device-side replay of the stopping rule over the all-reduced per-sweep sums of a blind chunk (dist.py)."""
+        _chk2d(V, "hals V")
+        r, ncols = V.shape
+        n = int(sums.numel())
+        if sums.dtype != torch.float64 or not sums.is_contiguous() or status.dtype != torch.float64:
+            raise EngineError("hals_stop_restore: sums / status must be float64 device tensors")
+        sp = _ptr(snapshots) if snapshots is not None else C.c_void_p(0)
+        ss = snapshots.stride(0) if snapshots is not None else 0
+        _lib.check(self.lib.nnf_hals_stop_restore_f32(self.ctx, _ptr(sums), n, int(head), int(budget), float(delta), _ptr(V),
+                                                      _ld(V), r, ncols, sp, ss, _ptr(status), self._stream()),
+                   "nnf_hals_stop_restore_f32")
+        return status
+
     # ---- MU / beta-divergence -----------------------------------------------------------------------
     MU_FUSED_MAX_RANK = 64   # the fused two-MFMA kernels are built for r <= 64 (beta = 2 has no limit: Gram form)
 

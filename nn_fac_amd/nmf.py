@@ -157,6 +157,10 @@ class _StepBuffers:
         self.select(0)
         self.guess_u = _dist.SweepGuess()
         self.guess_v = _dist.SweepGuess()
+        self.async_sharded = True         # row-sharded U-side solve: device-side stopping decision (dist.sharded_hals_solve_async)
+        self.sync_next = False            # row-sharded: the next step uses the host-synchronous U-side protocol (after a redo)
+        self.last_step_async = False
+        self.async_hits = self.async_misses = 0
         self.safe_solve = False           # set by run_steps after a persistent solve timed out (chunked launches from then on)
         # the r x r Gram of an update is independent of its cross product (nmf.py:407-408, :432-433): it runs on a side
         # stream, with its own context (a context's workspace serves one stream at a time), under the streaming kernel
@@ -191,11 +195,18 @@ class _SolveTimedOut(Exception):
     """A persistent HALS solve gave up waiting for its other workgroups (status word 1)."""
 
 
+class _GuessMissed(Exception):
+    """Row-sharded run: the blind chunk of the device-side protocol did not contain the stopping sweep in its snapshot window
+    (status words 3 / 4 of nnf_hals_stop_restore_f32): the iteration is redone with the host-synchronous protocol."""
+
+
 def _raise_on_status(host, nstat, timeout_ok=False):
     for i in range(nstat):
         code = int(host[8 * i + _engine.ST_ERR])
         if code == 2:
             raise err.ZeroColumnWhenUnautorized("A column of U is zero with nonzero condition")
+        if code in (_dist.ERR_BEFORE_WINDOW, _dist.ERR_NOT_STOPPED):
+            raise _GuessMissed()
         if code != 0:
             if timeout_ok:
                 raise _SolveTimedOut()
@@ -257,6 +268,9 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
         _raise_on_status(host, step["nstat"], timeout_ok=not getattr(ws, "safe_solve", False))
         pending.pop(0)                     # (a step that timed out stays at the head: run_steps resumes from it)
         result = (step["Ut"], step["V"])
+        if step.get("async_u"):            # row-sharded, device-side protocol: centre the next blind chunk on this count
+            ws.async_hits += 1
+            ws.guess_u.value = max(8, min(int(host[_engine.ST_CNT]) - 1 + 4, ws.guess_u.max_chunk))
         stop = bool(retired(step["it"], float(host[16]),
                             [int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(step["nstat"])]))
 
@@ -293,7 +307,8 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
             hooks["before_u_solve"] = lambda ev=costed["ev"]: main.wait_event(ev)
         Ut, V, nstat = _one_nmf_step_dev(eng, ws, X, rank, Ut, V, update_rule, beta, sparsity_coefficients,
                                          fixed_modes, normalize, deterministic, group=group, skip_cost=overlap, **hooks)
-        step = dict(it=iteration, slot=ws.slot, Ut=Ut, V=V, nstat=nstat, ev=None)
+        step = dict(it=iteration, slot=ws.slot, Ut=Ut, V=V, nstat=nstat, ev=None, async_u=ws.last_step_async)
+        ws.sync_next = False
         if overlap:
             costed = owed
             owed = step
@@ -318,6 +333,15 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
             failed = pending[0]["it"]             # the step being retired is still at the head of the list
             fall_back()
             Ut, V = result                        # factors of the last iteration that retired cleanly
+            iteration = failed
+        except _GuessMissed:
+            failed = pending[0]["it"]
+            drain()
+            pending.clear()
+            owed = costed = None
+            ws.sync_next = True                   # redo this iteration with the exact, host-synchronous protocol
+            ws.async_misses += 1
+            Ut, V = result
             iteration = failed
     if cuda and (pending or overlap):     # dropped speculative iterations still use the shared scratch: let them drain
         main.synchronize()
@@ -423,7 +447,15 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                 timer = time.time() - t0
             if before_u_solve is not None:
                 before_u_solve()
-            if sharded:
+            ws.last_step_async = False
+            if sharded and hasattr(eng, "hals_stop_restore") and not ws.sync_next and ws.async_sharded:
+                # no host round trip: blind chunk + all-reduce + device-side replay of the stopping rule; a missed guess
+                # shows in the status block and run_steps redoes the iteration through the branch below
+                _dist.sharded_hals_solve_async(eng, ws.VMt, ws.G, Ut, group, ws.guess_u, ws.block[8 * nstat:8 * nstat + 8],
+                                               budget=HALS_INNER["maxiter"], delta=HALS_INNER["delta"],
+                                               sparsity=sparsity_coefficients[0])
+                ws.last_step_async = True
+            elif sharded:
                 eps, cnt, eps0 = _dist.sharded_hals_solve(eng, ws.VMt, ws.G, Ut, group, ws.guess_u,
                                                           budget=HALS_INNER["maxiter"], delta=HALS_INNER["delta"],
                                                           sparsity=sparsity_coefficients[0])

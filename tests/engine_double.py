@@ -114,3 +114,15 @@ class OracleEngine:
         cost.copy_(torch.tensor([np.sum((T.numpy() - model) ** 2)], dtype=torch.float64))
         Y.copy_(torch.from_numpy(np.einsum('ijk,kr->rij', T.numpy(), F[2])))
         return Y
+
+    def hals_stop_restore(self, sums, head, budget, delta, V, snapshots, status):
+        s = sums.tolist()
+        stop = next((j for j, v in enumerate(s) if not (v >= delta * s[0]) or j + 1 >= budget), None)
+        status[2] = s[0]
+        if stop is None:
+            status[0], status[1], status[3] = s[-1], float(len(s) + 1), 4.0
+        else:
+            status[0], status[1], status[3] = s[stop], float(stop + 2), (3.0 if stop < head else 0.0)
+            if head <= stop < len(s) - 1:
+                V.copy_(snapshots[stop - head])
+        return status

@@ -21,7 +21,7 @@ import nnfac_oracle as orc
 from engine_double import OracleEngine  # noqa: E402
 
 
-def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2):
+def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2, guess=(3, 5, 2)):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=nranks)
     try:
@@ -33,7 +33,10 @@ def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2
         V = torch.from_numpy(V0.copy())
         # the product's own buffers and outer loop (status ring, fused all-reduce of the V-side terms), engine double below
         eng, ws = OracleEngine(), nmf_mod._StepBuffers(Xl, r, dtype=torch.float64)
-        ws.guess_u = nd.SweepGuess(first=3, max_chunk=5, window=2)   # small on purpose: continue, exact stop, snapshot, replay
+        # (3, 5, 2): small on purpose -- the device-side protocol always misses (chunk shorter than the solve) and every
+        # iteration is redone through the synchronous one: continue, exact stop, snapshot, replay.  (16, 104, 8): the
+        # defaults -- misses while the guess settles, then hits
+        ws.guess_u = nd.SweepGuess(first=guess[0], max_chunk=guess[1], window=guess[2])
         costs, sweeps = [], []
 
         def retired(it, cost, sw):
@@ -43,7 +46,7 @@ def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2
 
         Ut, V = nmf_mod.run_steps(eng, ws, Xl, r, Ut, V, iters, rule, beta, sparsity, [], [False, False], True, retired,
                                   group=dist.group.WORLD)
-        q.put((rank, lo, hi, Ut.numpy().T.copy(), V.numpy().copy(), costs, sweeps))
+        q.put((rank, lo, hi, Ut.numpy().T.copy(), V.numpy().copy(), costs, sweeps, (ws.async_hits, ws.async_misses)))
     finally:
         dist.destroy_process_group()
 
@@ -56,13 +59,15 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("guess", [(3, 5, 2), (16, 104, 8)])
 @pytest.mark.parametrize("sparsity", [[None, None], [0.05, 0.02]])
-def test_row_sharded_step_equals_unsharded_oracle(sparsity):
-    m, n, r, iters, nranks = 301, 40, 6, 4, 2          # odd m: unequal shards
+def test_row_sharded_step_equals_unsharded_oracle(sparsity, guess):
+    m, n, r, iters, nranks = 301, 40, 6, 8, 2          # odd m: unequal shards
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(k, nranks, port, m, n, r, iters, sparsity, q)) for k in range(nranks)]
+    procs = [ctx.Process(target=_worker, args=(k, nranks, port, m, n, r, iters, sparsity, q, "hals", 2, guess))
+             for k in range(nranks)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(nranks))
@@ -76,10 +81,15 @@ def test_row_sharded_step_equals_unsharded_oracle(sparsity):
                                      sweeps=sw)
     Ucat = np.concatenate([x[3] for x in res], axis=0)
     np.testing.assert_allclose(Ucat, U, rtol=1e-9, atol=1e-12)
-    for rank, lo, hi, Ul, Vl, cl, sl in res:
+    for rank, lo, hi, Ul, Vl, cl, sl, (hits, misses) in res:
         np.testing.assert_allclose(Vl, V, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(cl, costs, rtol=1e-9)
         assert sl == sw                                   # identical inner sweep counts on every rank
+        assert hits + misses >= iters                     # every iteration went through the device-side protocol first
+        if guess[1] >= 100:
+            assert hits >= 1, (hits, misses, sw)          # ... and once the guess has settled it hits
+        else:
+            assert hits == 0 or max(sw[0::2]) <= 4        # a 5-sweep chunk cannot contain a longer solve's stop
     assert np.array_equal(res[0][4], res[1][4])           # replicated V bitwise identical across ranks
 
 
@@ -102,7 +112,7 @@ def test_row_sharded_mu_step_equals_unsharded_oracle(beta):
     U, V, costs, _ = orc.compute_nmf(X, r, U0, V0, n_iter_max=iters, tol=0, update_rule="mu", beta=beta,
                                      return_costs=True, deterministic=True)
     np.testing.assert_allclose(np.concatenate([x[3] for x in res], axis=0), U, rtol=1e-9, atol=1e-12)
-    for rank, lo, hi, Ul, Vl, cl, sl in res:
+    for rank, lo, hi, Ul, Vl, cl, sl, _ in res:
         np.testing.assert_allclose(Vl, V, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(cl, costs, rtol=1e-9)
 

@@ -457,3 +457,38 @@ def test_hals_chained_launches_equal_one_launch(layout, slice_, monkeypatch, bui
         V2, eps2, cnt2, _ = hals_nnls_acc(UtM, UtU, V0, **kw)
         monkeypatch.setattr(eng_mod.Engine, "HALS_MAX_SWEEPS_PER_LAUNCH", 1000)
         assert cnt1 == cnt2 and eps1 == eps2 and np.array_equal(V1, V2), (maxiter, delta, cnt1, cnt2)
+
+
+def test_device_side_stop_decision_of_the_sharded_solve(built_lib):
+    """dist.sharded_hals_solve_async on one rank (no group): a blind chunk + nnf_hals_stop_restore_f32 must leave the factor
+    and status words of the persistent solve when the chunk's snapshot window contains the stopping sweep, and flag a missed
+    guess otherwise (3: the rule fired before the window; 4: not within the chunk) -- never a wrong factor silently."""
+    from nn_fac_amd import dist as nd
+    from nn_fac_amd.engine import get_engine, ST_EPS, ST_CNT, ST_EPS0, ST_ERR
+    eng = get_engine("cuda:0")
+    rng = np.random.RandomState(5)
+    r, n = 20, 70000                      # lane kernel
+    U = rng.rand(300, r)
+    M = U @ rng.rand(r, n) + 1e-2 * rng.rand(300, n)
+    UtU, UtM, V0 = dev(U.T @ U), dev(U.T @ M), dev(rng.rand(r, n))
+    ref = V0.clone()
+    st = eng.hals_solve(UtM, UtU, ref, 100, delta=0.01).cpu()
+    cnt = int(st[ST_CNT])
+    assert 4 < cnt - 1 < 90
+    for value, want_err in ((cnt - 1 + 4, 0), (cnt - 1, 0), (cnt - 1 + 7, 0), (cnt - 3, 4), (cnt - 1 + 30, 3)):
+        F = V0.clone()
+        status = torch.zeros(8, dtype=torch.float64, device="cuda")
+        guess = nd.SweepGuess(first=value, max_chunk=104, window=8)
+        nd.sharded_hals_solve_async(eng, UtM, UtU, F, None, guess, status, budget=100, delta=0.01)
+        s = status.cpu()
+        assert int(s[ST_ERR]) == want_err, (value, s)
+        if want_err == 0:
+            assert int(s[ST_CNT]) == cnt and float(s[ST_EPS]) == float(st[ST_EPS]) and float(s[ST_EPS0]) == float(st[ST_EPS0])
+            assert torch.equal(F, ref)
+    # at the sweep budget the stop is the last sweep by construction
+    ref2 = V0.clone()
+    st2 = eng.hals_solve(UtM, UtU, ref2, 6, delta=0.0).cpu()
+    F = V0.clone()
+    status = torch.zeros(8, dtype=torch.float64, device="cuda")
+    nd.sharded_hals_solve_async(eng, UtM, UtU, F, None, nd.SweepGuess(first=50, max_chunk=104, window=8), status, budget=6, delta=0.0)
+    assert int(status[ST_ERR]) == 0 and int(status[ST_CNT]) == int(st2[ST_CNT]) == 7 and torch.equal(F, ref2)

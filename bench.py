@@ -397,6 +397,9 @@ def bench_nmf(cx, args, cfg, steps, warmup, with_cpu, with_fixed, with_kernels):
     run = NmfRun(cx, X, Ut, V, r, rule, beta)
     dt, cost, start = run.measure(warmup, steps)
     sweeps = list(run.sweeps)
+    if cx.world > 1 and os.environ.get("NNF_BENCH_DEBUG"):
+        print(f"[rank {cx.rank}] sharded U-side protocol: {run.ws.async_hits} device-side decisions, "
+              f"{run.ws.async_misses} redone synchronously; sweeps {sweeps}", file=sys.stderr, flush=True)
     out = {"value": units * steps / dt, "ms_per_step": 1e3 * dt / steps, "final_cost": cost,
            "inner_sweeps_per_step_last": sweeps[-1] if sweeps else None,
            "inner_sweeps_mean": (sum(sum(x) for x in sweeps) / len(sweeps)) if sweeps and sweeps[0] else None,

@@ -132,3 +132,40 @@ def sharded_hals_solve_async(eng, cross, gram, F, group, guess, status, budget=1
     nd = torch.cat(parts) if len(parts) > 1 else parts[0]
     allreduce_(nd, group)
     eng.hals_stop_restore(nd, head, budget, delta, F, snap, status)
+
+
+def sharded_random_init(m, n, rank, group, seed=0, device=None, exact_stream=False):
+    """Random start values of a row-sharded factorisation (initialize_factors.py:40-46 per shard).
+
+    Returns (U0_block, V0, (lo, hi)): this rank's rows [lo, hi) of U_0 (m x rank) and the whole V_0 (rank x n), V_0 identical
+    on every rank.  Default: drawn on the device -- V_0 from `seed`, the row block from `seed * nranks + 1 + rank` -- so that
+    neither factor ever exists on the host (config E: U_0 alone is 800 MB in float64).  `exact_stream=True` reproduces the
+    reference's legacy NumPy stream instead (np.random.seed(seed); rand(m, rank); rand(rank, n)): every rank skips to its
+    rows in that stream, so the concatenated blocks ARE the unsharded reference start (host memory: one block + V_0)."""
+    import numpy as np
+    nranks, r_ = world(group), (dist.get_rank(group) if group is not None else 0)
+    lo, hi = shard_rows(m, r_, nranks)
+    if exact_stream:
+        rng = np.random.RandomState(seed)
+        done = 0
+        while done < lo * rank:                      # skip the rows of the ranks before this one, a bounded piece at a time
+            k = min(lo * rank - done, 1 << 24)
+            rng.random_sample(k)
+            done += k
+        U0 = rng.random_sample((hi - lo, rank))
+        rest = (m - hi) * rank
+        while rest > 0:
+            k = min(rest, 1 << 24)
+            rng.random_sample(k)
+            rest -= k
+        V0 = rng.random_sample((rank, n))
+        U0, V0 = torch.from_numpy(U0), torch.from_numpy(V0)
+        if device is not None:
+            U0, V0 = U0.to(device=device, dtype=torch.float32), V0.to(device=device, dtype=torch.float32)
+        return U0, V0, (lo, hi)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    gv = torch.Generator(device=dev).manual_seed(int(seed))
+    gu = torch.Generator(device=dev).manual_seed(int(seed) * nranks + 1 + r_)
+    V0 = torch.rand(rank, n, device=dev, generator=gv)
+    U0 = torch.rand(hi - lo, rank, device=dev, generator=gu)
+    return U0, V0, (lo, hi)

@@ -57,8 +57,12 @@ def nmf(data, rank, init="random", U_0=None, V_0=None, n_iter_max=100, tol=1e-8,
 def compute_nmf(data, rank, U_in, V_in, n_iter_max=100, tol=1e-8,
                 update_rule="hals", beta=2,
                 sparsity_coefficients=[None, None], fixed_modes=[], normalize=[False, False],
-                verbose=False, return_costs=False, deterministic=False, sweep_log=None):
-    """Outer loop of nmf.py:284-329.  ``sweep_log`` (extension): list receiving the inner sweep counts."""
+                verbose=False, return_costs=False, deterministic=False, sweep_log=None, group=None):
+    """Outer loop of nmf.py:284-329.  ``sweep_log`` (extension): list receiving the inner sweep counts.
+    ``group`` (extension): a torch.distributed process group -- `data` and `U_in` are then THIS RANK'S row block of a
+    row-sharded problem (contiguous blocks, nn_fac_amd.dist.shard_rows), `V_in` is replicated; the Gram / cross terms, the
+    stopping scalars and the cost are all-reduced over the group (RCCL over xGMI) and every rank returns its
+    block of U, the whole V and the global costs (start values: nn_fac_amd.dist.sharded_random_init)."""
     dev = device_of(data, U_in, V_in)
     eng = _engine.get_engine(dev)
     X = to_dev(data, dev)
@@ -102,7 +106,7 @@ def compute_nmf(data, rank, U_in, V_in, n_iter_max=100, tol=1e-8,
         return False
 
     Ut, V = run_steps(eng, ws, X, rank, Ut, V, n_iter_max, update_rule, beta, sparsity_coefficients, fixed_modes,
-                      normalize, deterministic, retired)
+                      normalize, deterministic, retired, group=group)
 
     U_out, V_out = like_input(Ut.t(), U_in), like_input(V, V_in)
     if return_costs:
@@ -157,7 +161,15 @@ class _StepBuffers:
         self.select(0)
         self.guess_u = _dist.SweepGuess()
         self.guess_v = _dist.SweepGuess()
-        self.async_sharded = True         # row-sharded U-side solve: device-side stopping decision (dist.sharded_hals_solve_async)
+        # Row-sharded U-side solve with the device-side stopping decision (dist.sharded_hals_solve_async): opt-in with
+        # NNF_SHARDED_ASYNC=1.  A missed guess costs a pipeline drain + a redone iteration, and the sweep counts of the first
+        # outer iterations jump by tens (33, 52, 67, 38, ... at config B), so it is engaged only once two consecutive solves
+        # differ by <= 4 sweeps (`async_ready`).  Validated for correctness (gloo world-size-2 tests, one-GPU kernel test);
+        # its gain needs one process per GPU to show -- with two ranks time-slicing ONE GPU (the only rehearsal available
+        # here) the unsynchronised ranks starve each other's persistent V-side solves -- hence not the default.
+        self.async_sharded = __import__("os").environ.get("NNF_SHARDED_ASYNC", "0") == "1"
+        self.async_ready = False
+        self.last_u_count = None
         self.sync_next = False            # row-sharded: the next step uses the host-synchronous U-side protocol (after a redo)
         self.last_step_async = False
         self.async_hits = self.async_misses = 0
@@ -268,6 +280,10 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
         _raise_on_status(host, step["nstat"], timeout_ok=not getattr(ws, "safe_solve", False))
         pending.pop(0)                     # (a step that timed out stays at the head: run_steps resumes from it)
         result = (step["Ut"], step["V"])
+        if group is not None and update_rule == "hals" and step["nstat"] >= 1 and 0 not in fixed_modes:
+            cnt_u = int(host[_engine.ST_CNT]) - 1
+            ws.async_ready = ws.last_u_count is not None and abs(cnt_u - ws.last_u_count) <= 4
+            ws.last_u_count = cnt_u
         if step.get("async_u"):            # row-sharded, device-side protocol: centre the next blind chunk on this count
             ws.async_hits += 1
             ws.guess_u.value = max(8, min(int(host[_engine.ST_CNT]) - 1 + 4, ws.guess_u.max_chunk))
@@ -448,7 +464,7 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             if before_u_solve is not None:
                 before_u_solve()
             ws.last_step_async = False
-            if sharded and hasattr(eng, "hals_stop_restore") and not ws.sync_next and ws.async_sharded:
+            if sharded and hasattr(eng, "hals_stop_restore") and not ws.sync_next and ws.async_sharded and ws.async_ready:
                 # no host round trip: blind chunk + all-reduce + device-side replay of the stopping rule; a missed guess
                 # shows in the status block and run_steps redoes the iteration through the branch below
                 _dist.sharded_hals_solve_async(eng, ws.VMt, ws.G, Ut, group, ws.guess_u, ws.block[8 * nstat:8 * nstat + 8],

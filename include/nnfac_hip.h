@@ -79,6 +79,22 @@ int nnf_ctx_set_probe(nnf_ctx* ctx, void* ev_begin, void* ev_end);
 #define NNF_PROBE_COUNT 7
 int nnf_ctx_set_probe_kernel(nnf_ctx* ctx, int kernel_id);
 
+/* ---- multi-GPU exchange of the row-sharded path: RCCL all-reduce (sum, in place) over xGMI -------------
+ * One process per GPU.  Rank 0 draws a 128-byte id (nnf_comm_unique_id) and hands it to the other ranks by any channel of
+ * the host application; every rank then calls nnf_comm_create(its ctx, nranks, rank, id) -- collective, like
+ * ncclCommInitRank.  What a sharded NMF iteration exchanges (nn_fac_amd/nmf.py does the same through torch.distributed):
+ *   V update: UtM (r x n) | UtU (r x r) in ONE buffer -> nnf_allreduce_f32;  U update: the per-sweep stopping sums
+ *   (nnf_hals_sweeps_f32 -> nnf_allreduce_f64 -> nnf_hals_stop_restore_f32);  cost: one double -> nnf_allreduce_f64.
+ * RCCL is bound at run time (dlopen); NNF_ERR_DEVICE when it is not available. */
+typedef struct nnf_comm nnf_comm;
+int nnf_comm_unique_id(void* id_out_128_bytes);
+int nnf_comm_create(nnf_comm** out_comm, nnf_ctx* ctx, int nranks, int rank, const void* id_128_bytes);
+int nnf_comm_destroy(nnf_comm* comm);
+int nnf_comm_size(const nnf_comm* comm);
+int nnf_comm_rank(const nnf_comm* comm);
+int nnf_allreduce_f32(nnf_comm* comm, float* buf, int64_t count, void* stream);
+int nnf_allreduce_f64(nnf_comm* comm, double* buf, int64_t count, void* stream);
+
 /* G[r x r] = A[r x K] * A^T.   Replaces VVt = np.dot(V, V.T) (nmf.py:407), UtU = np.dot(U.T, U) (nmf.py:432),
  * and each factor Gram in ntf.py:442-445.  Split-K partials are summed in fp64 in a fixed order. */
 int nnf_gram_f32(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg, void* stream);

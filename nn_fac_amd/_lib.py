@@ -21,6 +21,13 @@ SIGNATURES = {
     "nnf_ctx_create": (_i32, [C.POINTER(_p), _i32, C.c_size_t]),
     "nnf_ctx_destroy": (_i32, [_p]),
     "nnf_ctx_workspace_bytes": (C.c_size_t, [_p]),
+    "nnf_comm_unique_id": (_i32, [_p]),
+    "nnf_comm_create": (_i32, [C.POINTER(_p), _p, _i32, _i32, _p]),
+    "nnf_comm_destroy": (_i32, [_p]),
+    "nnf_comm_size": (_i32, [_p]),
+    "nnf_comm_rank": (_i32, [_p]),
+    "nnf_allreduce_f32": (_i32, [_p, _p, _i64, _p]),
+    "nnf_allreduce_f64": (_i32, [_p, _p, _i64, _p]),
     "nnf_gram_f32": (_i32, [_p, _p, _i32, _i64, _i64, _p, _i64, _p]),
     "nnf_xht_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32, _i64, _p, _i64, _p]),
     "nnf_xty_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32, _i64, _p, _i64, _p]),

@@ -450,6 +450,49 @@ class Engine:
         return o
 
 
+class Comm:
+    """RCCL communicator of the C ABI (nnf_comm_*): what a C-ABI consumer uses for the row-sharded exchanges.  The Python
+    drivers go through torch.distributed (the same RCCL underneath); this wrapper exists for the ABI tests and for hosts
+    that do not initialise torch.distributed."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().nnf_comm_unique_id(buf), "nnf_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, engine, nranks, rank, unique_id):
+        self.engine = engine
+        h = C.c_void_p()
+        _lib.check(engine.lib.nnf_comm_create(C.byref(h), engine.ctx, int(nranks), int(rank),
+                                              C.create_string_buffer(unique_id, 128)), "nnf_comm_create")
+        self.h = h
+
+    def size(self):
+        return self.engine.lib.nnf_comm_size(self.h)
+
+    def rank(self):
+        return self.engine.lib.nnf_comm_rank(self.h)
+
+    def allreduce_(self, t):
+        if not t.is_cuda or not t.is_contiguous() or t.dtype not in (torch.float32, torch.float64):
+            raise EngineError("Comm.allreduce_: contiguous float32 / float64 device tensor expected")
+        fn = self.engine.lib.nnf_allreduce_f32 if t.dtype == torch.float32 else self.engine.lib.nnf_allreduce_f64
+        _lib.check(fn(self.h, _ptr(t), t.numel(), self.engine._stream()), "nnf_allreduce")
+        return t
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.engine.lib.nnf_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def get_engine(device=None):
     """Process-wide engine for `device` (default: current device)."""
     if not torch.cuda.is_available():

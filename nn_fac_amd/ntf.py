@@ -1,5 +1,5 @@
 """NTF (nonnegative PARAFAC / CP) driver on the MI355X engine -- drop-in for nn_fac/ntf.py
-(ntf :19-199, compute_ntf :201-344, one_ntf_step :347-477) for 3-way tensors.
+(ntf :19-199, compute_ntf :201-344, one_ntf_step :347-477), tensors of any order >= 3.
 
 Per updated mode the reference statements map to the C ABI as follows (factors kept transposed, R x dim):
 
@@ -14,7 +14,9 @@ Per updated mode the reference statements map to the C ABI as follows (factors k
 
 Differences kept on purpose: ``one_ntf_step`` exposes ``alpha`` like the reference (default 0.5 = wall-clock dependent,
 ntf.py:349); ``compute_ntf`` adds ``alpha`` / ``delta`` keywords (default: the reference's) so that deterministic runs
-(alpha = inf) are reachable through the driver.  Only 3-way tensors are accelerated (NotImplementedError otherwise).
+(alpha = inf) are reachable through the driver.  Tensors of order > 3 run through the same 3-way kernels on VIEWS of the
+tensor that group adjacent modes, against the Khatri-Rao product of each group's factors (_NtfState.view3); the dimension
+tree and the fused cost pass are 3-way only.
 """
 import math
 import time
@@ -63,22 +65,26 @@ class _NtfState:
     MTTKRP output (R x I_k) together with the mode-0 Gram (R x R) -- one collective --, the cost one f64."""
 
     def __init__(self, eng, T, group=None):
-        if T.dim() != 3:
-            raise NotImplementedError("the MI355X engine accelerates 3-way tensors (nnf_mttkrp3_f32)")
+        if T.dim() < 3:
+            raise NotImplementedError("NTF needs a tensor of order >= 3 (a matrix is nmf's business)")
+        if T.dim() > 3 and _dist.world(group) > 1:
+            raise NotImplementedError("leading-mode-sharded NTF is built for 3-way tensors")
         self.eng = eng
         self.group = group
         self.T = T.contiguous()
-        I, J, K = self.T.shape
-        t2 = self.T.view(I, J * K)
+        self.nway = self.T.dim()
+        t2 = self.T.view(self.T.shape[0], -1)
         self.norm2 = eng.dot(t2, t2)          # float64 device scalar, ||T||^2
         if _dist.world(group) > 1:
             _dist.allreduce_(self.norm2, group)
         self.guess0 = _dist.SweepGuess()
         self._unf = {}
         self._Y, self._Y_of, self._grams = None, None, {}
-        # per-iteration status: 3 HALS status blocks + cost at [24]; a ring with pinned host mirrors (run_ntf_steps)
-        self.blocks = torch.zeros((3, 8 * 3 + 8), dtype=torch.float64, device=T.device)
-        self.host = torch.zeros((3, 8 * 3 + 8), dtype=torch.float64)
+        # per-iteration status: one HALS status block per mode, then the cost at [8 * nway]; a ring with pinned host
+        # mirrors (run_ntf_steps)
+        self.cost_at = 8 * self.nway
+        self.blocks = torch.zeros((3, self.cost_at + 8), dtype=torch.float64, device=T.device)
+        self.host = torch.zeros((3, self.cost_at + 8), dtype=torch.float64)
         if T.is_cuda:
             self.host = self.host.pin_memory()
         self.select(0)
@@ -86,6 +92,26 @@ class _NtfState:
     def select(self, slot):
         self.slot = slot
         self.block = self.blocks[slot]
+
+    def view3(self, mode, Ft):
+        """Order-N tensors through the 3-way kernels: mode `mode` of T (I_0 x ... x I_{N-1}, C order) is mode m3 of a 3-way
+        VIEW of the same memory whose other two axes are groups of adjacent modes, against the Khatri-Rao product of each
+        group's factors (first factor of a group slowest = tl.unfold / tl.tenalg.khatri_rao order):
+            first mode : (I_0, I_1, rest)         [F_0, F_1, KR(F_2..)]           m3 = 0
+            last mode  : (rest, I_{N-2}, I_{N-1}) [KR(F_0..F_{N-3}), F_{N-2}, F_{N-1}]   m3 = 2
+            otherwise  : (left, I_n, right)       [KR(F_0..F_{n-1}), F_n, KR(F_{n+1}..)] m3 = 1
+        Returns (T3, [three transposed factors], m3).  The grouped factors are R x prod(group dims): small next to T."""
+        N, sh = self.nway, self.T.shape
+        if N == 3:
+            return self.T, list(Ft), mode
+        if mode == 0:
+            return self.T.view(sh[0], sh[1], -1), [Ft[0], Ft[1], _kr_group_t(Ft[2:])], 0
+        if mode == N - 1:
+            return self.T.view(-1, sh[N - 2], sh[N - 1]), [_kr_group_t(Ft[:N - 2]), Ft[N - 2], Ft[N - 1]], 2
+        left = 1
+        for s in sh[:mode]:
+            left *= int(s)
+        return self.T.view(left, sh[mode], -1), [_kr_group_t(Ft[:mode]), Ft[mode], _kr_group_t(Ft[mode + 1:])], 1
 
     def _ybuf(self, R):
         I, J, K = self.T.shape
@@ -123,6 +149,14 @@ class _NtfState:
         return self._unf[mode]
 
 
+def _kr_group_t(Fts):
+    """khatri_rao(group)^T for a list of transposed factors (R x dim each): R x prod(dims), first factor slowest."""
+    res = Fts[0]
+    for f in Fts[1:]:
+        res = (res[:, :, None] * f[:, None, :]).reshape(res.shape[0], -1)
+    return res.contiguous()
+
+
 def _krao_t(Ft, skip):
     """khatri_rao(factors, skip_matrix=skip)^T as an R x prod(other dims) tensor, first remaining mode slowest."""
     others = [f for i, f in enumerate(Ft) if i != skip]
@@ -140,10 +174,12 @@ def _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, cost, fuse_
             and Ft[0].shape[0] <= getattr(eng, "CP3_FUSED_MAX_RANK", 0):
         st.cost_and_partial(Ft, cost)                # ||T - model||^2
     elif update_rule == "hals":
-        eng.cp3_betadiv(st.T, Ft, 2, out=cost)
+        T3, F3, _ = st.view3(0, Ft)
+        eng.cp3_betadiv(T3, F3, 2, out=cost)
         cost.mul_(2.0)                               # ||T - model||^2
     else:
-        eng.cp3_betadiv(st.T, Ft, beta, out=cost)
+        T3, F3, _ = st.view3(0, Ft)
+        eng.cp3_betadiv(T3, F3, beta, out=cost)
     if sharded:
         _dist.allreduce_(cost, st.group)             # additive over the blocks of the leading mode
     sparsity_error = None
@@ -179,7 +215,8 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
     # same partial product Y = T x_2 F2^T -- one pass over T instead of two.  Only where the result does not depend on the
     # wall clock (alpha = inf): the timed rule prices every mode's own Gram + MTTKRP (ntf.py:440-451).
     Y = None
-    if update_rule == "hals" and math.isinf(alpha) and 0 not in fixed_modes and 1 not in fixed_modes \
+    N = st.nway
+    if N == 3 and update_rule == "hals" and math.isinf(alpha) and 0 not in fixed_modes and 1 not in fixed_modes \
             and hasattr(eng, "mttkrp3_from_partial"):
         Y = st.partial(Ft[2])
 
@@ -188,9 +225,10 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
             return eng.mttkrp3_from_partial(Y, Ft[1], 2, out=out)
         if Y is not None and mode == 1:
             return eng.mttkrp3_from_partial(Y, Ft[0], 1, out=out)      # Ft[0]: already this iteration's update
-        return eng.mttkrp3(st.T, Ft, mode, out=out)
+        T3, F3, m3 = st.view3(mode, Ft)
+        return eng.mttkrp3(T3, F3, m3, out=out)
 
-    for mode in [m for m in range(3) if m not in fixed_modes]:
+    for mode in [m for m in range(N) if m not in fixed_modes]:
         if update_rule == "hals":
             deterministic = math.isinf(alpha)
             if not deterministic:
@@ -241,7 +279,7 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
             Ft[mode] = eng.mu_right(st.unfolded_t(mode), _krao_t(Ft, mode), Ft[mode], beta)
 
     if not skip_cost:
-        _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, st.block[24:25],
+        _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, st.block[st.cost_at:st.cost_at + 1],
                   fuse_next=fuse_next and Y is not None)
     return Ft, nstat
 
@@ -267,7 +305,7 @@ def run_ntf_steps(st, rank, Ft, n_iter, update_rule, beta, sparsity_coefficients
             if int(host[8 * i + _engine.ST_ERR]) != 0:
                 raise err.EngineError("hals grid barrier timed out; result invalid")
         result = step["Ft"]
-        stop = bool(retired(step["it"], float(host[24]),
+        stop = bool(retired(step["it"], float(host[st.cost_at]),
                             [int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(step["nstat"])]))
 
     for iteration in range(n_iter):
@@ -361,4 +399,4 @@ def one_ntf_step(unfolded_tensors, rank, in_factors, norm_tensor, update_rule, b
     Ft, nstat = _one_ntf_step_dev(st, rank, Ft, update_rule, beta, list(sparsity_coefficients), fixed_modes, normalize,
                                   alpha, delta)
     host = st.block.cpu()
-    return [like_input(f.t(), in_factors[i]) for i, f in enumerate(Ft)], float(host[24])
+    return [like_input(f.t(), in_factors[i]) for i, f in enumerate(Ft)], float(host[st.cost_at])

@@ -492,3 +492,23 @@ def test_device_side_stop_decision_of_the_sharded_solve(built_lib):
     status = torch.zeros(8, dtype=torch.float64, device="cuda")
     nd.sharded_hals_solve_async(eng, UtM, UtU, F, None, nd.SweepGuess(first=50, max_chunk=104, window=8), status, budget=6, delta=0.0)
     assert int(status[ST_ERR]) == 0 and int(status[ST_CNT]) == int(st2[ST_CNT]) == 7 and torch.equal(F, ref2)
+
+
+def test_c_abi_rccl_communicator_single_rank(built_lib):
+    """nnf_comm_* / nnf_allreduce_f32|f64: the RCCL exchange of the row-sharded path behind the C ABI.  One GPU here, so a
+    communicator of ONE rank: id, init, in-place sum all-reduce (the identity) of the V-side buffer UtM | UtU and of a
+    float64 vector on the caller's stream, destroy."""
+    from nn_fac_amd.engine import get_engine, Comm
+    eng = get_engine("cuda:0")
+    uid = Comm.unique_id()
+    assert len(uid) == 128
+    comm = Comm(eng, 1, 0, uid)
+    assert comm.size() == 1 and comm.rank() == 0
+    a = torch.rand(50 * 2000 + 50 * 50, device="cuda")
+    b = torch.rand(104, dtype=torch.float64, device="cuda")
+    a0, b0 = a.clone(), b.clone()
+    comm.allreduce_(a)
+    comm.allreduce_(b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, a0) and torch.equal(b, b0)
+    comm.close()

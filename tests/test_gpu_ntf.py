@@ -182,3 +182,29 @@ def test_fused_cost_and_partial(built_lib, shape, R):
     assert abs(float(cost) - want) <= 2e-5 * want, (float(cost), want)
     np.testing.assert_allclose(Y.cpu().numpy(), np.einsum('ijk,kr->rij', T64, F64[2]), rtol=2e-5)
     assert abs(float(cost) - 2 * float(eng.cp3_betadiv(Td, Ft, 2))) <= 1e-5 * want
+
+
+@pytest.mark.parametrize("shape,R", [((9, 8, 7, 6), 3), ((5, 6, 4, 3, 7), 2), ((20, 3, 17, 11), 5)])
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 1), ("mu", 2)])
+def test_ntf_order_n(built_lib, shape, R, rule, beta):
+    """Tensors of order 4 and 5 (the reference loops over arbitrary modes, ntf.py:309-311,437-456): every mode's MTTKRP runs
+    through the 3-way kernels on a grouped view of T (_NtfState.view3) -- factors, costs and sweep counts vs the oracle."""
+    from nn_fac_amd.ntf import compute_ntf
+    rng = np.random.RandomState(len(shape) * 100 + R)
+    gen = [rng.rand(s, R) for s in shape]
+    T = gen[0]
+    for g in gen[1:]:
+        T = T[..., None, :] * g
+    T = (T.sum(axis=-1) + 1e-2 * rng.rand(*shape)).astype(np.float32)
+    F0 = [rng.rand(s, R).astype(np.float32) + 0.01 for s in shape]
+    N = len(shape)
+    kw = dict(n_iter_max=4, tol=0, update_rule=rule, beta=beta, return_costs=True, alpha=math.inf,
+              sparsity_coefficients=[None] * N, normalize=[False] * N)
+    sw, swo = [], []
+    F, costs, _ = compute_ntf(T, R, F0, sweep_log=sw, **kw)
+    Fo, co, _ = orc.compute_ntf(T.astype(np.float64), R, [f.astype(np.float64) for f in F0], sweeps=swo, **kw)
+    tol = 2e-3 if rule == "hals" else 5e-5
+    for i in range(N):
+        assert F[i].shape == Fo[i].shape and rel(F[i], Fo[i]) < tol, (i, rel(F[i], Fo[i]))
+    np.testing.assert_allclose(costs, co, rtol=2e-3 if rule == "hals" else 1e-4)
+    assert sw == swo

@@ -157,6 +157,13 @@ int nnf_hals_stop_restore_f32(nnf_ctx* ctx, const double* sums_f64, int nsweeps,
 int nnf_mu_left_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
                     const float* V, int64_t ldv, int r, double beta, float* Ut_out, int64_t lduo, void* stream);
 
+/* nnf_mu_left_f32 with beta = 1 that also returns *cost_f64 = beta_divergence(X, U V, 1) of the factors it STARTS from
+ * (mu.py:84-88 + nmf.py:455): the update forms every entry of U V anyway, so the cost of outer iteration i is a by-product of
+ * the left update of iteration i+1 and the separate pass over X (nnf_betadiv_f32) is only needed after the last one.
+ * Same update as nnf_mu_left_f32 bit for bit.  r <= 64. */
+int nnf_mu_left_kl_cost_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                            const float* V, int64_t ldv, int r, float* Ut_out, int64_t lduo, double* cost_f64, void* stream);
+
 /* switch_alternate_mu(..., "V") (mu.py:26-27): V_out[k,j] = max(V[k,j] * (num/den)^gamma, 1e-12) with
  *   num = U^T((UV)^(beta-2) .* X), den = U^T (UV)^(beta-1); split over m, fixed-order slab reduction. */
 int nnf_mu_right_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,

@@ -40,6 +40,7 @@ SIGNATURES = {
     "nnf_ctx_set_probe": (_i32, [_p, _p, _p]),
     "nnf_ctx_set_probe_kernel": (_i32, [_p, _i32]),
     "nnf_mu_left_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _i64, _p]),
+    "nnf_mu_left_kl_cost_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _p]),
     "nnf_mu_right_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _i64, _p]),
     "nnf_mu_right_accum_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _i64, _p, _i64, _p, _p]),
     "nnf_ttm3_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _i32, _i32, _p, _p]),

@@ -17,7 +17,7 @@
 #include "k_stream_common.h"
 #include <math.h>
 
-enum { BM_KL = 1, BM_FROB = 2, BM_GEN = 9 };   // BM_FROB: R = X (plain X V^T) + the squared residual, see nnf_cp3_partial_cost_f32
+enum { BM_KL = 1, BM_FROB = 2, BM_KLC = 3, BM_GEN = 9 };   // BM_KLC: the KL update + the KL divergence of its INPUT factors   // BM_FROB: R = X (plain X V^T) + the squared residual, see nnf_cp3_partial_cost_f32
 
 // extra operands of the left kernel's BM_FROB form: Khatri-Rao left factor generated from two short factors, cost partials
 struct mu_left_extra {
@@ -70,7 +70,7 @@ __device__ __forceinline__ void stageA_direct(const float* __restrict__ A, int64
 
 template <int BM>
 __device__ __forceinline__ void mu_elem(float x, float p, float beta, float& r1, float& r2) {
-    if constexpr (BM == BM_KL) {
+    if constexpr (BM == BM_KL || BM == BM_KLC) {
         r1 = x * __builtin_amdgcn_rcpf(p);
         r2 = 0.f;
     } else if constexpr (BM == BM_FROB) {
@@ -439,13 +439,17 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                         const float dd = ok ? (xb[t & 1][nt][reg] - accP[nt][reg]) : 0.f;
                         csum = fmaf(dd, dd, csum);
                     }
+                    if constexpr (BM == BM_KLC) {   // beta_divergence(X, UV, 1) of the factors this update starts from
+                        const float term = nnf_cost_term<NNF_COST_KL>(xb[t & 1][nt][reg], accP[nt][reg], 1.f);
+                        csum += ok ? term : 0.f;
+                    }
                     R1[nt][reg] = ok ? r1 : 0.f;
                     if constexpr (BM == BM_GEN) R2[nt][reg] = ok ? r2 : 0.f;
                 }
             }
             // finish this group's residual sum HERE: left alone, LLVM sinks the whole dependent chain of a chunk (and the 48
             // differences it consumes) to the chunk's last block -- 256 VGPRs + spills instead of ~180
-            if constexpr (BM == BM_FROB) asm volatile("" : "+v"(csum));
+            if constexpr (BM == BM_FROB || BM == BM_KLC) asm volatile("" : "+v"(csum));
             // MFMA #2: num[rk][i] += V[rk][j] * R[j][i], k = the block's 16 columns
             f32x4 af[MT];
 #pragma unroll
@@ -494,7 +498,7 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                 }
         }
     }
-    if constexpr (BM == BM_FROB) {   // fp32 per lane (a few hundred terms), fp64 from the wave level up, fixed order
+    if constexpr (BM == BM_FROB || BM == BM_KLC) {   // fp32 per lane (a few hundred terms), fp64 from the wave level up, fixed order
         double* red = reinterpret_cast<double*>(smem);    // the chunk images are dead: every wave is past its last read
         __syncthreads();
         const double tot = nnf_block_sum_f64((double)csum, red);
@@ -609,7 +613,7 @@ static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int6
     const size_t shm = mu_shm(MT, r, BM != BM_GEN);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_mu_left_kernel<MT, BM, VEC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    if (BM == BM_KL) {  // den[k] = rowsum(V)[k]   (mu.py:86-87)
+    if (BM == BM_KL || BM == BM_KLC) {  // den[k] = rowsum(V)[k]   (mu.py:86-87)
         const int rc = nnf_launch_rowsum(cur, V, ldv, r, n, dvec, st);
         if (rc != NNF_OK) return rc;
     }
@@ -622,7 +626,7 @@ static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int6
         grid = slots;
     }
     if (n_hi * 256 + (grid - n_hi) * 192 < m) return NNF_ERR_UNSUPPORTED;   // (cannot happen)
-    if (BM == BM_FROB) {
+    if (BM == BM_FROB || BM == BM_KLC) {
         ex.partial = (double*)cur.take((size_t)grid * 8);
         if (!ex.partial || !cost_out) return NNF_ERR_WORKSPACE;
     }
@@ -631,7 +635,7 @@ static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int6
                        (float)beta, dvec, raw_num ? -1.f : gamma_of(beta), Ut_out, lduo, a_vec_ok, (int)n_hi, ex);
     NNF_CHECK_LAUNCH();
     nnf_probe(ctx, NNF_PROBE_MU_LEFT, 1, st);
-    if (BM == BM_FROB) return nnf_launch_sum_f64(ex.partial, grid, 1.0, cost_out, st);
+    if (BM == BM_FROB || BM == BM_KLC) return nnf_launch_sum_f64(ex.partial, grid, 1.0, cost_out, st);
     return NNF_OK;
 }
 
@@ -912,4 +916,35 @@ extern "C" int nnf_cp3_partial_cost_f32(nnf_ctx* ctx, const float* T, int64_t I,
         default: return NNF_ERR_UNSUPPORTED;
     }
 #undef CP3PC
+}
+
+// KL multiplicative update of the left factor (nnf_mu_left_f32 with beta = 1) that ALSO returns beta_divergence(X, U V, 1)
+// of the factors it starts from (mu.py:84-88 + nmf.py:455).  The update kernel forms every entry of P = U V anyway and holds
+// the matching X value: the divergence term rides along (VALU work next to an MFMA-bound kernel), so the cost of outer
+// iteration i is a by-product of the left update of iteration i+1 and the separate pass over X (nnf_betadiv_f32: a quarter of
+// a KL iteration at 100000 x 2000, rank 50) is only needed after the last iteration.  Same update as nnf_mu_left_f32, bit
+// for bit.  r <= 64.
+extern "C" int nnf_mu_left_kl_cost_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
+                                       int64_t ldu, const float* V, int64_t ldv, int r, float* Ut_out, int64_t lduo,
+                                       double* cost_f64, void* stream) {
+    int rc = mu_args_ok(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 1.0, Ut_out);
+    if (rc != NNF_OK) return rc;
+    if (lduo < m || !cost_f64) return NNF_ERR_ARG;
+    if (r > 64) return NNF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    nnf_ws_cursor cur(ctx);
+    const mu_left_extra ex{nullptr, 0, 1, nullptr};
+    const int MT = (r + 15) / 16;
+    const bool vec = x_vec_ok(X, ldx);
+#define KLC(MTV)                                                                                                             \
+    return vec ? launch_mu_left<MTV, BM_KLC, true>(ctx, cur, X, m, n, ldx, Ut, ldu, V, ldv, r, 1.0, Ut_out, lduo, st, 0, ex, cost_f64) \
+               : launch_mu_left<MTV, BM_KLC, false>(ctx, cur, X, m, n, ldx, Ut, ldu, V, ldv, r, 1.0, Ut_out, lduo, st, 0, ex, cost_f64)
+    switch (MT) {
+        case 1: KLC(1);
+        case 2: KLC(2);
+        case 3: KLC(3);
+        case 4: KLC(4);
+        default: return NNF_ERR_UNSUPPORTED;
+    }
+#undef KLC
 }

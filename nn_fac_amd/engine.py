@@ -227,10 +227,20 @@ class Engine:
             dvec = Ut.sum(dim=1, dtype=torch.float64) if kl else None
         return num, den, dvec
 
-    def mu_left(self, X, Ut, V, beta, out=None):
+    def mu_left(self, X, Ut, V, beta, out=None, cost_out=None):
+        """`cost_out` (1-element float64 device tensor; beta = 1, r <= 64 only): also receives beta_divergence(X, U V, 1) of
+        the INPUT factors (nnf_mu_left_kl_cost_f32)."""
         _chk2d(X, "mu X"), _chk2d(Ut, "mu Ut"), _chk2d(V, "mu V")
         m, n = X.shape
         r = Ut.shape[0]
+        if cost_out is not None:
+            if float(beta) != 1.0 or r > self.MU_FUSED_MAX_RANK:
+                raise EngineError("mu_left: the fused cost is built for beta = 1 and r <= 64")
+            O = out if out is not None else torch.empty_like(Ut)
+            _lib.check(self.lib.nnf_mu_left_kl_cost_f32(self.ctx, _ptr(X), m, n, _ld(X), _ptr(Ut), _ld(Ut), _ptr(V), _ld(V),
+                                                        r, _ptr(O), _ld(O), _ptr(cost_out), self._stream()),
+                       "nnf_mu_left_kl_cost_f32")
+            return O
         if r > self.MU_FUSED_MAX_RANK and float(beta) != 2.0:
             num, den, dvec = self._mu_large_rank(X, Ut, V, beta, "left")
             return self.mu_apply(Ut, num, den, dvec, beta, out=out)

@@ -253,7 +253,12 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
     overlap = (cuda and update_rule == "hals" and 1 not in fixed_modes and isinstance(eng, _engine.Engine)
                and ws.cost_stream is not None
                and (_dist.world(group) == 1 or __import__("os").environ.get("NNF_SHARDED_OVERLAP") == "1"))
-    depth = PIPELINE_DEPTH + (1 if overlap else 0)
+    # MU, beta = 1: the left update of iteration i+1 forms U_i V_i entry by entry -- the KL cost of iteration i rides along
+    # (nnf_mu_left_kl_cost_f32) and the separate cost pass over X (a quarter of a KL iteration at config C) is only run after
+    # the last iteration.  Like the overlapped HALS cost, the host then looks at costs two iterations behind the device.
+    fused_mu = (cuda and update_rule == "mu" and float(beta) == 1.0 and 0 not in fixed_modes and _dist.world(group) == 1
+                and isinstance(eng, _engine.Engine) and Ut.shape[0] <= eng.MU_FUSED_MAX_RANK)
+    depth = PIPELINE_DEPTH + (1 if (overlap or fused_mu) else 0)
     assert ws.blocks.shape[0] > depth
     pending = []          # steps not yet handed to `retired`: dicts {it, slot, Ut, V, nstat, ev}
     result = (Ut, V)
@@ -266,8 +271,13 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
         with torch.cuda.stream(stream):
             if stream is not main:
                 stream.wait_event(main.record_event())       # factors, status words of `step`: all enqueued on main
-            _step_cost(ws.cost_eng if stream is not main else eng, X, step["Ut"], step["V"], update_rule, beta,
-                       sparsity_coefficients, block[16:17], group)
+            if fused_mu:
+                # the last step's cost from the SAME kernel as every other cost of the run (an update whose output is
+                # dropped): a run stopped early and a run of exactly that many iterations give bitwise equal costs
+                eng.mu_left(X, step["Ut"], step["V"], beta, cost_out=block[16:17])
+            else:
+                _step_cost(ws.cost_eng if stream is not main else eng, X, step["Ut"], step["V"], update_rule, beta,
+                           sparsity_coefficients, block[16:17], group)
             ws.host[step["slot"]].copy_(block, non_blocking=True)
             step["ev"] = stream.record_event()
 
@@ -316,16 +326,24 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
     while iteration < n_iter:
         ws.select(iteration % ws.blocks.shape[0])
         hooks = {}
+        if fused_mu and owed is not None:
+            hooks["mu_cost_out"] = ws.blocks[owed["slot"]][16:17]        # cost of the previous step, by-product of this left update
         if overlap and owed is not None:
             hooks["before_v_solve"] = lambda prev=owed: cost_of(prev, ws.cost_stream)
         if overlap and costed is not None:
             # the cost launched during the previous step must be out of the way before this step's U-side solve
             hooks["before_u_solve"] = lambda ev=costed["ev"]: main.wait_event(ev)
         Ut, V, nstat = _one_nmf_step_dev(eng, ws, X, rank, Ut, V, update_rule, beta, sparsity_coefficients,
-                                         fixed_modes, normalize, deterministic, group=group, skip_cost=overlap, **hooks)
+                                         fixed_modes, normalize, deterministic, group=group,
+                                         skip_cost=overlap or fused_mu, **hooks)
         step = dict(it=iteration, slot=ws.slot, Ut=Ut, V=V, nstat=nstat, ev=None, async_u=ws.last_step_async)
         ws.sync_next = False
-        if overlap:
+        if fused_mu:
+            if owed is not None:          # its cost has just been enqueued with this step's left update
+                ws.host[owed["slot"]].copy_(ws.blocks[owed["slot"]], non_blocking=True)
+                owed["ev"] = main.record_event()
+            owed = step
+        elif overlap:
             costed = owed
             owed = step
         elif cuda:
@@ -341,7 +359,7 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
                 if stop:
                     break
             if iteration == n_iter:
-                if overlap and not stop and owed is not None and owed["ev"] is None:
+                if (overlap or fused_mu) and not stop and owed is not None and owed["ev"] is None:
                     cost_of(owed, main)               # the last step has no V-side solve behind it to hide under
                 while pending and not stop:
                     retire()
@@ -427,7 +445,7 @@ def _step_cost(eng, X, Ut, V, update_rule, beta, sparsity_coefficients, out, gro
 
 
 def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
-                      deterministic, group=None, skip_cost=False, before_u_solve=None, before_v_solve=None):
+                      deterministic, group=None, skip_cost=False, before_u_solve=None, before_v_solve=None, mu_cost_out=None):
     """Device-resident step.  Ut_in (r x m) and V_in (r x n) are not modified.  Returns the new factors and the number
     of HALS solves run; the cost and the solves' status words are left in ws.block (read back by the caller).
     With `group` (torch.distributed process group) X / Ut are this rank's row block and V is replicated (dist.py).
@@ -481,7 +499,10 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                            ws.block[8 * nstat:8 * nstat + 8], safe=ws.guess_u if getattr(ws, "safe_solve", False) else None)
             nstat += 1
         else:
-            Ut = eng.mu_left(X, Ut_in, V, beta)         # nmf.py:422
+            if mu_cost_out is not None:                 # + beta_divergence(X, U_in V_in, 1): the previous iteration's cost
+                Ut = eng.mu_left(X, Ut_in, V, beta, cost_out=mu_cost_out)
+            else:
+                Ut = eng.mu_left(X, Ut_in, V, beta)     # nmf.py:422
 
     if 1 not in fixed_modes:
         if update_rule == "hals":

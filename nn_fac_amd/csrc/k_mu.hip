@@ -439,35 +439,12 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                         const float dd = ok ? (xb[t & 1][nt][reg] - accP[nt][reg]) : 0.f;
                         csum = fmaf(dd, dd, csum);
                     }
-
+                    if constexpr (BM == BM_KLC) {   // beta_divergence(X, UV, 1) of the factors this update starts from
+                        const float term = nnf_cost_term<NNF_COST_KL>(xb[t & 1][nt][reg], accP[nt][reg], 1.f);
+                        csum += ok ? term : 0.f;
+                    }
                     R1[nt][reg] = ok ? r1 : 0.f;
                     if constexpr (BM == BM_GEN) R2[nt][reg] = ok ? r2 : 0.f;
-                }
-            }
-            if constexpr (BM == BM_KLC) {   // beta_divergence(X, UV, 1) of the factors this update starts from
-                // u = (x - p)/p = R1 - 1 up to rounding, but formed from the difference (no cancellation); masked entries: 0
-                // (one row tile -- four entries per lane -- at a time: a whole group's u's would not fit the registers at r > 48)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    f32x4 uu;
-                    float umax = 0.f;
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const bool ok = ((16 * nt + ii) < rows) && (reg < colrem);
-                        uu[reg] = ok ? nnf_kl_rel(xb[t & 1][nt][reg], accP[nt][reg]) : 0.f;
-                        umax = fmaxf(umax, fabsf(uu[reg]));
-                    }
-                    if (__builtin_amdgcn_ballot_w64(!(umax < 0.25f)) == 0ull) {   // wave-uniform: logarithm-free form
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) csum += nnf_kl_term_fast(uu[reg], accP[nt][reg]);   // u = 0 -> 0
-                    } else {
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const bool ok = ((16 * nt + ii) < rows) && (reg < colrem);
-                            const float term = nnf_cost_term<NNF_COST_KL>(xb[t & 1][nt][reg], accP[nt][reg], 1.f);
-                            csum += ok ? term : 0.f;
-                        }
-                    }
                 }
             }
             // finish this group's residual sum HERE: left alone, LLVM sinks the whole dependent chain of a chunk (and the 48

@@ -786,36 +786,12 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
                 }
         } else
         if (rows == 32 && 64 * (int64_t)(blk + 1) <= n) {   // interior block (wave-uniform): no edge masks
-            bool fast = false;
-            if constexpr (OP == NNF_COST_KL) {   // every entry of the block within 25 % of the data: logarithm-free form
-                float umax = 0.f, u[2][4][4];
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
+                for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) {
-                            u[rt][reg][cc] = nnf_kl_rel(xb[rt][reg][cc], acc[rt][cc][reg]);
-                            umax = fmaxf(umax, fabsf(u[rt][reg][cc]));
-                        }
-                fast = __builtin_amdgcn_ballot_w64(!(umax < 0.25f)) == 0ull;
-                if (fast) {
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg)
-#pragma unroll
-                            for (int cc = 0; cc < 4; ++cc) loc += nnf_kl_term_fast(u[rt][reg][cc], acc[rt][cc][reg]);
-                }
-            }
-            if (!fast) {
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) loc += nnf_cost_term<OP>(xb[rt][reg][cc], acc[rt][cc][reg], beta);
-            }
+                    for (int cc = 0; cc < 4; ++cc) loc += nnf_cost_term<OP>(xb[rt][reg][cc], acc[rt][cc][reg], beta);
         } else {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)

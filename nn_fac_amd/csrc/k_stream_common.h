@@ -91,25 +91,6 @@ __device__ __forceinline__ float nnf_h(float t, float q) {
     return fabsf(t) < 0.25f ? series : direct;
 }
 
-// KL term on the fast path, for model entries within 25 % of the data (every entry of a wave's block, tested wave-uniformly
-// by the caller; anything else -- including x = 0 -- takes nnf_cost_term<NNF_COST_KL>):
-//   x log(x/p) - x + p = p g(u),  u = (x - p)/p,  g(u) = (1+u) log1p(u) - u = u^2 - (1+u) h(u),  h(u) = u - log1p(u).
-// With s = u/(2+u):  log1p(u) = 2 atanh(s)  and  u - 2s = u^2/(2+u) EXACTLY, so
-//   h(u) = u^2/(2+u) - 2 s^3 (1/3 + s^2/5 + s^4/7 + s^6/9 + s^8/11)       (|s| <= 1/7: the next term is < 1e-9 of the sum)
-// -- no logarithm, no cancellation beyond a factor two in g, one reciprocal; ~14 issue slots instead of ~30.
-__device__ __forceinline__ float nnf_kl_rel(float x, float p) { return (x - p) * __builtin_amdgcn_rcpf(p); }
-__device__ __forceinline__ float nnf_kl_term_fast(float u, float p) {
-    const float rc = __builtin_amdgcn_rcpf(2.f + u);
-    const float s = u * rc, s2 = s * s;
-    float poly = fmaf(s2, 1.f / 11.f, 1.f / 9.f);
-    poly = fmaf(s2, poly, 1.f / 7.f);
-    poly = fmaf(s2, poly, 1.f / 5.f);
-    poly = fmaf(s2, poly, 1.f / 3.f);
-    const float uu = u * u;
-    const float h = fmaf(-2.f * s * s2, poly, uu * rc);
-    return p * fmaf(-(1.f + u), h, uu);
-}
-
 template <int OP>
 __device__ __forceinline__ float nnf_cost_term(float x, float p, float beta) {
     if constexpr (OP == NNF_COST_FROB) {

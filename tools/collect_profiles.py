@@ -1,27 +1,59 @@
-"""Copy the summaries written by tools/bench_profile.sh (under gpurun_out/) into profiles/ and recompute the HBM traffic
-of the dominant kernel from the PMC passes (FETCH_SIZE is doubled: the gfx950 correction of MI355X_MICROARCH.md)."""
-import csv, glob, json, os, shutil, sys, collections
+"""Copy the summaries written by tools/bench_profile.sh (gpurun_out/prof_<CONFIG>/) into profiles/ and recompute the HBM
+traffic of each configuration's main kernels from the PMC passes (FETCH_SIZE doubled: the gfx950 correction of
+MI355X_MICROARCH.md; WRITE_SIZE as reported; both in KiB).
+
+    python tools/collect_profiles.py r02 B C D
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-shutil.copy(os.path.join(G, "prof_stats_summary.txt"), os.path.join(P, f"{tag}_bench_kernel_stats.txt"))
-ks = sorted(glob.glob(os.path.join(G, "prof_stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
-if ks:
-    shutil.copy(ks[-1], os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
-shutil.copy(os.path.join(G, "prof_pmc_summary.txt"), os.path.join(P, f"{tag}_bench_pmc_fetch_write_sq.txt"))
-shutil.copy(os.path.join(G, "bench.json"), os.path.join(P, f"{tag}_bench_line.json"))
-acc = collections.defaultdict(list)
-for d in ("prof_fetch", "prof_write"):
-    for f in glob.glob(os.path.join(G, d, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "nnf_xty_kernel" in r["Kernel_Name"]:
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-fetch = sum(acc["FETCH_SIZE"]) / len(acc["FETCH_SIZE"])
-write = sum(acc["WRITE_SIZE"]) / len(acc["WRITE_SIZE"])
-out = {"kernel": "nnf_xty_kernel<3,2,true>", "fetch_size_kib_raw": fetch, "write_size_kib": write,
-       "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
-       "note": "separate --pmc passes of `python bench.py --steps 3 --warmup 1 --no-cpu` (tools/bench_profile.sh); "
-               f"FETCH_SIZE doubled per the gfx950 correction; mean over {len(acc['FETCH_SIZE'])} launches",
-       "source": f"profiles/{tag}_bench_pmc_fetch_write_sq.txt"}
-json.dump(out, open(os.path.join(P, f"{tag}_xty_traffic.json"), "w"), indent=1)
-print(out)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+configs = sys.argv[2:] or ["B", "C", "D"]
+MAIN = {"B": ["nnf_xty_kernel", "nnf_xht_kernel", "nnf_cost_kernel", "nnf_hals_kernel", "nnf_hals_quad_kernel"],
+        "C": ["nnf_mu_left_kernel", "nnf_mu_right_kernel", "nnf_cost_kernel"],
+        "D": ["nnf_mu_left_kernel", "nnf_mttkrp_rows_kernel", "nnf_xht_kernel", "nnf_hals_quad_kernel"]}
+for cfg in configs:
+    O = os.path.join(G, f"prof_{cfg}")
+    if not os.path.isdir(O):
+        print("missing", O)
+        continue
+    shutil.copy(os.path.join(O, "stats_summary.txt"), os.path.join(P, f"{tag}_{cfg}_kernel_stats.txt"))
+    ks = sorted(glob.glob(os.path.join(O, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    if ks:
+        shutil.copy(ks[-1], os.path.join(P, f"{tag}_{cfg}_kernel_stats.csv"))
+    shutil.copy(os.path.join(O, "pmc_summary.txt"), os.path.join(P, f"{tag}_{cfg}_pmc_fetch_write_sq.txt"))
+    line = [ln for ln in open(os.path.join(O, "bench.json")) if ln.startswith("{")]
+    if line:
+        with open(os.path.join(P, f"{tag}_{cfg}_bench_line.json"), "w") as fh:
+            fh.write(line[-1])
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in ("fetch", "write", "sq"):
+        for f in glob.glob(os.path.join(O, d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                for k in MAIN.get(cfg, []):
+                    if k in r["Kernel_Name"]:
+                        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {}
+    for k, cs in acc.items():
+        if not cs.get("FETCH_SIZE") or not cs.get("WRITE_SIZE"):
+            continue
+        fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
+        write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+        e = {"fetch_size_kib_raw": fetch, "write_size_kib": write, "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
+             "launches": len(cs["FETCH_SIZE"])}
+        if cs.get("SQ_VALU_MFMA_BUSY_CYCLES") and cs.get("SQ_BUSY_CYCLES"):
+            e["mfma_busy_frac"] = (sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(cs["SQ_VALU_MFMA_BUSY_CYCLES"])) / \
+                (4 * sum(cs["SQ_BUSY_CYCLES"]) / len(cs["SQ_BUSY_CYCLES"]))
+        out[k] = e
+    out["_note"] = ("separate --pmc passes of `python3 bench.py --config %s --steps 3 --warmup 1 --no-cpu --no-fixed --no-extra "
+                    "--no-kernels` (tools/bench_profile.sh); FETCH_SIZE doubled per the gfx950 correction; means over the "
+                    "launches of each kernel" % cfg)
+    json.dump(out, open(os.path.join(P, f"{tag}_{cfg}_traffic.json"), "w"), indent=1)
+    print(cfg, {k: v.get("hbm_bytes_per_launch") for k, v in out.items() if isinstance(v, dict)})

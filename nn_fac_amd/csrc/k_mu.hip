@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) void nnf_small_gemm_rect_kernel(const float* _
 extern "C" int nnf_small_gemm_f32(nnf_ctx* ctx, const float* A, int64_t lda, int p, int q, const float* B, int64_t ldb,
                                   int64_t cols, float* out, int64_t ldo, void* stream) {
     if (!ctx || !A || !B || !out || p < 1 || q < 1 || cols < 1 || lda < q || ldb < cols || ldo < cols) return NNF_ERR_ARG;
-    if (p > NNF_MAX_RANK || q > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    if ((int64_t)p * q > 16384) return NNF_ERR_UNSUPPORTED;   // A is staged whole in LDS (64 KB)
     int64_t grid = nnf_cdiv(cols, 256);
     if (grid > 4096) grid = 4096;
     const size_t shm = (size_t)p * q * 4;

@@ -1,5 +1,7 @@
 """NTD (nonnegative Tucker decomposition) driver on the MI355X engine -- drop-in for nn_fac/ntd.py
-(ntd :27-246, compute_ntd :248-433, one_ntd_step :436-645, one_ntd_step_mu :658-698) for 3-way tensors.
+(ntd :27-246, compute_ntd :248-433, one_ntd_step :436-645, one_ntd_step_mu :658-698), tensors of any order >= 3 (every mode
+product runs through the 3-way kernel on a VIEW (left, I_n, right) of the tensor; the core update merges the trailing core
+modes into one -- their Gram is the Kronecker product -- so that nnf_ntd_core_pg_f32's three-mode loop serves it).
 
 HALS step, per updated mode n (factors kept transposed, r_n x I_n; statement -> C ABI):
 
@@ -77,19 +79,21 @@ class _NtdState:
     """Device-resident tensor, its squared norm, (MU only) the materialised unfoldings, and the per-step status block."""
 
     def __init__(self, eng, T):
-        if T.dim() != 3:
-            raise NotImplementedError("the MI355X engine accelerates 3-way tensors (nnf_ttm3_f32)")
+        if T.dim() < 3:
+            raise NotImplementedError("NTD needs a tensor of order >= 3")
         self.eng = eng
         self.T = T.contiguous()
-        I, J, K = self.T.shape
-        self.t0 = self.T.view(I, J * K)
+        self.nway = self.T.dim()
+        self.t0 = self.T.view(self.T.shape[0], -1)
         self.norm2 = eng.dot(self.t0, self.t0)          # float64 device scalar, ||T||^2 (read once by the driver)
         self.norm2_host = None
         self._unf_t = {}
-        # 3 HALS status blocks (8 doubles each) + 6 doubles of the core update + the cost; two of them with pinned host
-        # mirrors: compute_ntd enqueues iteration i+1 before it looks at the block of iteration i
-        self.blocks = torch.zeros((2, 8 * 3 + 8), dtype=torch.float64, device=T.device)
-        self.host = torch.zeros((2, 8 * 3 + 8), dtype=torch.float64)
+        # one HALS status block (8 doubles) per mode, then 6 doubles of the core update, then the cost; two of them with
+        # pinned host mirrors: compute_ntd enqueues iteration i+1 before it looks at the block of iteration i
+        self.pg_at = 8 * self.nway
+        self.cost_at = self.pg_at + 6
+        self.blocks = torch.zeros((2, self.cost_at + 2), dtype=torch.float64, device=T.device)
+        self.host = torch.zeros((2, self.cost_at + 2), dtype=torch.float64)
         if T.is_cuda:
             self.host = self.host.pin_memory()
         self.select(0)
@@ -130,49 +134,84 @@ def _core_mode_dots(core, mats, skip=None):
     return out
 
 
+def _ttm(eng, X, Ft_i, pos):
+    """Mode product of a contiguous tensor X (any order) along axis `pos` with a transposed factor Ft_i (r x d): the 3-way
+    kernel nnf_ttm3_f32 on the view (left, d, right).  First axis -> the W^T X kernel, result in place; last axis -> the
+    X H^T kernel, the new axis comes out FIRST; a middle axis -> the VALU slab kernel, in place.  Returns (tensor, new_pos)."""
+    sh = list(X.shape)
+    left, right = 1, 1
+    for d in sh[:pos]:
+        left *= int(d)
+    for d in sh[pos + 1:]:
+        right *= int(d)
+    r = Ft_i.shape[0]
+    if left == 1:                       # first axis (or only extents of 1 before it): the result stays where it is
+        out = eng.ttm3(X.reshape(sh[pos], right, 1), Ft_i, 0)                   # (r, right, 1)
+        return out.view(sh[:pos] + [r] + sh[pos + 1:]), pos
+    if right == 1:                      # last axis (or only extents of 1 behind it): the new axis comes out first
+        out = eng.ttm3(X.reshape(1, left, sh[pos]), Ft_i, 2)                    # (r, 1, left)
+        return out.view([r] + sh[:pos] + sh[pos + 1:]), 0
+    out = eng.ttm3(X.reshape(left, sh[pos], right), Ft_i, 1)                    # (left, r, right)
+    return out.view(sh[:pos] + [r] + sh[pos + 1:]), pos
+
+
+def _contract_others(eng, temp, axes, core, n):
+    """(<temp, core> over the modes != n)^T (ntd.py:555-556): temp carries the rank extents of the other modes in the order
+    `axes[:-1]` and I_n last; r_n x I_n = (core with mode n first, the others in that order) @ (temp as P x I_n)."""
+    others = axes[:-1]
+    A = core.permute([n] + others).reshape(core.shape[n], -1).contiguous()
+    B = temp.reshape(-1, temp.shape[-1])
+    if A.shape[0] * A.shape[1] <= 16384 and hasattr(eng, "small_gemm"):
+        return eng.small_gemm(A, B)
+    return (A @ B).contiguous()
+
+
 def _one_ntd_step_dev(st, core_in, Ft_in, sparsity_coefficients, fixed_modes, normalize, mode_core_norm, alpha, delta):
     """ntd.py:514-645 on the device.  Ft: transposed factors (r_n x I_n).  Returns (core, Ft, number of HALS solves);
-    the cost is left in st.block[30] and the status words in st.block[0:24] / [24:30]."""
+    the cost is left in st.block[st.cost_at], the status words of the solves in st.block[0 : 8 N], of the core update behind."""
     eng = st.eng
+    N = st.nway
     for fixed_value in fixed_modes:
         sparsity_coefficients[fixed_value] = None
     core = core_in.clone()
     Ft = list(Ft_in)
     dev = st.T.device
-    modes_list = [m for m in range(3) if m not in fixed_modes]
+    modes_list = [m for m in range(N) if m not in fixed_modes]
     if not modes_list:
         raise UnboundLocalError("one_ntd_step needs at least one non-fixed factor mode (ntd.py:581 reuses its 'temp')")
     nstat = 0
-    W0 = None           # T x_0 F_0^T, shared by the mode-1 and mode-2 updates
-    grams = [None, None, None]
+    W0 = None           # T x_0 F_0^T, shared by the updates of every mode but the first
+    grams = [None] * N
     deterministic = math.isinf(alpha)
     for mode in modes_list:
         if not deterministic:
             torch.cuda.synchronize(dev)
             t0 = time.time()
-        for i in range(3):
+        for i in range(N):
             if i != mode:
                 grams[i] = eng.gram(Ft[i])                                    # elemprod (ntd.py:534-537)
-        others = [i for i in range(3) if i != mode]
-        tmp = _core_mode_dots(core, [grams[i] if i != mode else None for i in range(3)], skip=mode)
+        others = [i for i in range(N) if i != mode]
+        tmp = _core_mode_dots(core, [grams[i] if i != mode else None for i in range(N)], skip=mode)
         UtU = torch.tensordot(tmp, core, dims=(others, others)).contiguous()  # r_n x r_n (ntd.py:544)
-        # temp = T x_{i != mode} F_i^T (ntd.py:550), arranged so that every product contracts a first or a last axis
+        # temp = T x_{i != mode} F_i^T (ntd.py:550).  The pass over T contracts its first axis (W^T X kernel; shared by all
+        # modes but the first) or, for mode 0, its last one (X H^T kernel); what follows works on a tensor I/r times smaller:
+        # the modes above `mode` are last when their turn comes (taken in decreasing order, each result moves to the front),
+        # the ones below sit in the middle (slab kernel).  `mode` itself always ends up last.
         if mode == 0:
-            w = eng.ttm3(st.T, Ft[2], 2)                                      # (c, I, J)
-            c_, I_, J_ = w.shape
-            w = eng.xht(w.view(c_ * I_, J_), Ft[1]).view(-1, c_, I_)          # (b, c, I)
-            temp = w.permute(2, 0, 1)                                         # view as (I, b, c)
+            temp, _ = _ttm(eng, st.T, Ft[N - 1], N - 1)
+            axes = [N - 1] + list(range(N - 1))
+            rest = list(range(N - 2, 0, -1))
         else:
             if W0 is None:
-                W0 = eng.ttm3(st.T, Ft[0], 0)                                 # (a, J, K)
-            a_, J_, K_ = W0.shape
-            if mode == 1:
-                w = eng.xht(W0.view(a_ * J_, K_), Ft[2]).view(-1, a_, J_)     # (c, a, J)
-                temp = w.permute(1, 2, 0)                                     # (a, J, c)
-            else:
-                temp = torch.matmul(Ft[1], W0)                                # (a, b, K): core-width batched GEMM
-        MtU = torch.tensordot(temp, core, dims=(others, others))              # I_n x r_n (ntd.py:555)
-        UtM = MtU.t().contiguous()
+                W0, _ = _ttm(eng, st.T, Ft[0], 0)
+            temp, axes = W0, list(range(N))
+            rest = [i for i in range(N - 1, 0, -1) if i != mode]
+        for i in rest:
+            pos = axes.index(i)
+            temp, newpos = _ttm(eng, temp, Ft[i], pos)
+            if newpos != pos:                                                 # a last axis came out first
+                axes = [i] + axes[:pos] + axes[pos + 1:]
+        UtM = _contract_others(eng, temp, axes, core, mode)                   # (ntd.py:555-556)
         new = Ft[mode].clone()
         budget = 100
         if not deterministic:
@@ -191,19 +230,37 @@ def _one_ntd_step_dev(st, core_in, Ft_in, sparsity_coefficients, fixed_modes, no
         if mode == 0:
             W0 = None
     last = modes_list[-1]
-    # all_MtX = temp x_last F_last^T with the NEW factor; all_MtM = elemprod with the last Gram refreshed (ntd.py:581-583)
-    all_MtX = torch.movedim(torch.tensordot(Ft[last], temp, dims=([1], [last])), 0, last).contiguous()
+    # all_MtX = temp x_last F_last^T with the NEW factor; all_MtM = elemprod with the last Gram refreshed (ntd.py:581-583):
+    # `last` is temp's last axis, its product comes out first -> back to the core's mode order (core-sized)
+    mtx, _ = _ttm(eng, temp.contiguous(), Ft[last], len(axes) - 1)
+    order = [last] + axes[:-1]
+    all_MtX = mtx.permute([order.index(i) for i in range(N)]).contiguous()
     grams[last] = eng.gram(Ft[last])
-    for i in range(3):
-        if grams[i] is None:            # a fixed mode that was never "other": cannot happen with >= 1 free mode of 3
+    for i in range(N):
+        if grams[i] is None:            # a fixed mode that was never "other": cannot happen with >= 1 free mode
             grams[i] = eng.gram(Ft[i])
     sparse = 0 if sparsity_coefficients[-1] is None else sparsity_coefficients[-1]
-    pg = st.block[24:30]
-    eng.ntd_core_pg(core, all_MtX, grams, sparse, delta, 300, st.norm_sq(), status=pg)
-    cost = st.block[30:31]
+    pg = st.block[st.pg_at:st.pg_at + 6]
+    if N == 3:
+        eng.ntd_core_pg(core, all_MtX, grams, sparse, delta, 300, st.norm_sq(), status=pg)
+    else:
+        # the projected-gradient kernel loops over three modes: the trailing core modes are merged into one, whose Gram is
+        # the Kronecker product of theirs (core x_2 M_2 x_3 M_3 ... = merged core x_2 (M_2 (x) M_3 ...), row-major merge;
+        # sigma_max of a Kronecker product is the product of the sigma_max: same step, ntd.py:588-596)
+        tail = 1
+        for d in core.shape[2:]:
+            tail *= int(d)
+        if tail > 128:
+            raise NotImplementedError("NTD of order > 3: the product of the core's trailing extents must be <= 128")
+        Mk = grams[2]
+        for g in grams[3:]:
+            Mk = torch.kron(Mk.contiguous(), g.contiguous())
+        c3 = core.view(core.shape[0], core.shape[1], tail)
+        eng.ntd_core_pg(c3, all_MtX.view(c3.shape), [grams[0], grams[1], Mk], sparse, delta, 300, st.norm_sq(), status=pg)
+    cost = st.block[st.cost_at:st.cost_at + 1]
     if normalize[-1]:
         core = _normalize_core(core, mode_core_norm)
-    # ||T - core x_0 F_0 x_1 F_1 x_2 F_2||^2.  The reference evaluates it in the Gram form ||T||^2 - 2<MtX, core> + <MtM core,
+    # ||T - core x_0 F_0 x_1 F_1 ...||^2.  The reference evaluates it in the Gram form ||T||^2 - 2<MtX, core> + <MtM core,
     # core> (ntd.py:635-639) in fp64; with fp32 contractions that form is good to ~1e-7 ||T||^2, which is the size of the cost
     # itself for a near-exact fit (tools/stress_tensor.py: 1e-2 ... 2e-1 relative error on normalised costs of 1e-6).  One
     # streaming pass over T against the mode-0 matrix form (the cost kernel, product never materialised) is exact to ~1e-6
@@ -212,9 +269,9 @@ def _one_ntd_step_dev(st, core_in, Ft_in, sparsity_coefficients, fixed_modes, no
     sparsity_error = None
     for index, sp in enumerate(sparsity_coefficients):
         if sp:
-            if index < 3:      # np.linalg.norm(factor, ord=1): max column abs-sum = max row abs-sum of the transposed factor
+            if index < N:      # np.linalg.norm(factor, ord=1): max column abs-sum = max row abs-sum of the transposed factor
                 term = 2 * sp * Ft[index].abs().sum(dim=1).max().double()
-            elif index == 3:
+            elif index == N:
                 term = 2 * sp * core.abs().sum().double()
             else:
                 raise NotImplementedError("TODEBUG: Too many sparsity coefficients, should have been raised before.")
@@ -226,29 +283,41 @@ def _one_ntd_step_dev(st, core_in, Ft_in, sparsity_coefficients, fixed_modes, no
 
 
 def _core_expand_mode0(core, Ft):
-    """unfold(core x_1 F_1 x_2 F_2, 0): the r_0 x (J*K) right operand of the mode-0 matrix problem (core-width GEMMs)."""
-    w = torch.tensordot(core, Ft[2], dims=([2], [0]))                        # (a, b, K)
-    w = torch.einsum('abk,bj->ajk', w, Ft[1])                                 # (a, J, K)
+    """unfold(core x_1 F_1 x_2 F_2 ..., 0): the r_0 x prod(I_1..) right operand of the mode-0 matrix problem (core-width
+    GEMMs; the result is r_0 / I_0 of the tensor's size)."""
+    w = core
+    for i in range(core.dim() - 1, 0, -1):
+        w = torch.movedim(torch.tensordot(w, Ft[i], dims=([i], [0])), -1, i)
     return w.reshape(w.shape[0], -1).contiguous()
 
 
 def _mu_tensorial_dev(st, core, Ft, beta):
     """mu.py:138-159.  num/den = (L2 | L1) x_i F_i^T: the mode-0 product is the right-update accumulation of the matrix
-    problem T_(0) ~ F_0 V0 (one fused pass over T), the other two are core-width contractions."""
+    problem T_(0) ~ F_0 V0 (one fused pass over T), the others are mode products of an r_0 x I_1 x ... intermediate."""
     eng = st.eng
+    N = st.nway
     if beta < 0:
         raise err.InvalidArgumentValue("Invalid value for beta: negative one.") from None
     V0 = _core_expand_mode0(core, Ft)
     num, den, dvec = eng.mu_right_accum(st.t0, Ft[0], V0, beta)
-    J, K = st.T.shape[1], st.T.shape[2]
+    dims = [int(d) for d in st.T.shape[1:]]
 
-    def down(x):   # (a, J*K) -> x_1 F_1^T x_2 F_2^T -> (a, b, c)
-        w = torch.tensordot(x.view(-1, J, K), Ft[2], dims=([2], [1]))         # (a, J, c)
-        return torch.einsum('ajc,bj->abc', w, Ft[1])
+    def down(x):   # (r_0, I_1 * ... ) -> x_i F_i^T for every i >= 1 -> the core's shape
+        w, axes = x.view([x.shape[0]] + dims), list(range(N))
+        for i in range(N - 1, 0, -1):
+            pos = axes.index(i)
+            w, newpos = _ttm(eng, w.contiguous(), Ft[i], pos)
+            if newpos != pos:
+                axes = [i] + axes[:pos] + axes[pos + 1:]
+        return w.permute([axes.index(i) for i in range(N)]).contiguous()
     num3 = down(num)
     if dvec is not None:   # beta = 1: L1 = ones -> outer product of the factors' column sums
-        s1, s2 = Ft[1].sum(dim=1).double(), Ft[2].sum(dim=1).double()
-        den3 = (dvec.view(-1, 1, 1) * s1.view(1, -1, 1) * s2.view(1, 1, -1)).float()
+        den3 = dvec.view([-1] + [1] * (N - 1))
+        for i in range(1, N):
+            shape = [1] * N
+            shape[i] = -1
+            den3 = den3 * Ft[i].sum(dim=1).double().view(shape)
+        den3 = den3.float()
     else:
         den3 = down(den)
     from .utils.beta_divergence import gamma_beta
@@ -260,13 +329,14 @@ def _mu_tensorial_dev(st, core, Ft, beta):
 
 
 def _one_ntd_step_mu_dev(st, core_in, Ft_in, beta, fixed_modes, normalize, mode_core_norm):
-    """ntd.py:664-698 on the device; the (un-normalised, ntd.py:696) cost is left in st.block[30]."""
+    """ntd.py:664-698 on the device; the (un-normalised, ntd.py:696) cost is left in st.block[st.cost_at]."""
     eng = st.eng
+    N = st.nway
     core = core_in.clone()
     Ft = list(Ft_in)
-    for mode in [m for m in range(3) if m not in fixed_modes]:
+    for mode in [m for m in range(N) if m not in fixed_modes]:
         # V = unfold(core x_{i != mode} F_i, mode): r_mode x prod(other dims), core-width GEMMs
-        mats = [Ft[i].t() if i != mode else None for i in range(3)]
+        mats = [Ft[i].t() if i != mode else None for i in range(N)]
         V = torch.movedim(_core_mode_dots(core, mats, skip=mode), mode, 0)
         V = V.reshape(V.shape[0], -1).contiguous()
         # mu_betadivmin(F, V, unfold(T, mode)) (ntd.py:672) on the TRANSPOSED problem unfold^T ~ V^T F^T: the unfolding is
@@ -275,7 +345,7 @@ def _one_ntd_step_mu_dev(st, core_in, Ft_in, beta, fixed_modes, normalize, mode_
     core = _mu_tensorial_dev(st, core, Ft, beta)
     if normalize[-1]:
         core = _normalize_core(core, mode_core_norm)
-    eng.betadiv(st.t0, Ft[0], _core_expand_mode0(core, Ft), beta, out=st.block[30:31])
+    eng.betadiv(st.t0, Ft[0], _core_expand_mode0(core, Ft), beta, out=st.block[st.cost_at:st.cost_at + 1])
     return core, Ft
 
 
@@ -320,14 +390,14 @@ def compute_ntd(tensor_in, ranks, core_in, factors_in, n_iter_max=100, tol=1e-6,
         if ev is not None:
             ev.synchronize()
         host = st.host[slot]
-        cost = float(host[30])
+        cost = float(host[st.cost_at])
         for i in range(nstat):
             if int(host[8 * i + _engine.ST_ERR]) != 0:
                 raise err.EngineError("hals grid barrier timed out; result invalid")
         if sweep_log is not None:
             sweep_log.extend(int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(nstat))
         if pg_log is not None and update_rule == "hals":
-            pg_log.append(int(host[24]))
+            pg_log.append(int(host[st.pg_at]))
         result = (core_i, Ft_i)
         toc.append(time.time() - tic)
         cost_fct_vals.append(cost)
@@ -389,7 +459,7 @@ def one_ntd_step(tensor, ranks, in_core, in_factors, norm_tensor,
     for i in range(nstat):
         if int(host[8 * i + _engine.ST_ERR]) != 0:
             raise err.EngineError("hals grid barrier timed out; result invalid")
-    return like_input(core, in_core), [like_input(f.t(), in_factors[i]) for i, f in enumerate(Ft)], float(host[30])
+    return like_input(core, in_core), [like_input(f.t(), in_factors[i]) for i, f in enumerate(Ft)], float(host[st.cost_at])
 
 
 def one_ntd_step_mu(tensor, ranks, in_core, in_factors, beta, norm_tensor,
@@ -402,4 +472,4 @@ def one_ntd_step_mu(tensor, ranks, in_core, in_factors, beta, norm_tensor,
     Ft = [to_dev_t(f, dev) for f in in_factors]
     core, Ft = _one_ntd_step_mu_dev(st, core, Ft, beta, fixed_modes, normalize, mode_core_norm)
     return (like_input(core, in_core), [like_input(f.t(), in_factors[i]) for i, f in enumerate(Ft)],
-            float(st.block[30]))
+            float(st.block[st.cost_at]))

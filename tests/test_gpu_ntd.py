@@ -215,3 +215,33 @@ def test_ntd_early_stop_drops_the_speculative_iteration(built_lib, rule, beta):
     assert np.array_equal(Cs, Ck)
     for a, b in zip(Fs, Fk):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape,ranks", [((9, 8, 7, 6), (3, 2, 3, 2)), ((6, 5, 4, 5, 4), (2, 2, 2, 3, 2)), ((20, 6, 11, 9), (4, 3, 5, 2))])
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 1), ("mu", 2)])
+def test_ntd_order_n(built_lib, shape, ranks, rule, beta):
+    """Tensors of order 4 and 5 (the reference loops over arbitrary modes, ntd.py:534-557): every mode product is the 3-way
+    kernel on a view (left, I_n, right), the core update merges the trailing core modes (Kronecker Gram) -- core, factors,
+    costs, sweep and projected-gradient counts vs the oracle."""
+    from nn_fac_amd.ntd import compute_ntd
+    rng = np.random.RandomState(sum(shape) + sum(ranks))
+    N = len(shape)
+    G = rng.rand(*ranks)
+    Fs = [rng.rand(s, q) for s, q in zip(shape, ranks)]
+    T = orc.multi_mode_dot(G, Fs) + 1e-2 * rng.rand(*shape)
+    T = T.astype(np.float32)
+    C0 = (rng.rand(*ranks) + 0.05).astype(np.float32)
+    F0 = [(rng.rand(s, q) + 0.05).astype(np.float32) for s, q in zip(shape, ranks)]
+    kw = dict(n_iter_max=3, tol=0, update_rule=rule, beta=beta, return_costs=True, deterministic=True,
+              sparsity_coefficients=[None] * (N + 1), normalize=[False] * (N + 1))
+    sw, pg, swo, pgo = [], [], [], []
+    core, F, costs, _ = compute_ntd(T, list(ranks), C0, F0, sweep_log=sw, pg_log=pg, **kw)
+    co, Fo, cso, _ = orc.compute_ntd(T.astype(np.float64), list(ranks), C0.astype(np.float64), [f.astype(np.float64) for f in F0],
+                                     sweeps=swo, pg_iters=pgo, **kw)
+    tol = 5e-3 if rule == "hals" else 1e-4
+    assert core.shape == co.shape and rel(core, co) < tol, rel(core, co)
+    for i in range(N):
+        assert rel(F[i], Fo[i]) < tol, (i, rel(F[i], Fo[i]))
+    np.testing.assert_allclose(costs, cso, rtol=5e-3 if rule == "hals" else 2e-4)
+    if rule == "hals":
+        assert sw == swo and pg == pgo, (sw, swo, pg, pgo)

@@ -123,6 +123,13 @@ int nnf_hals_solve_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float*
                        int r, int64_t ncols, int max_sweeps, double delta, float sparsity, unsigned flags,
                        double* status_f64, void* stream);
 
+/* hals_nnls_acc as one_ntf_step calls it (ntf.py:442-456): Gram = UtU_a .* UtU_b (the `cross` of two factor Grams; UtU_b may be
+ * NULL), start values V_in, result in V_out (may alias V_in) -- nnf_hals_solve_f32 without the Hadamard launch and the copy
+ * in front of it.  max_sweeps <= 1000. */
+int nnf_hals_solve_cross_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU_a, const float* UtU_b, int64_t ldg,
+                             const float* V_in, int64_t ldvi, float* V_out, int64_t ldvo, int r, int64_t ncols, int max_sweeps,
+                             double delta, float sparsity, unsigned flags, double* status_f64, void* stream);
+
 /* max_sweeps above 1000 (one launch tags at most 1000 sweeps; nnf_hals_solve_f32 answers NNF_ERR_UNSUPPORTED): chain
  * nnf_hals_solve_f32(..., 1000, ...) with nnf_hals_solve_continue_f32(..., sweeps_done = 1000, 2000, ..., max_sweeps = the
  * next slice <= 1000, ...) on the same stream and status block.  A continuation whose predecessor already ended the solve

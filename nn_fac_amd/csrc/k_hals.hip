@@ -162,6 +162,12 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
     }
 }
 
+__global__ void nnf_hals_hadamard_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t ld, int r,
+                                        float* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < r * r) out[e] = A[(int64_t)(e / r) * ld + (e % r)] * B[(int64_t)(e / r) * ld + (e % r)];
+}
+
 // out[s] = sum_b partials[s][b]  (index order)
 __global__ __launch_bounds__(256) void nnf_hals_sum_sweeps_kernel(const double* __restrict__ partials, int nblocks,
                                                                   double* __restrict__ out) {
@@ -185,7 +191,7 @@ template <int MODE>
 static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V, int64_t ldv,
                       int r, int64_t ncols, int nsweeps, double delta, float sparsity, unsigned flags, double* status,
                       double* nodelta_out, hipStream_t st, float* snapshots = nullptr, int64_t snap_stride = 0,
-                      int sweep0 = 0) {
+                      int sweep0 = 0, const float* UtU2 = nullptr, const float* Vsrc = nullptr, int64_t ldvs = 0) {
     if (!ctx || !UtM || !UtU || !V || r < 1 || ncols < 1 || ldm < ncols || ldv < ncols || ldg < r || nsweeps < 0)
         return NNF_ERR_ARG;
     if (MODE == 0 && !status) return NNF_ERR_ARG;
@@ -219,6 +225,27 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     if (MODE == 1) sweep_partials = (double*)cur.take((size_t)(nsweeps > 0 ? nsweeps : 1) * max_blocks * 8);
     if (!Gp || !dinv || !counter || !slots || !sslots || (MODE == 1 && !sweep_partials))
         return NNF_ERR_WORKSPACE;
+    if (Vsrc == nullptr || Vsrc == V) { Vsrc = V; ldvs = ldv; }
+    if (!quad && (UtU2 != nullptr || Vsrc != V)) {
+        // the Hadamard Gram and the separate start values are native to the few-column (quad) kernel -- the shape they were
+        // made for (NTF factors); the other layouts get them from two small element-wise launches
+        if (UtU2 != nullptr) {
+            float* Gh = (float*)cur.take((size_t)r * r * 4);
+            if (!Gh) return NNF_ERR_WORKSPACE;
+            hipLaunchKernelGGL(nnf_hals_hadamard_kernel, dim3((r * r + 255) / 256), dim3(256), 0, st, UtU, UtU2, ldg, r, Gh);
+            NNF_CHECK_LAUNCH();
+            UtU = Gh;
+            ldg = r;
+            UtU2 = nullptr;
+        }
+        if (Vsrc != V) {
+            if (hipMemcpy2DAsync(V, (size_t)ldv * 4, Vsrc, (size_t)ldvs * 4, (size_t)ncols * 4, (size_t)r, hipMemcpyDeviceToDevice,
+                                 st) != hipSuccess)
+                return NNF_ERR_LAUNCH;
+            Vsrc = V;
+            ldvs = ldv;
+        }
+    }
     if (!quad) {
         hipLaunchKernelGGL(nnf_hals_prep_kernel, dim3(RP), dim3(128), 0, st, UtU, ldg, r, RP, Gp, dinv,
                            want_gs ? Gp + gs_off : (float*)nullptr, counter,
@@ -237,8 +264,8 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
         if ((((int64_t)(r - 1) * ldv + ncols) * 4) >= (int64_t)0x7fff0000 || (((int64_t)(r - 1) * ldm + ncols) * 4) >= (int64_t)0x7fff0000)
             return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
         hals_args a{UtM, ldm, nullptr, nullptr, nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status, sweep_partials,
-                    snapshots, snap_stride, sweep0};
-        rc = nnf_hals_quad_run(ctx, UtU, ldg, Gp, counter, a, &nblocks, st);
+                    snapshots, snap_stride, sweep0, Vsrc, ldvs};
+        rc = nnf_hals_quad_run(ctx, UtU, UtU2, ldg, Gp, counter, a, &nblocks, st);
         if (rc != NNF_OK) return rc;
         if (nsweeps == 0) return NNF_OK;
     } else if (generic) {
@@ -262,7 +289,7 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
         if ((((int64_t)(r - 1) * ldv + ncols) * 4) >= (int64_t)0x7fff0000 || (((int64_t)(r - 1) * ldm + ncols) * 4) >= (int64_t)0x7fff0000)
             return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
         hals_args a{UtM, ldm, Gp, dinv, want_gs ? Gp + gs_off : nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status,
-                    sweep_partials, snapshots, snap_stride, sweep0};
+                    sweep_partials, snapshots, snap_stride, sweep0, V, ldv};
         nnf_probe(ctx, NNF_PROBE_HALS, 0, st);
         if (RP <= 48) rc = nnf_hals_fast_part0(ctx, RP, a, max_blocks, &nblocks, st);
         else if (RP <= 64) rc = nnf_hals_fast_part1(ctx, RP, a, max_blocks, &nblocks, st);
@@ -371,4 +398,19 @@ extern "C" int nnf_hals_stop_restore_f32(nnf_ctx* ctx, const double* sums_f64, i
                        budget, delta, V, ldv, r, ncols, snapshots, snap_stride, status_f64);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
+}
+
+// hals_nnls_acc as one_ntf_step calls it (ntf.py:442-456): the Gram is the Hadamard product of two factor Grams
+// (`cross`), the start values are the current factor and the result is a NEW factor.  Same solve as nnf_hals_solve_f32
+// with UtU := UtU_a .* UtU_b (UtU_b may be NULL) and V_out := V_in before the first sweep -- without the Hadamard launch and
+// the copy in front of it (the few-column kernel forms the product while it stages the Gram and reads its start values
+// from V_in; the other layouts do both with small launches of their own).  V_in may equal V_out.
+extern "C" int nnf_hals_solve_cross_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU_a, const float* UtU_b,
+                                        int64_t ldg, const float* V_in, int64_t ldvi, float* V_out, int64_t ldvo, int r,
+                                        int64_t ncols, int max_sweeps, double delta, float sparsity, unsigned flags,
+                                        double* status_f64, void* stream) {
+    if (!V_in || ldvi < ncols) return NNF_ERR_ARG;
+    if (max_sweeps > NNF_HALS_MAX_SWEEPS) return NNF_ERR_UNSUPPORTED;
+    return hals_entry<0>(ctx, UtM, ldm, UtU_a, ldg, V_out, ldvo, r, ncols, max_sweeps, delta, sparsity, flags, status_f64,
+                         nullptr, (hipStream_t)stream, nullptr, 0, 0, UtU_b, V_in, ldvi);
 }

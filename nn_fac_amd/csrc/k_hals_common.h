@@ -278,6 +278,8 @@ struct hals_args {
     float* snapshots;     // mode 1, optional: V after every sweep, [sweep][r][ncols]
     int64_t snap_stride;
     int sweep0;           // mode 0: sweeps already done by earlier launches of the same solve (nnf_hals_solve_continue_f32)
+    const float* Vsrc;    // start values (r x ncols, row stride ldvs); == V for an in-place solve (quad kernel; the other
+    int64_t ldvs;         // layouts get a copy made by the entry point)
 };
 
 // Continuation of a solve longer than one launch can tag (NNF_HALS_MAX_SWEEPS): `status` holds the state the previous launch
@@ -300,5 +302,5 @@ int nnf_hals_fast_part3(nnf_ctx*, int RP, const hals_args&, int max_blocks_cap, 
 // k_hals_quad.hip: four lanes per column, for solves with few columns
 bool nnf_hals_quad_fits(nnf_ctx*, int r, int64_t ncols, int max_blocks_cap);
 size_t nnf_hals_quad_gram_floats(int r);
-int nnf_hals_quad_run(nnf_ctx*, const float* UtU, int64_t ldg, float* Gq, unsigned* counter, hals_args a, int* nblocks_out,
-                      hipStream_t);
+int nnf_hals_quad_run(nnf_ctx*, const float* UtU, const float* UtU2, int64_t ldg, float* Gq, unsigned* counter, hals_args a,
+                      int* nblocks_out, hipStream_t);

@@ -30,15 +30,21 @@ __device__ __forceinline__ float dpp_quad(float x) {
 // prep: LDS image of the row-scaled Gram.  Row k (k < RQ = 4*CH) is four chunks of CHP = roundup(CH, 4) floats; chunk q holds
 // G'[k][q*CH + jj] = UtU[k][q*CH + jj] / UtU[k][k], jj < CH (0 in the padding, outside r x r and in rows with a zero
 // diagonal).  Then 1/diag per row (0 = skip row), zeroed barrier word and status.
-__global__ void nnf_hals_prep_quad_kernel(const float* __restrict__ UtU, int64_t ldg, int r, int CH, float* __restrict__ Gq,
-                                          float* __restrict__ dinvq, unsigned* counter, double* status) {
+// UtU2 != nullptr: the Gram is the Hadamard product UtU .* UtU2 (the `cross` of ntf.py:442-445, formed here instead of by a
+// launch of its own).
+__global__ void nnf_hals_prep_quad_kernel(const float* __restrict__ UtU, const float* __restrict__ UtU2, int64_t ldg, int r, int CH,
+                                          float* __restrict__ Gq, float* __restrict__ dinvq, unsigned* counter, double* status) {
     const int RQ = 4 * CH, CHP = (CH + 3) & ~3, RS = 4 * CHP;
     const int k = blockIdx.x;                   // one workgroup per image row, 0 .. RQ-1
-    const float d = (k < r) ? UtU[(int64_t)k * ldg + k] : 0.f;
+    auto gram = [&](int a, int b) -> float {
+        const float g = UtU[(int64_t)a * ldg + b];
+        return UtU2 ? g * UtU2[(int64_t)a * ldg + b] : g;
+    };
+    const float d = (k < r) ? gram(k, k) : 0.f;
     const float di = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;
     for (int c = threadIdx.x; c < RS; c += blockDim.x) {
         const int q = c / CHP, jj = c - q * CHP, j = q * CH + jj;
-        Gq[k * RS + c] = (k < r && jj < CH && j < r) ? UtU[(int64_t)k * ldg + j] * di : 0.f;
+        Gq[k * RS + c] = (k < r && jj < CH && j < r) ? gram(k, j) * di : 0.f;
     }
     if (threadIdx.x == 0) dinvq[k] = di;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -161,6 +167,11 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
     const int ldv4 = (int)(a.ldv * 4), ldm4 = (int)(a.ldm * 4);
     // per-lane byte offset of row q*CH of its column; rows >= r and idle lanes land outside the descriptor (0 / dropped)
     const int voffv = valid ? (int)(col * 4 + (int64_t)q * CH * ldv4) : (int)0x7ffffff0;
+    // start values: a.Vsrc (== a.V for an in-place solve)
+    const rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Vsrc), 0,
+                                                         (int)(((int64_t)(a.r - 1) * a.ldvs + a.ncols) * 4), 0x00020000);
+    const int ldvs4 = (int)(a.ldvs * 4);
+    const int voffs = valid ? (int)(col * 4 + (int64_t)q * CH * ldvs4) : (int)0x7ffffff0;
     const int voffb = valid ? (int)(col * 4 + (int64_t)q * CH * ldm4) : (int)0x7ffffff0;
     float v[CH], b[CH], own[4];
 #pragma unroll
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
         const int kk = q * CH + j;
-        v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voffv, j * ldv4, 0));
+        v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, voffs, j * ldvs4, 0));
         const float bm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, voffb, j * ldm4, 0));
         b[j] = (bm - a.sp) * a.dinv[kk];
     }
@@ -340,12 +351,12 @@ size_t nnf_hals_quad_gram_floats(int r) {
 }
 
 // Gq: workspace of nnf_hals_quad_gram_floats(r) floats.  a.Gp / a.dinv are set here.
-int nnf_hals_quad_run(nnf_ctx* ctx, const float* UtU, int64_t ldg, float* Gq, unsigned* counter, hals_args a, int* nblocks_out,
-                      hipStream_t st) {
+int nnf_hals_quad_run(nnf_ctx* ctx, const float* UtU, const float* UtU2, int64_t ldg, float* Gq, unsigned* counter, hals_args a,
+                      int* nblocks_out, hipStream_t st) {
     const int ch = quad_ch(a.r), rq = 4 * ch, rs = 4 * ((ch + 3) & ~3);
     if (ch == 0) return NNF_ERR_UNSUPPORTED;
     float* dinvq = Gq + (size_t)rq * rs;
-    hipLaunchKernelGGL(nnf_hals_prep_quad_kernel, dim3(4 * ch), dim3(64), 0, st, UtU, ldg, a.r, ch, Gq, dinvq, counter,
+    hipLaunchKernelGGL(nnf_hals_prep_quad_kernel, dim3(4 * ch), dim3(64), 0, st, UtU, UtU2, ldg, a.r, ch, Gq, dinvq, counter,
                        (a.mode == 0 && a.sweep0 == 0) ? a.status : (double*)nullptr);
     NNF_CHECK_LAUNCH();
     if (a.max_sweeps == 0) return NNF_OK;

@@ -527,11 +527,19 @@ static int launch_gram(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, 
     const int64_t max_split = nnf_cdiv(K, 64);
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
+    // short factors (the I_mode x R factors of NTF / NTD, K <= 1024): one workgroup, no split, written straight into G -- the
+    // whole Gram is a few microseconds of work and the slab reduction would be a second launch of the same length
+    if (K <= 1024 && ldg == r) nsplit = 1;
     const int64_t kps = nnf_rup(nnf_cdiv(K, nsplit), 64);
     nsplit = nnf_cdiv(K, kps);
+    const int a_vec_ok = ((((uintptr_t)A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
+    if (nsplit == 1 && ldg == r) {
+        hipLaunchKernelGGL((nnf_gram_kernel<MT>), dim3(1), dim3(256), 0, st, A, r, K, lda, G, kps, a_vec_ok);
+        NNF_CHECK_LAUNCH();
+        return NNF_OK;
+    }
     float* slabs = (float*)cur.take((size_t)nsplit * r * r * 4);
     if (!slabs) return NNF_ERR_WORKSPACE;
-    const int a_vec_ok = ((((uintptr_t)A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     hipLaunchKernelGGL((nnf_gram_kernel<MT>), dim3((int)nsplit), dim3(256), 0, st, A, r, K, lda, slabs, kps, a_vec_ok);
     NNF_CHECK_LAUNCH();
     return nnf_launch_reduce_slabs(slabs, (int)nsplit, (int64_t)r * r, r, r, r, G, ldg, st);

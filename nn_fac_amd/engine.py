@@ -169,6 +169,22 @@ class Engine:
             done += step
         return st
 
+    def hals_solve_cross(self, UtM, Ga, Gb, V_in, V_out, max_sweeps, delta=0.01, sparsity=None, normalize=False, status=None):
+        """hals_solve with the Gram Ga .* Gb (Gb may be None), start values V_in and the result in V_out (ntf.py:442-456)."""
+        _chk2d(UtM, "hals UtM"), _chk2d(Ga, "hals Ga"), _chk2d(V_in, "hals V_in"), _chk2d(V_out, "hals V_out")
+        r, ncols = V_out.shape
+        if UtM.shape != (r, ncols) or V_in.shape != (r, ncols) or Ga.shape[0] < r or (Gb is not None and
+                                                                                       (Gb.shape != Ga.shape or _ld(Gb) != _ld(Ga))):
+            raise EngineError("hals_solve_cross: shape mismatch")
+        self._check_rowsync_columns(normalize, ncols)
+        st = status if status is not None else torch.empty(ST_WORDS, dtype=torch.float64, device=V_out.device)
+        _lib.check(self.lib.nnf_hals_solve_cross_f32(self.ctx, _ptr(UtM), _ld(UtM), _ptr(Ga), _ptr(Gb) if Gb is not None else None,
+                                                     _ld(Ga), _ptr(V_in), _ld(V_in), _ptr(V_out), _ld(V_out), r, ncols,
+                                                     int(max_sweeps), float(delta), float(sparsity or 0.0),
+                                                     self._hals_flags(sparsity, normalize, False), _ptr(st), self._stream()),
+                   "nnf_hals_solve_cross_f32")
+        return st
+
     def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False, snapshots=None):
         """Exactly `nsweeps` in-place sweeps; returns the per-sweep LOCAL sum of squared steps (float64, device).
         snapshots (optional, contiguous float32 [>= nsweeps, r, ncols]): block s receives V after sweep s+1."""

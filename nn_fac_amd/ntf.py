@@ -234,6 +234,7 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
             if not deterministic:
                 torch.cuda.synchronize(dev)
                 t0 = time.time()
+            Ga = Gb = None              # the two Grams whose Hadamard product is `cross` (ntf.py:442-445)
             if sharded and mode != 0:
                 # MTTKRP output (R x I_mode) and the Gram of the sharded mode-0 factor (R x R) are sums over the blocks of
                 # the leading mode (ntf.py:442-449): they share an allocation and ONE all-reduce
@@ -243,15 +244,26 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
                 eng.gram(Ft[0], out=g0)
                 rhs_of(mode, out=rhs_t)
                 _dist.allreduce_(buf, st.group)
-                cross = eng.hadamard(g0, st.gram_of(3 - mode, Ft[3 - mode]))
+                Ga, Gb = g0, st.gram_of(3 - mode, Ft[3 - mode])
             else:
-                cross = None
-                for i, f in enumerate(Ft):
-                    if i != mode:
-                        g = st.gram_of(i, f)
-                        cross = g if cross is None else eng.hadamard(cross, g)
+                grams = [st.gram_of(i, f) for i, f in enumerate(Ft) if i != mode]
+                Ga = grams[0]
+                for g in grams[1:-1]:                   # order > 3: all but the last factor of the product folded here
+                    Ga = eng.hadamard(Ga, g)
+                Gb = grams[-1] if len(grams) > 1 else None
                 rhs_t = rhs_of(mode)
             budget = 100
+            fused = deterministic and hasattr(eng, "hals_solve_cross") and not (sharded and mode == 0)
+            if fused:
+                # Hadamard product formed while the solve stages its Gram, start values read from the current factor, the
+                # result written to a NEW tensor: no Hadamard launch, no copy in front of the solve
+                new = torch.empty_like(Ft[mode])
+                eng.hals_solve_cross(rhs_t, Ga, Gb, Ft[mode], new, budget, delta=delta, sparsity=sparsity_coefficients[mode],
+                                     normalize=normalize[mode], status=st.block[8 * nstat:8 * nstat + 8])
+                nstat += 1
+                Ft[mode] = new
+                continue
+            cross = Ga if Gb is None else eng.hadamard(Ga, Gb)
             new = Ft[mode].clone()
             if sharded and mode == 0:
                 eps, cnt, eps0 = _dist.sharded_hals_solve(eng, rhs_t, cross, new, st.group, st.guess0, budget=budget,

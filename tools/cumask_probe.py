@@ -1,4 +1,8 @@
-"""CU-masked streams (hipExtStreamCreateWithCUMask): does keeping the V-side sweep kernel and the cost kernel on disjoint
+"""Do not run under rocprofv3: the profiler segfaults in __cxa_finalize on a process that owns CU-masked streams
+(gpurun_out/prof_mask.log, round 1; the stream-creation interception of rocprofiler-sdk does not expect hipExtStreamCreateWithCUMask
+streams at teardown).  Experiment dropped.
+
+CU-masked streams (hipExtStreamCreateWithCUMask): does keeping the V-side sweep kernel and the cost kernel on disjoint
 CUs remove the slowdown measured by tools/contention_probe.py?  Prints the solve time alone / next to the cost kernel for a
 few mask layouts."""
 import ctypes as C, os, sys, torch

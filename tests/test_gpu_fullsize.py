@@ -140,3 +140,58 @@ def test_bench_single_rank_rccl_smoke(built_lib):
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 1 and "nccl" in out["config"]["parallelism"] and out["value"] > 0
     assert out["roofline"]["kernel"].startswith("nnf_xty_kernel") and out["roofline"]["launch_ms"] > 0
+
+
+def test_config_e_full_size_on_one_gpu(built_lib):
+    """configs[4] at its FULL size on one GPU (10^6 x 4000, rank 100: X is 16 GB, never on the host; bench.py's generator):
+    one HALS iteration through the product's step, checked by size-independent properties -- the oracle would need ~50 GB and
+    minutes here.  (a) V X^T and U^T X against torch products of row chunks (the 64-bit row offsets, the multi-round tilings
+    and the 1e6-column strided U-side solve only exist at this size); (b) the cost against a chunked fp64 residual; (c) the
+    U-side solve, whose columns are independent, against the SAME number of sweeps run on one 50000-column slice alone
+    (resident kernel instead of the strided one); (d) the V-side solve against a re-solve from the same operands (bitwise)."""
+    import bench
+    from nn_fac_amd.engine import get_engine, ST_CNT, ST_ERR
+    from nn_fac_amd import nmf as nmf_mod
+    m, n, r = 1000000, 4000, 100
+    dev = torch.device("cuda:0")
+    eng = get_engine(dev)
+    parts = [bench.synth_nmf_block_device(m // 8, n, r, b, 977, dev, torch) for b in range(8)]
+    X = torch.cat([p[0] for p in parts])
+    Ut0 = torch.cat([p[1] for p in parts]).t().contiguous()
+    del parts
+    V0 = torch.rand(r, n, device=dev, generator=torch.Generator(device=dev).manual_seed(4242))
+    ws = nmf_mod._StepBuffers(X, r)
+    Ut1, V1, nstat = nmf_mod._one_nmf_step_dev(eng, ws, X, r, Ut0, V0, "hals", 2, [None, None], [], [False, False], True)
+    host = ws.block.cpu()
+    assert nstat == 2 and int(host[ST_ERR]) == 0 and int(host[8 + ST_ERR]) == 0
+    su, sv = int(host[ST_CNT]) - 1, int(host[8 + ST_CNT]) - 1
+    assert 2 <= su <= 100 and 2 <= sv <= 100
+
+    def relerr(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    # (a) the cross products, on three row chunks spread over the matrix (incl. the last rows)
+    VMt = eng.xht(X, V0)
+    UtM = eng.xty(X, Ut1)
+    acc = torch.zeros(r, n, dtype=torch.float64, device=dev)
+    for lo in range(0, m, 125000):
+        acc += Ut1[:, lo:lo + 125000].double() @ X[lo:lo + 125000].double()
+    assert relerr(UtM, acc) < 1e-5
+    for lo in (0, 437500, 999000):
+        hi = min(m, lo + 1000)
+        assert relerr(VMt[:, lo:hi], V0.double() @ X[lo:hi].double().t()) < 1e-5
+    # (b) the cost of the step
+    want = 0.0
+    for lo in range(0, m, 125000):
+        want += float(((X[lo:lo + 125000].double() - Ut1[:, lo:lo + 125000].double().t() @ V1.double()) ** 2).sum())
+    assert abs(float(host[16]) - want) <= 1e-5 * want, (float(host[16]), want)
+    # (c) columns of the U-side solve are independent given the sweep count
+    G = eng.gram(V0)
+    lo, hi = 300000, 350000
+    F = Ut0[:, lo:hi].contiguous()
+    eng.hals_sweeps(VMt[:, lo:hi].contiguous(), G, F, su)
+    assert relerr(F, Ut1[:, lo:hi]) < 1e-5
+    # (d) the replicated V-side solve is deterministic
+    G2 = eng.gram(Ut1)
+    V2 = V0.clone()
+    st = eng.hals_solve(UtM, G2, V2, 100, delta=0.01).cpu()
+    assert int(st[ST_CNT]) - 1 == sv and torch.equal(V2, V1)

@@ -222,6 +222,148 @@ __global__ __launch_bounds__(1024) void nnf_ntd_core_pg_kernel(float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same loop on d0 workgroups (one per mode-0 slab of the core) for cores of a few thousand entries, where one CU spends
+// ~18 us per step (300 steps = most of an NTD iteration at 300^3 / 20^3).  The three mode products of the gradient commute:
+// a workgroup forms  y = slab x_1 M1 x_2 M2  locally (two small products on its d1 x d2 slab), publishes it, and after ONE grid
+// barrier combines everybody's y with its row of M0:  (core x M)[a] = sum_a'' M0[a][a''] y[a''].  The squared norm of the previous
+// step's update travels with y, so the stopping test of ntd.py:609 is taken right after the barrier -- BEFORE the update of the
+// step it decides about is applied: no speculation, no roll-back, one barrier per step.  fp64 throughout, every workgroup
+// adds the partials in index order (same doubles everywhere -> same decisions).  Exchange through agent-scope atomics
+// (write-through stores / cache-bypassing loads), ping-pong buffers by step parity, bounded spins (status[5] = 1 on a time-out).
+// ---------------------------------------------------------------------------------------------------------
+struct pg_multi_sync {
+    unsigned* counter;                 // arrivals, zeroed before the launch
+    unsigned long long* Y;             // [2][d0][S1] doubles (as bits)
+    unsigned long long* part;          // [2][d0][2] doubles (as bits): partial sums that travel with a barrier
+};
+__device__ __forceinline__ void pg_st(unsigned long long* p, double v) {
+    __hip_atomic_store(p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double pg_ld(const unsigned long long* p) {
+    return __builtin_bit_cast(double, __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// all workgroups arrive; returns false on a time-out (workgroup-uniform).  `episode` counts barriers from 1.
+__device__ __forceinline__ bool pg_grid_barrier(unsigned* counter, unsigned episode, unsigned nwg, unsigned* flag) {
+    __syncthreads();                                        // this workgroup's stores have been issued
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = episode * nwg;
+        unsigned spins = 0, ok = 1;
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22)) { ok = 0; break; }
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    return *flag != 0u;
+}
+
+__global__ __launch_bounds__(256) void nnf_ntd_core_pg_multi_kernel(float* __restrict__ core_g, const float* __restrict__ mtx_g,
+                                                                   const float* __restrict__ M0g, const float* __restrict__ M1g,
+                                                                   const float* __restrict__ M2g, int d0, int d1, int d2,
+                                                                   double sparse, double delta, int max_iter, double norm_sq,
+                                                                   double* __restrict__ status, pg_multi_sync sy) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int a = blockIdx.x, S1 = d1 * d2;
+    const unsigned nwg = gridDim.x;
+    double* vx = lds_all;            // 128
+    double* vy = vx + 128;           // 128
+    double* red = vy + 128;          // 16
+    double* m0 = red + 16;           // d0 doubles: row a of M0 (padded to 128)
+    const int p1 = (d1 + 3) & ~3, p2 = (d2 + 3) & ~3;
+    float* T1 = reinterpret_cast<float*>(m0 + 128);
+    float* T2 = T1 + d1 * p1;
+    double* c = reinterpret_cast<double*>(T2 + d2 * p2 + ((d1 * p1 + d2 * p2) & 1));   // 8-byte aligned (both blocks are multiples of 4 floats)
+    double* mx = c + S1;
+    double* y = mx + S1;
+    double* ta = y + S1;
+    __shared__ unsigned flag;
+    for (int e = threadIdx.x; e < S1; e += blockDim.x) { c[e] = (double)core_g[(size_t)a * S1 + e]; mx[e] = (double)mtx_g[(size_t)a * S1 + e]; }
+    for (int e = threadIdx.x; e < d0; e += blockDim.x) m0[e] = (double)M0g[a * d0 + e];
+    for (int e = threadIdx.x; e < d1 * p1; e += blockDim.x) { const int r_ = e / p1, b = e - r_ * p1; T1[e] = b < d1 ? M1g[b * d1 + r_] : 0.f; }
+    for (int e = threadIdx.x; e < d2 * p2; e += blockDim.x) { const int r_ = e / p2, b = e - r_ * p2; T2[e] = b < d2 ? M2g[b * d2 + r_] : 0.f; }
+    __syncthreads();
+    double step = 1.0;   // ntd.py:592-596, every workgroup the same arithmetic
+    step *= 1.0 / pg_sigma_max(M0g, d0, vx, vy, red);
+    step *= 1.0 / pg_sigma_max(M1g, d1, vx, vy, red);
+    step *= 1.0 / pg_sigma_max(M2g, d2, vx, vy, red);
+    step = rint(step * 1e6) / 1e6;
+
+    unsigned episode = 0;
+    bool ok = true;
+    double s2_mine = 0.0, upd0 = 0.0, upd = 1.0;
+    int t = 1;
+    // gradient of the current core: ta = (core x_0 M0 x_1 M1 x_2 M2)[a]; brings back the sum of the partials p0 published with it
+    auto full_product = [&](double pub0, double pub1, double& sum0, double& sum1) -> bool {
+        pg_mode_dot<double>(c, ta, T1, 1, d1, d2, 1);          // (ends with a barrier)
+        pg_mode_dot<double>(ta, y, T2, 1, d1, d2, 2);
+        ++episode;
+        unsigned long long* Yp = sy.Y + (size_t)(episode & 1) * nwg * S1;
+        for (int e = threadIdx.x; e < S1; e += blockDim.x) pg_st(Yp + (size_t)a * S1 + e, y[e]);
+        unsigned long long* Pp = sy.part + (size_t)(episode & 1) * nwg * 2;
+        if (threadIdx.x == 0) { pg_st(Pp + 2 * a, pub0); pg_st(Pp + 2 * a + 1, pub1); }
+        if (!pg_grid_barrier(sy.counter, episode, nwg, &flag)) return false;
+        for (int e = threadIdx.x; e < S1; e += blockDim.x) {
+            double s = 0.0;
+            for (unsigned q = 0; q < nwg; ++q) s += m0[q] * pg_ld(Yp + (size_t)q * S1 + e);
+            ta[e] = s;
+        }
+        double q0 = 0.0, q1 = 0.0;
+        for (unsigned q = 0; q < nwg; ++q) { q0 += pg_ld(Pp + 2 * q); q1 += pg_ld(Pp + 2 * q + 1); }   // every thread, index order
+        sum0 = q0;
+        sum1 = q1;
+        __syncthreads();
+        return true;
+    };
+    while (true) {
+        double n2 = 0.0, dummy = 0.0;
+        ok = full_product(s2_mine, 0.0, n2, dummy);
+        if (!ok) break;
+        if (t >= 2) {
+            upd = sqrt(n2);
+            if (t == 2) upd0 = upd;
+        }
+        if (!(t <= max_iter && (t == 1 || upd >= delta * upd0))) break;   // ntd.py:609, decided before the update is applied
+        double s2 = 0.0;
+        for (int e = threadIdx.x; e < S1; e += blockDim.x) {
+            const double grad = -mx[e] + ta[e] + sparse;
+            const double dc = fmin(step * grad, c[e]);
+            c[e] -= dc;
+            s2 += dc * dc;
+        }
+        s2_mine = pg_block_sum(s2, red);
+        ++t;
+    }
+    // ta = (core x M)[a] for the final core: ntd.py:639
+    double ip = 0.0, qf = 0.0;
+    if (ok) {
+        for (int e = threadIdx.x; e < S1; e += blockDim.x) { ip += mx[e] * c[e]; qf += ta[e] * c[e]; }
+        ip = pg_block_sum(ip, red);
+        qf = pg_block_sum(qf, red);
+        ++episode;
+        unsigned long long* Pp = sy.part + (size_t)(episode & 1) * nwg * 2;
+        if (threadIdx.x == 0) { pg_st(Pp + 2 * a, ip); pg_st(Pp + 2 * a + 1, qf); }
+        ok = pg_grid_barrier(sy.counter, episode, nwg, &flag);
+        if (ok) {
+            ip = 0.0;
+            qf = 0.0;
+            for (unsigned q = 0; q < nwg; ++q) { ip += pg_ld(Pp + 2 * q); qf += pg_ld(Pp + 2 * q + 1); }
+        }
+    }
+    for (int e = threadIdx.x; e < S1; e += blockDim.x) core_g[(size_t)a * S1 + e] = (float)c[e];
+    if (a == 0 && threadIdx.x == 0) {
+        status[0] = (double)(t - 1);
+        status[1] = upd;
+        status[2] = upd0;
+        status[3] = step;
+        status[4] = norm_sq - 2.0 * ip + qf;
+        status[5] = ok ? 0.0 : 1.0;
+    }
+}
+
 extern "C" int nnf_ntd_core_pg_f32(nnf_ctx* ctx, float* core, const float* MtX, const float* M0, const float* M1, const float* M2,
                                    int d0, int d1, int d2, double sparse, double delta, int max_iter, double norm_sq,
                                    double* status_f64, void* stream) {
@@ -233,6 +375,27 @@ extern "C" int nnf_ntd_core_pg_f32(nnf_ctx* ctx, float* core, const float* MtX, 
     const size_t lim = (size_t)160 * 1024;
     const int threads = S >= 1024 ? 1024 : (S >= 512 ? 512 : 256);
     hipStream_t st = (hipStream_t)stream;
+    {   // a few thousand entries and several mode-0 slabs: one workgroup per slab (NNF_NTD_PG_MULTI=0: the one-workgroup form)
+        static const bool multi_ok = !(getenv("NNF_NTD_PG_MULTI") && getenv("NNF_NTD_PG_MULTI")[0] == '0');
+        const int64_t S1 = (int64_t)d1 * d2;
+        const size_t shm = (size_t)(128 + 128 + 16 + 128) * 8 + ((size_t)d1 * ((d1 + 3) & ~3) + (size_t)d2 * ((d2 + 3) & ~3) + 2) * 4 +
+                           (size_t)4 * S1 * 8;
+        if (multi_ok && S >= 2048 && d0 >= 4 && d0 <= ctx->num_cus && shm <= (size_t)150 * 1024) {
+            nnf_ws_cursor cur(ctx);
+            unsigned* counter = (unsigned*)cur.take(256);
+            unsigned long long* Y = (unsigned long long*)cur.take((size_t)2 * S * 8);
+            unsigned long long* part = (unsigned long long*)cur.take((size_t)2 * d0 * 2 * 8);
+            if (!counter || !Y || !part) return NNF_ERR_WORKSPACE;
+            if (hipMemsetAsync(counter, 0, 4, st) != hipSuccess) return NNF_ERR_LAUNCH;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_ntd_core_pg_multi_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+                return NNF_ERR_LAUNCH;
+            hipLaunchKernelGGL(nnf_ntd_core_pg_multi_kernel, dim3(d0), dim3(256), shm, st, core, MtX, M0, M1, M2, d0, d1, d2, sparse,
+                               delta, max_iter, norm_sq, status_f64, pg_multi_sync{counter, Y, part});
+            NNF_CHECK_LAUNCH();
+            return NNF_OK;
+        }
+    }
     if (fixed + (size_t)4 * S * 8 <= lim) {          // everything in LDS, fp64 storage
         const size_t shm = fixed + (size_t)4 * S * 8;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_ntd_core_pg_kernel<double>),

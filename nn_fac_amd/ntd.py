@@ -396,6 +396,8 @@ def compute_ntd(tensor_in, ranks, core_in, factors_in, n_iter_max=100, tol=1e-6,
                 raise err.EngineError("hals grid barrier timed out; result invalid")
         if sweep_log is not None:
             sweep_log.extend(int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(nstat))
+        if update_rule == "hals" and int(host[st.pg_at + 5]) != 0:
+            raise err.EngineError("NTD core update: grid barrier timed out; result invalid")
         if pg_log is not None and update_rule == "hals":
             pg_log.append(int(host[st.pg_at]))
         result = (core_i, Ft_i)

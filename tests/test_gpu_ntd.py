@@ -245,3 +245,65 @@ def test_ntd_order_n(built_lib, shape, ranks, rule, beta):
     np.testing.assert_allclose(costs, cso, rtol=5e-3 if rule == "hals" else 2e-4)
     if rule == "hals":
         assert sw == swo and pg == pgo, (sw, swo, pg, pgo)
+
+
+def test_core_update_on_one_workgroup_per_slab(built_lib, monkeypatch):
+    """nnf_ntd_core_pg_f32 for a core of a few thousand entries (16 x 12 x 12 = 2304): the projected-gradient loop of
+    ntd.py:588-619 runs on one workgroup per mode-0 slab with one grid barrier per step -- same iteration count, step, core
+    and error as the one-workgroup form (NNF_NTD_PG_MULTI=0; both fp64, the mode products in a different order) and as the
+    oracle's loop."""
+    import subprocess
+    import json
+    code = r"""
+import sys, os, json, numpy as np, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle"))
+from nn_fac_amd.engine import get_engine
+eng = get_engine("cuda:0")
+rng = np.random.RandomState(3)
+d = (16, 12, 12)
+F = [rng.rand(40 + 5 * i, d[i]) for i in range(3)]
+M = [f.T @ f for f in F]
+core = rng.rand(*d) + 0.05
+MtX = np.einsum('abc,ia,jb,kc->ijk', rng.rand(*d), *M)[:d[0], :d[1], :d[2]] if False else None
+G = rng.rand(*d)
+MtX = np.einsum('abc,xa,yb,zc->xyz', G, *M)          # MtX of an exactly representable tensor: the loop converges towards G
+c = torch.from_numpy(core.astype(np.float32)).cuda().contiguous()
+st = eng.ntd_core_pg(c, torch.from_numpy(MtX.astype(np.float32)).cuda(), [torch.from_numpy(m.astype(np.float32)).cuda() for m in M],
+                     0.01, 0.01, 300, 12345.0).cpu().tolist()
+print(json.dumps({"status": st, "core": c.cpu().double().numpy().ravel().tolist()}))
+"""
+    outs = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, NNF_NTD_PG_MULTI=flag)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]))
+    multi, single = outs
+    assert multi["status"][5] == 0 and int(multi["status"][0]) == int(single["status"][0]) and int(multi["status"][0]) >= 3
+    assert multi["status"][3] == single["status"][3]                     # the rounded step
+    np.testing.assert_allclose(multi["status"][1:3], single["status"][1:3], rtol=1e-9)
+    np.testing.assert_allclose(multi["status"][4], single["status"][4], rtol=1e-9)
+    np.testing.assert_allclose(multi["core"], single["core"], rtol=1e-6, atol=1e-9)
+    # and the oracle's loop on the same (fp32-rounded) operands
+    rng = np.random.RandomState(3)
+    d = (16, 12, 12)
+    F = [rng.rand(40 + 5 * i, d[i]) for i in range(3)]
+    M = [(f.T @ f).astype(np.float32).astype(np.float64) for f in F]
+    core = (rng.rand(*d) + 0.05).astype(np.float32).astype(np.float64)
+    G = rng.rand(*d)
+    MtX = np.einsum('abc,xa,yb,zc->xyz', G, *[f.T @ f for f in F]).astype(np.float32).astype(np.float64)
+    step = 1.0
+    for m in M:
+        step *= 1 / np.linalg.svd(m, compute_uv=False)[0]
+    step = round(step, 6)
+    cnt, upd0, upd = 1, 0, 1
+    while cnt <= 300 and upd >= 0.01 * upd0:
+        grad = -MtX + orc.multi_mode_dot(core, M) + 0.01
+        dc = np.minimum(step * grad, core)
+        core = core - dc
+        upd = np.sqrt(np.sum(dc ** 2))
+        if cnt == 1:
+            upd0 = upd
+        cnt += 1
+    assert int(multi["status"][0]) == cnt - 1 and abs(multi["status"][3] - step) < 1e-12
+    assert rel(np.array(multi["core"]).reshape(d), core) < 1e-5

@@ -784,39 +784,53 @@ extern "C" int nnf_mu_left_num_f32(nnf_ctx* ctx, const float* X, int64_t m, int6
 // H_{l+1}^T W_{l+1}^T, deep_nmf.py:93; the rank-sized links of the NTD chains).  One thread per output, k in order.
 __global__ __launch_bounds__(256) void nnf_small_gemm_rect_kernel(const float* __restrict__ A, int64_t lda, int p, int q,
                                                                   const float* __restrict__ B, int64_t ldb, int64_t cols,
-                                                                  float* __restrict__ out, int64_t ldo) {
+                                                                  float* __restrict__ out, int64_t ldo, int64_t bstride,
+                                                                  int64_t ostride) {
+    // grid = (column blocks of 256, chunks of 8 output rows, batch); thread = one column, 8 outputs, k in order
     extern __shared__ float sA[];
-    for (int e = threadIdx.x; e < p * q; e += 256) sA[e] = A[(int64_t)(e / q) * lda + (e % q)];
+    const int k0 = blockIdx.y * 8;
+    const int nr = (p - k0 < 8) ? (p - k0) : 8;
+    for (int e = threadIdx.x; e < nr * q; e += 256) sA[e] = A[(int64_t)(k0 + e / q) * lda + (e % q)];
     __syncthreads();
-    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < cols; j += (int64_t)gridDim.x * 256) {
-        for (int k0 = 0; k0 < p; k0 += 8) {   // 8 output rows per pass over the column of B
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int l = 0; l < q; ++l) {
-                const float b = B[(int64_t)l * ldb + j];
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    const float* Bb = B + (int64_t)blockIdx.z * bstride;
+    float* ob = out + (int64_t)blockIdx.z * ostride;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int l0 = 0; l0 < q; l0 += 8) {      // eight loads of B in flight (one at a time the loop is a chain of memory latencies)
+        float b[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) b[t] = (l0 + t < q) ? Bb[(int64_t)(l0 + t) * ldb + j] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (l0 + t < q) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (k0 + u < p) acc[u] = fmaf(sA[(k0 + u) * q + l], b, acc[u]);
+                    if (u < nr) acc[u] = fmaf(sA[u * q + l0 + t], b[t], acc[u]);
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (k0 + u < p) out[(int64_t)(k0 + u) * ldo + j] = acc[u];
-        }
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < nr) ob[(int64_t)(k0 + u) * ldo + j] = acc[u];
+}
+// batched form: out[z] = A B[z] for z < batch (B[z] = B + z * bstride, out[z] = out + z * ostride); batch = 1: plain
+int nnf_small_gemm_launch(const float* A, int64_t lda, int p, int q, const float* B, int64_t ldb, int64_t cols, float* out,
+                          int64_t ldo, int64_t batch, int64_t bstride, int64_t ostride, hipStream_t st) {
+    if ((int64_t)8 * q * 4 > 64 * 1024 || batch > 65535 || nnf_cdiv(p, 8) > 65535) return NNF_ERR_UNSUPPORTED;
+    const size_t shm = (size_t)8 * q * 4;
+    if (shm > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_small_gemm_rect_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(nnf_small_gemm_rect_kernel, dim3((unsigned)nnf_cdiv(cols, 256), (unsigned)nnf_cdiv(p, 8), (unsigned)batch),
+                       dim3(256), shm, st, A, lda, p, q, B, ldb, cols, out, ldo, bstride, ostride);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
 }
 extern "C" int nnf_small_gemm_f32(nnf_ctx* ctx, const float* A, int64_t lda, int p, int q, const float* B, int64_t ldb,
                                   int64_t cols, float* out, int64_t ldo, void* stream) {
     if (!ctx || !A || !B || !out || p < 1 || q < 1 || cols < 1 || lda < q || ldb < cols || ldo < cols) return NNF_ERR_ARG;
-    if ((int64_t)p * q > 16384) return NNF_ERR_UNSUPPORTED;   // A is staged whole in LDS (64 KB)
-    int64_t grid = nnf_cdiv(cols, 256);
-    if (grid > 4096) grid = 4096;
-    const size_t shm = (size_t)p * q * 4;
-    if (shm > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_small_gemm_rect_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL(nnf_small_gemm_rect_kernel, dim3((int)grid), dim3(256), shm, (hipStream_t)stream, A, lda, p, q, B, ldb,
-                       cols, out, ldo);
-    NNF_CHECK_LAUNCH();
-    return NNF_OK;
+    if ((int64_t)p * q > 16384) return NNF_ERR_UNSUPPORTED;
+    return nnf_small_gemm_launch(A, lda, p, q, B, ldb, cols, out, ldo, 1, 0, 0, (hipStream_t)stream);
 }
 
 // deep_KL_mu (deep_mu.py:8-14), element-wise tail:  a = hsum[k] - lambda*log(WHnext[k,i]),  b = F[k,i]*num[k,i],

@@ -54,6 +54,9 @@ extern "C" int nnf_ttm3_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, 
     nnf_ws_cursor cur(ctx);
     if (mode == 0) return nnf_xty_impl(ctx, cur, T, I, J * K, J * K, Ft, r, ldf, out, J * K, st);
     if (mode == 2) return nnf_xht_impl(ctx, cur, T, I * J, K, K, Ft, r, ldf, out, I * J, st);
+    // middle axis: per slab i, out_i (r x K) = Ft (r x J) T_i (J x K) -- a batch of products with one rank-sized left operand
+    if ((int64_t)8 * J * 4 <= 64 * 1024 && I <= 65535)
+        return nnf_small_gemm_launch(Ft, ldf, r, (int)J, T, K, K, out, K, I, J * K, (int64_t)r * K, st);
     if (I > 65535) return NNF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((nnf_ttm_mid_kernel<16>), dim3((unsigned)nnf_cdiv(K, 256), (unsigned)I), dim3(256), 0, st, T, J, K, Ft, ldf,
                        r, out);
@@ -245,13 +248,16 @@ __device__ __forceinline__ double pg_ld(const unsigned long long* p) {
 }
 // all workgroups arrive; returns false on a time-out (workgroup-uniform).  `episode` counts barriers from 1.
 __device__ __forceinline__ bool pg_grid_barrier(unsigned* counter, unsigned episode, unsigned nwg, unsigned* flag) {
-    __syncthreads();                                        // this workgroup's stores have been issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's published words have reached the L2 ...
+    __syncthreads();                                        // ... and so have those of every wave of the workgroup
     if (threadIdx.x == 0) {
+        // every exchanged word is an agent-scope atomic (write-through store / cache-bypassing load): relaxed ordering + the
+        // drain below is enough, and spares the cache write-back / invalidate an acquire-release pair costs per barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = episode * nwg;
         unsigned spins = 0, ok = 1;
-        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 22)) { ok = 0; break; }
         }
@@ -306,15 +312,31 @@ __global__ __launch_bounds__(256) void nnf_ntd_core_pg_multi_kernel(float* __res
         unsigned long long* Pp = sy.part + (size_t)(episode & 1) * nwg * 2;
         if (threadIdx.x == 0) { pg_st(Pp + 2 * a, pub0); pg_st(Pp + 2 * a + 1, pub1); }
         if (!pg_grid_barrier(sy.counter, episode, nwg, &flag)) return false;
+        // everybody's y against this workgroup's row of M0.  The loads of up to 32 slabs are issued together (an L2 round trip
+        // each: one at a time they would be the whole step), the sum runs in slab order.
         for (int e = threadIdx.x; e < S1; e += blockDim.x) {
             double s = 0.0;
-            for (unsigned q = 0; q < nwg; ++q) s += m0[q] * pg_ld(Yp + (size_t)q * S1 + e);
+            for (unsigned q0_ = 0; q0_ < nwg; q0_ += 32) {
+                double v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v[u] = (q0_ + u < nwg) ? pg_ld(Yp + (size_t)(q0_ + u) * S1 + e) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 32; ++u)
+                    if (q0_ + u < nwg) s += m0[q0_ + u] * v[u];
+            }
             ta[e] = s;
         }
-        double q0 = 0.0, q1 = 0.0;
-        for (unsigned q = 0; q < nwg; ++q) { q0 += pg_ld(Pp + 2 * q); q1 += pg_ld(Pp + 2 * q + 1); }   // every thread, index order
-        sum0 = q0;
-        sum1 = q1;
+        // the travelling partial sums: lanes of the first wave fetch them, fixed-order wave sum, broadcast through LDS
+        if (threadIdx.x < 64) {
+            double q0 = 0.0, q1 = 0.0;
+            for (unsigned q = threadIdx.x; q < nwg; q += 64) { q0 += pg_ld(Pp + 2 * q); q1 += pg_ld(Pp + 2 * q + 1); }
+            q0 = nnf_wave_sum_f64(q0);
+            q1 = nnf_wave_sum_f64(q1);
+            if (threadIdx.x == 0) { red[8] = q0; red[9] = q1; }
+        }
+        __syncthreads();
+        sum0 = red[8];
+        sum1 = red[9];
         __syncthreads();
         return true;
     };
@@ -347,10 +369,11 @@ __global__ __launch_bounds__(256) void nnf_ntd_core_pg_multi_kernel(float* __res
         unsigned long long* Pp = sy.part + (size_t)(episode & 1) * nwg * 2;
         if (threadIdx.x == 0) { pg_st(Pp + 2 * a, ip); pg_st(Pp + 2 * a + 1, qf); }
         ok = pg_grid_barrier(sy.counter, episode, nwg, &flag);
-        if (ok) {
-            ip = 0.0;
-            qf = 0.0;
-            for (unsigned q = 0; q < nwg; ++q) { ip += pg_ld(Pp + 2 * q); qf += pg_ld(Pp + 2 * q + 1); }
+        if (ok && threadIdx.x < 64) {
+            double q0 = 0.0, q1 = 0.0;
+            for (unsigned q = threadIdx.x; q < nwg; q += 64) { q0 += pg_ld(Pp + 2 * q); q1 += pg_ld(Pp + 2 * q + 1); }
+            ip = nnf_wave_sum_f64(q0);
+            qf = nnf_wave_sum_f64(q1);
         }
     }
     for (int e = threadIdx.x; e < S1; e += blockDim.x) core_g[(size_t)a * S1 + e] = (float)c[e];

@@ -105,6 +105,10 @@ __device__ __forceinline__ void nnf_xcd_map(int bid, int members, int& group, in
 int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, int rows, int64_t cols, int64_t lds,
                             float* out, int64_t ldo, hipStream_t st);
 
+// out[z] = A (p x q) B[z] (q x cols), z < batch: a rank-sized left operand staged in LDS (k_mu.hip)
+int nnf_small_gemm_launch(const float* A, int64_t lda, int p, int q, const float* B, int64_t ldb, int64_t cols, float* out,
+                          int64_t ldo, int64_t batch, int64_t bstride, int64_t ostride, hipStream_t st);
+
 // out[0] = scale * sum of `count` doubles, index order, one workgroup
 int nnf_launch_sum_f64(const double* partial, int64_t count, double scale, double* out, hipStream_t st);
 

@@ -161,9 +161,7 @@ def _contract_others(eng, temp, axes, core, n):
     others = axes[:-1]
     A = core.permute([n] + others).reshape(core.shape[n], -1).contiguous()
     B = temp.reshape(-1, temp.shape[-1])
-    if A.shape[0] * A.shape[1] <= 16384 and hasattr(eng, "small_gemm"):
-        return eng.small_gemm(A, B)
-    return (A @ B).contiguous()
+    return eng.xty(B, A)          # A (r_n x P) @ B (P x I_n): the W^T X kernel with P = prod(other ranks) "rows"
 
 
 def _one_ntd_step_dev(st, core_in, Ft_in, sparsity_coefficients, fixed_modes, normalize, mode_core_norm, alpha, delta):

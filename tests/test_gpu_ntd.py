@@ -275,7 +275,8 @@ print(json.dumps({"status": st, "core": c.cpu().double().numpy().ravel().tolist(
     outs = []
     for flag in ("1", "0"):
         env = dict(os.environ, NNF_NTD_PG_MULTI=flag)
-        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]))
     multi, single = outs

@@ -35,6 +35,16 @@ def allreduce_(t, group):
     return t
 
 
+def agree_int(value, group, device=None):
+    """Rank 0's `value` on every rank (a broadcast): quantities derived from the wall clock -- the sweep budget of
+    nnls.py:156,190-194 -- differ from rank to rank, and the replicated solves must take the same decisions."""
+    if group is None or dist.get_world_size(group) == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if hasattr(dist, "get_global_rank") else 0, group=group)
+    return int(t.item())
+
+
 def shard_rows(m, rank, nranks):
     """Contiguous row block [lo, hi) of rank `rank` (sizes differ by at most one)."""
     base, extra = divmod(m, nranks)

@@ -203,6 +203,11 @@ def _gram_on_side(ws, eng, A, out, start_from=None):
         return side.record_event(), copy
 
 
+def _sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize(dev)
+
+
 class _SolveTimedOut(Exception):
     """A persistent HALS solve gave up waiting for its other workgroups (status word 1)."""
 
@@ -389,7 +394,22 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
 HALS_INNER = {"maxiter": 100, "delta": 0.01}
 
 
-def _hals_call(eng, cross, gram, F, sparsity, normalize, deterministic, timer, status, safe=None):
+def _timed_budget(eng, cross, gram, F, sparsity, normalize, timer, group=None):
+    """Sweep budget of the wall-clock rule: rho = atime / btime with btime = the time of one sweep, measured on a scratch copy
+    (nnls.py:155,190-194), cnt <= 1 + 0.5 rho (nnls.py:156).  Row-sharded runs take rank 0's figure on every rank."""
+    from .update_rules.nnls import sweep_budget
+    probe = F.clone()
+    _sync(F.device)
+    t0 = time.time()
+    eng.hals_sweeps(cross, gram, probe, 1, sparsity=sparsity, normalize=normalize)
+    _sync(F.device)
+    btime = max(time.time() - t0, 10e-7)
+    rho = timer / btime if timer else 100000
+    budget = max(1, sweep_budget(HALS_INNER["maxiter"], 0.5, rho))
+    return _dist.agree_int(budget, group, F.device)
+
+
+def _hals_call(eng, cross, gram, F, sparsity, normalize, deterministic, timer, status, safe=None, group=None):
     """hals_nnls_acc(..., maxiter=100, atime=timer, alpha=inf|0.5, delta=0.01) of nmf.py:415-419,440-444, in place.
     `safe` (a dist.SweepGuess): the solve runs as chunked fixed-count launches whose workgroups never wait for each other
     (run_steps' fall-back after a persistent solve timed out); row normalisation needs the persistent kernel and cannot."""
@@ -401,15 +421,7 @@ def _hals_call(eng, cross, gram, F, sparsity, normalize, deterministic, timer, s
         status[:4] = torch.tensor([eps, cnt, eps0, 0.0], dtype=torch.float64)
         return status
     if not deterministic:
-        # wall-clock rule: rho = atime / btime with btime = time of one sweep (nnls.py:190-194)
-        probe = F.clone()
-        torch.cuda.synchronize(F.device)
-        t0 = time.time()
-        eng.hals_sweeps(cross, gram, probe, 1, sparsity=sparsity, normalize=normalize)
-        torch.cuda.synchronize(F.device)
-        btime = max(time.time() - t0, 10e-7)
-        rho = timer / btime if timer else 100000
-        budget = max(1, sweep_budget(HALS_INNER["maxiter"], 0.5, rho))
+        budget = _timed_budget(eng, cross, gram, F, sparsity, normalize, timer, group)
     return eng.hals_solve(cross, gram, F, budget, delta=HALS_INNER["delta"], sparsity=sparsity, normalize=normalize, nonzero=False,
                           status=status)
 
@@ -453,8 +465,9 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
     launched; with `skip_cost` the cost line is left to the caller (who overlaps it with the next V-side solve)."""
     sharded = _dist.world(group) > 1
     if sharded:
-        if update_rule == "hals" and (not deterministic or normalize[0]):
-            raise NotImplementedError("row-sharded HALS runs need deterministic=True and no U normalisation")
+        if update_rule == "hals" and normalize[0]:
+            raise NotImplementedError("row-sharded HALS runs cannot normalise the sharded factor (a grid-wide reduction per "
+                                      "row update across ranks)")
     if update_rule not in ["hals", "mu"]:
         raise err.InvalidArgumentValue(f"Invalid update rule: {update_rule}") from None
     if update_rule == "hals" and beta != 2:
@@ -470,19 +483,23 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
         if update_rule == "hals":
             timer = None
             if not deterministic:
-                torch.cuda.synchronize(dev)
+                _sync(dev)
                 t0 = time.time()
             done, Ut = _gram_on_side(ws, eng, V, ws.G, start_from=Ut_in)   # VVt (nmf.py:407); solve starts from U_in^T (:415)
             eng.xht(X, V, out=ws.VMt)                   # VMt  (nmf.py:408)
             if done is not None:
                 torch.cuda.current_stream(dev).wait_event(done)
             if not deterministic:
-                torch.cuda.synchronize(dev)
+                _sync(dev)
                 timer = time.time() - t0
             if before_u_solve is not None:
                 before_u_solve()
             ws.last_step_async = False
-            if sharded and hasattr(eng, "hals_stop_restore") and not ws.sync_next and ws.async_sharded and ws.async_ready:
+            budget_u = HALS_INNER["maxiter"]
+            if sharded and not deterministic:    # wall-clock rule (nnls.py:190-194): rank 0's budget on every rank
+                budget_u = _timed_budget(eng, ws.VMt, ws.G, Ut, sparsity_coefficients[0], False, timer, group)
+            if sharded and deterministic and hasattr(eng, "hals_stop_restore") and not ws.sync_next and ws.async_sharded \
+                    and ws.async_ready:
                 # no host round trip: blind chunk + all-reduce + device-side replay of the stopping rule; a missed guess
                 # shows in the status block and run_steps redoes the iteration through the branch below
                 _dist.sharded_hals_solve_async(eng, ws.VMt, ws.G, Ut, group, ws.guess_u, ws.block[8 * nstat:8 * nstat + 8],
@@ -491,7 +508,7 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                 ws.last_step_async = True
             elif sharded:
                 eps, cnt, eps0 = _dist.sharded_hals_solve(eng, ws.VMt, ws.G, Ut, group, ws.guess_u,
-                                                          budget=HALS_INNER["maxiter"], delta=HALS_INNER["delta"],
+                                                          budget=budget_u, delta=HALS_INNER["delta"],
                                                           sparsity=sparsity_coefficients[0])
                 ws.block[8 * nstat:8 * nstat + 4] = torch.tensor([eps, cnt, eps0, 0.0], dtype=torch.float64)
             else:
@@ -508,7 +525,7 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
         if update_rule == "hals":
             timer = None
             if not deterministic:
-                torch.cuda.synchronize(dev)
+                _sync(dev)
                 t0 = time.time()
             done, V = _gram_on_side(ws, eng, Ut, ws.G2, start_from=V_in)   # UtU (nmf.py:432); solve starts from V_in (:440)
             eng.xty(X, Ut, out=ws.UtM)                  # UtM  (nmf.py:433)
@@ -521,12 +538,13 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                     _dist.allreduce_(ws.G2, group)
                     _dist.allreduce_(ws.UtM, group)
             if not deterministic:
-                torch.cuda.synchronize(dev)
+                _sync(dev)
                 timer = time.time() - t0
             if before_v_solve is not None:
                 before_v_solve()
             _hals_call(eng, ws.UtM, ws.G2, V, sparsity_coefficients[1], normalize[1], deterministic, timer,
-                       ws.block[8 * nstat:8 * nstat + 8], safe=ws.guess_v if getattr(ws, "safe_solve", False) else None)
+                       ws.block[8 * nstat:8 * nstat + 8], safe=ws.guess_v if getattr(ws, "safe_solve", False) else None,
+                       group=group if sharded else None)
             nstat += 1
         else:
             if sharded:

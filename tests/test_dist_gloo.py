@@ -21,7 +21,7 @@ import nnfac_oracle as orc
 from engine_double import OracleEngine  # noqa: E402
 
 
-def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2, guess=(3, 5, 2)):
+def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2, guess=(3, 5, 2), deterministic=True):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=nranks)
     try:
@@ -45,7 +45,7 @@ def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2
             sweeps.extend(sw)
             return False
 
-        Ut, V = nmf_mod.run_steps(eng, ws, Xl, r, Ut, V, iters, rule, beta, sparsity, [], [False, False], True, retired,
+        Ut, V = nmf_mod.run_steps(eng, ws, Xl, r, Ut, V, iters, rule, beta, sparsity, [], [False, False], deterministic, retired,
                                   group=dist.group.WORLD)
         q.put((rank, lo, hi, Ut.numpy().T.copy(), V.numpy().copy(), costs, sweeps, (ws.async_hits, ws.async_misses)))
     finally:
@@ -308,3 +308,26 @@ def test_sharded_random_init_reproduces_the_reference_stream():
     assert np.array_equal(np.concatenate([b[0] for b in blocks]), U)
     assert all(torch.equal(blocks[0][2], b[2]) for b in blocks)                 # same V_0 on every rank
     assert not torch.equal(blocks[0][1][:10], blocks[1][1][:10])                # different row blocks
+
+
+def test_row_sharded_wall_clock_rule_agrees_across_ranks():
+    """deterministic=False (the reference's default: cnt <= 1 + alpha * atime / btime, nnls.py:156,190-194): the sweep budget
+    comes from the wall clock, which differs from rank to rank -- rank 0's figure is broadcast, so that the ranks run the same
+    sweeps and the replicated V stays bitwise identical.  Results are time dependent by design: only the agreement and the
+    descent are checked."""
+    m, n, r, iters, nranks = 211, 30, 5, 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(k, nranks, port, m, n, r, iters, [None, None], q, "hals", 2, (3, 5, 2), False))
+             for k in range(nranks)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(nranks))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][4], res[1][4])                      # V
+    assert res[0][6] == res[1][6] and res[0][5] == res[1][5]         # sweep counts, costs
+    costs = res[0][5]
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))

@@ -3,7 +3,8 @@
 The random branch reproduces the reference's legacy global NumPy stream bit for bit
 (initialize_factors.py:40-46,90-96): ``np.random.seed(seed); random.seed(seed); rand(m, r); rand(r, n)``.
 NNDSVD (initialize_factors.py:160-206) runs on the device: data of config-B/E size should not have
-to exist on the host.  Tucker (HOSVD) initialisers stay out of scope and raise.
+to exist on the host.  The Tucker initialiser (initialize_factors.py:68-81) restates tensorly 0.6.0's HOSVD + HOOI
+`tucker` on the device in float64.
 """
 import random
 
@@ -103,8 +104,51 @@ def ntf_initialization(tensor, rank, init_type, deterministic=False, seed=0):
     raise err.InvalidInitializationType("Initialization type not understood.")
 
 
+def _mode_dot_t(T, F, mode):
+    """T x_mode F^T for F of shape (n_mode, r): contracts mode `mode` of T with the rows of F."""
+    return torch.movedim(torch.tensordot(T, F, dims=([mode], [0])), -1, mode)
+
+
+def tucker_hooi(tensor, ranks, n_iter_max=100, tol=10e-5):
+    """tensorly.decomposition.tucker(tensor, ranks) of tensorly 0.6.0 (third party, setup.py:30) restated on the device in
+    float64: HOSVD start, then HOOI sweeps until the relative reconstruction error moves by less than tol (tested from the
+    third sweep on).  The leading left singular vectors of an unfolding come from `_thin_svd_top` (Gram route for the
+    strongly rectangular unfoldings of a big tensor).  Signs of singular vectors are arbitrary; the caller takes absolute
+    values.  NumPy in -> NumPy out; device tensor in -> device tensors (of the input dtype) out.
+    Checked against the oracle's tucker_hooi (itself pinned by NTD_tests.py:157-175,197-215) in tests/test_gpu_ntd.py."""
+    from .._convert import device_of
+    dev = device_of(tensor)
+    T = tensor.to(device=dev, dtype=torch.float64) if isinstance(tensor, torch.Tensor) else torch.from_numpy(
+        np.ascontiguousarray(tensor, dtype=np.float64)).to(dev)
+    N = T.dim()
+
+    def leading(X, mode):
+        unf = torch.movedim(X, mode, 0).reshape(X.shape[mode], -1)
+        return _thin_svd_top(unf, ranks[mode])[0].contiguous()
+    factors = [leading(T, m) for m in range(N)]
+    norm_t2 = float((T * T).sum())
+    errs = []
+    core = None
+    for it in range(n_iter_max):
+        for m in range(N):
+            approx = T
+            for i in range(N):
+                if i != m:
+                    approx = _mode_dot_t(approx, factors[i], i)
+            factors[m] = leading(approx, m)
+        core = T
+        for i in range(N):
+            core = _mode_dot_t(core, factors[i], i)
+        errs.append(np.sqrt(abs(norm_t2 - float((core * core).sum()))) / np.sqrt(norm_t2))
+        if it > 1 and abs(errs[-2] - errs[-1]) < tol:
+            break
+    if isinstance(tensor, torch.Tensor):
+        return core.to(tensor.dtype), [f.to(tensor.dtype) for f in factors]
+    return core.cpu().numpy(), [f.cpu().numpy() for f in factors]
+
+
 def ntd_initialization(tensor, ranks, init_type, deterministic=False, seed=0):
-    """initialize_factors.py:50-83; 'tucker' / 'chromas' need a Tucker decomposition (HOSVD), outside the hot path."""
+    """initialize_factors.py:50-83."""
     kind = init_type.lower()
     if kind == "random":
         factors = []
@@ -118,6 +162,13 @@ def ntd_initialization(tensor, ranks, init_type, deterministic=False, seed=0):
         the_core = np.random.rand(int(np.prod(ranks))).reshape(tuple(ranks))
         the_core[the_core < 1e-12] = 1e-12
         return the_core, factors
-    if kind in ("tucker", "chromas"):
-        raise NotImplementedError("tucker (HOSVD) initialisation is outside the accelerated hot path; pass init='custom'")
+    if kind == "tucker":        # :68-75 (tensorly's `random_state` only seeds ARPACK's start vector: the converged leading subspaces do not depend on it)
+        init_core, init_factors = tucker_hooi(tensor, list(ranks))
+        if isinstance(tensor, torch.Tensor):
+            return init_core.abs() + 1e-12, [f.abs() + 1e-12 for f in init_factors]
+        return np.abs(init_core) + 1e-12, [np.abs(f) + 1e-12 for f in init_factors]
+    if kind == "chromas":       # :77-80 -- Tucker where W is fixed to I12
+        core, factors = ntd_initialization(tensor, ranks, "tucker", deterministic=deterministic, seed=seed)
+        factors[0] = np.identity(12)
+        return core, factors
     raise err.InvalidInitializationType("Initialization type not understood.")

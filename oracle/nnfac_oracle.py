@@ -606,6 +606,41 @@ def random_tucker_full(shape, rank, seed):
     return multi_mode_dot(core, factors)
 
 
+def tucker_hooi(tensor, ranks, n_iter_max=100, tol=10e-5):
+    """tensorly.decomposition.tucker(tensor, ranks) of tensorly 0.6.0 (setup.py:30; THIRD-PARTY, not under /root/reference --
+    its published algorithm restated): higher-order SVD start (the leading left singular vectors of every unfolding), then
+    HOOI sweeps -- factor n := leading left singular vectors of unfold(tensor x_{i != n} F_i^T, n) -- until the relative
+    reconstruction error sqrt(|  ||T||^2 - ||core||^2  |) / ||T|| changes by less than tol = 10e-5 (checked from the third
+    sweep on) or n_iter_max = 100.  Singular vectors are defined up to sign; the only caller (ntd_initialization, 'tucker')
+    takes absolute values of core and factors, which removes the ambiguity.
+    PINNED by the reference's own known answers for init="tucker" (tests/NTD_tests.py:157-175 HALS, :197-215 MU beta=2) through
+    ntd_tucker_init + compute_ntd: tests/test_oracle_golden.py::test_tucker_init_known_answers (agreement ~1e-13)."""
+    N = tensor.ndim
+
+    def leading(M, k):
+        U, _, _ = np.linalg.svd(M, full_matrices=False)
+        return U[:, :k]
+    factors = [leading(unfold(tensor, m), ranks[m]) for m in range(N)]
+    norm_t = np.sqrt(np.sum(tensor ** 2))
+    errs = []
+    core = None
+    for it in range(n_iter_max):
+        for m in range(N):
+            approx = multi_mode_dot(tensor, factors, skip=m, transpose=True)
+            factors[m] = leading(unfold(approx, m), ranks[m])
+        core = multi_mode_dot(tensor, factors, transpose=True)
+        errs.append(np.sqrt(abs(norm_t ** 2 - np.sum(core ** 2))) / norm_t)
+        if it > 1 and abs(errs[-2] - errs[-1]) < tol:
+            break
+    return core, factors
+
+
+def ntd_tucker_init(tensor, ranks):
+    """initialize_factors.py:68-75 ('tucker'): |core| + 1e-12, |factors| + 1e-12 of tl_tucker(tensor, ranks)."""
+    core, factors = tucker_hooi(tensor, list(ranks))
+    return np.abs(core) + 1e-12, [np.abs(f) + 1e-12 for f in factors]
+
+
 def ntd_random_init(shape, ranks, seed):
     """initialize_factors.py:53-66 with deterministic=True (np.random.seed(seed); random.seed has no effect here)."""
     np.random.seed(seed)

@@ -157,6 +157,69 @@ def test_ntd_on_the_reference_test_problem(golden, rule, beta):
         np.testing.assert_allclose(costs, want, rtol=1e-4)
 
 
+def test_tucker_hooi_against_the_oracle():
+    """The device HOSVD + HOOI (utils/initialize_factors.tucker_hooi, fp64) against the oracle's restatement of tensorly's
+    tucker, compared after the absolute values the only caller takes (signs of singular vectors are arbitrary)."""
+    from nn_fac_amd.utils.initialize_factors import tucker_hooi
+    from test_oracle_golden import ntd_reference_tensor, NTD_TESTS_SHAPE, NTD_TESTS_RANKS
+    cases = [(ntd_reference_tensor(NTD_TESTS_SHAPE, NTD_TESTS_RANKS), list(NTD_TESTS_RANKS)),
+             (np.random.RandomState(3).rand(12, 9, 8, 7), [3, 4, 2, 3]),
+             (np.random.RandomState(4).rand(400, 6, 5), [4, 3, 2])]          # Gram route of the thin SVD (400 >> 30)
+    for T, ranks in cases:
+        want_c, want_f = orc.tucker_hooi(T, ranks)
+        got_c, got_f = tucker_hooi(T, ranks)
+        assert rel(np.abs(got_c), np.abs(want_c)) < 1e-8
+        for a, b in zip(got_f, want_f):
+            assert rel(np.abs(a), np.abs(b)) < 1e-8
+        tc, tf = tucker_hooi(torch.tensor(T, dtype=torch.float32, device="cuda"), ranks)      # device in -> device out
+        assert tc.is_cuda and tc.dtype == torch.float32 and rel(tc.abs().cpu().numpy(), np.abs(want_c)) < 1e-4
+
+
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 2)])
+def test_ntd_tucker_init_known_answers(rule, beta):
+    """ntd(init="tucker") on the reference's test problem against the reference's literal known answers
+    (NTD_tests.py:157-175 HALS, :197-215 MU beta=2) at the file's fp32 tolerances, and against the oracle's full outputs."""
+    from nn_fac_amd.ntd import ntd
+    from test_oracle_golden import ntd_reference_tensor, NTD_TESTS_SHAPE, NTD_TESTS_RANKS, TUCKER_INIT_KNOWN
+    T, ranks = ntd_reference_tensor(NTD_TESTS_SHAPE, NTD_TESTS_RANKS), list(NTD_TESTS_RANKS)
+    core, facs, costs, toc = ntd(T, list(ranks), init="tucker", n_iter_max=10, tol=1e-8, update_rule=rule, beta=beta,
+                                 sparsity_coefficients=[None] * 4, fixed_modes=[], normalize=[False] * 4, verbose=False,
+                                 return_costs=True, deterministic=True, seed=0)
+    c0, f0 = orc.ntd_tucker_init(T, ranks)
+    wc, wf, wcosts, _ = orc.compute_ntd(T, ranks, c0, f0, n_iter_max=10, tol=1e-8, update_rule=rule, beta=beta,
+                                        sparsity_coefficients=[None] * 4, normalize=[False] * 4, return_costs=True,
+                                        deterministic=True)
+    tol = 1e-3 if rule == "hals" else 1e-4
+    assert rel(core, wc) < tol
+    for i in range(3):
+        assert rel(facs[i], wf[i]) < tol
+    k = TUCKER_INIT_KNOWN[(rule, beta)]
+    got = (facs[0][0][0], facs[1][0][0], facs[2][0][0], core[0, 0, 0])
+    for a, b in zip(got, k[:4]):
+        assert abs(a - b) <= 10 * tol * abs(b)
+    if rule == "hals":
+        assert len(costs) == len(wcosts)
+        np.testing.assert_allclose(costs, wcosts, rtol=0, atol=2e-6)
+        assert abs(costs[0] - k[4]) < 2e-6 and abs(costs[-1] - k[5]) < 2e-6
+    else:
+        np.testing.assert_allclose(costs, wcosts, rtol=1e-4)
+        assert abs(costs[0] - k[4]) < 1e-4 * k[4] and abs(costs[-1] - k[5]) < 1e-4 * k[5]
+
+
+def test_ntd_chromas_init_fixes_identity_first_factor():
+    """initialize_factors.py:77-80 + ntd.py:240-241: Tucker start, W = I12 and mode 0 fixed."""
+    from nn_fac_amd.ntd import ntd
+    T = np.random.RandomState(5).rand(12, 10, 9)
+    core, facs = ntd(T, [12, 4, 3], init="chromas", n_iter_max=3, tol=1e-8, sparsity_coefficients=[None] * 4,
+                     fixed_modes=[], normalize=[False] * 4, deterministic=True, seed=0)
+    np.testing.assert_array_equal(np.asarray(facs[0]), np.identity(12))
+    c0, f0 = orc.ntd_tucker_init(T, [12, 4, 3])
+    f0[0] = np.identity(12)
+    wc, wf = orc.compute_ntd(T, [12, 4, 3], c0, f0, n_iter_max=3, tol=1e-8, sparsity_coefficients=[None] * 4,
+                             fixed_modes=[0], normalize=[False] * 4, deterministic=True)
+    assert rel(core, wc) < 1e-3 and rel(facs[1], wf[1]) < 1e-3 and rel(facs[2], wf[2]) < 1e-3
+
+
 def test_ntd_argument_errors():
     """Raise sites of ntd.py:213,228,232,234 and initialize_factors.py:83."""
     from nn_fac_amd.ntd import ntd

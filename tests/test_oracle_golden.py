@@ -270,3 +270,29 @@ def test_oracle_deep_nmf_matches_reference(golden):
         np.testing.assert_allclose(W[i], g[f"ml_W_{i}"], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(H[i], g[f"ml_H_{i}"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(rec, g["ml_errors"], rtol=1e-9, equal_nan=True)
+
+
+# ---- Tucker (HOSVD + HOOI) initialiser of NTD: pinned by the reference's own known answers for init="tucker" ----
+NTD_TESTS_SHAPE, NTD_TESTS_RANKS = (53, 85, 82), (9, 9, 3)      # what NTD_tests.py:18-21 draws with random.seed(0)
+
+
+TUCKER_INIT_KNOWN = {   # (factors[0][0][0], factors[1][0][0], factors[2][0][0], core[0,0,0], cost[0], cost[-1])
+    ("hals", 2): (0.16504481330298995, 0.09847086272185894, 0.11680262111792158, 11039.862648258559,
+                  0.00027083233922590056, 0.00010638116104305596),          # NTD_tests.py:168-175
+    ("mu", 2): (0.1633567459395657, 0.09484478066313659, 0.1174295516693132, 11046.430317228587,
+                22653.665491321422, 21679.048477120345),                    # NTD_tests.py:208-215
+}
+
+
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 2)])
+def test_tucker_init_known_answers(rule, beta):
+    """ntd(init="tucker", n_iter_max=10, tol=1e-8, deterministic=True, seed=0) of the reference's tests (NTD_tests.py:157-175,
+    197-215), through the restated tensorly tucker (oracle tucker_hooi) + the oracle's NTD loop: assertAlmostEqual precision."""
+    T, ranks = ntd_reference_tensor(NTD_TESTS_SHAPE, NTD_TESTS_RANKS), list(NTD_TESTS_RANKS)
+    c0, f0 = orc.ntd_tucker_init(T, ranks)
+    core, F, costs, _ = orc.compute_ntd(T, ranks, c0, f0, n_iter_max=10, tol=1e-8, update_rule=rule, beta=beta,
+                                        sparsity_coefficients=[None] * 4, normalize=[False] * 4, return_costs=True,
+                                        deterministic=True)
+    got = (F[0][0][0], F[1][0][0], F[2][0][0], core[0, 0, 0], costs[0], costs[-1])
+    for a, b in zip(got, TUCKER_INIT_KNOWN[(rule, beta)]):
+        assert abs(a - b) <= 5e-8 * max(1.0, abs(b)), (got, TUCKER_INIT_KNOWN[(rule, beta)])

@@ -263,6 +263,7 @@ def test_hals_fixed_sweeps_mode(eng, layout, monkeypatch):
 
 
 MU_SHAPES = [(200, 100, 10), (73, 25, 9), (1000, 260, 50), (513, 130, 33), (300, 7, 3), (5, 300, 2), (2000, 500, 64),
+             (260, 150, 18), (640, 200, 49), (333, 77, 17), (900, 300, 52),   # 16q+1..2 ranks: leftover ranks on the VALU pipe
              (700, 333, 65), (1500, 400, 100), (300, 200, 128)]     # r > 64: ratio kernel + plain contractions
 
 
@@ -282,6 +283,30 @@ def test_mu_and_betadiv_kernels(eng, m, n, r, beta):
     want = orc.beta_divergence(X32, U32 @ V32, beta)
     got = float(eng.betadiv(Xd, Utd, Vd, beta))
     assert abs(got - want) <= 2e-5 * abs(want)
+
+
+@pytest.mark.parametrize("r", [50, 40, 18])
+@pytest.mark.parametrize("beta", [1, 1.5])
+def test_mu_kernels_never_use_the_padding_between_rows(eng, r, beta):
+    """Factors and data handed over as row-strided views whose padding holds NaN (the chunk images of the fused kernels are
+    staged through a buffer resource that spans whole rows: columns past the matrix must be masked, 0 * NaN otherwise)."""
+    m, n = 333, 203
+    rng = np.random.RandomState(r)
+
+    def padded(a, pad):
+        t = torch.full((a.shape[0], a.shape[1] + pad), float("nan"), dtype=torch.float32, device="cuda")
+        t[:, :a.shape[1]] = torch.tensor(a, dtype=torch.float32)
+        return t[:, :a.shape[1]]
+    U, V = rng.rand(m, r) + 0.05, rng.rand(r, n) + 0.05
+    X = rng.rand(m, r) @ rng.rand(r, n) + 0.05
+    for pad in (4, 5):                  # 16-byte aligned rows and not
+        Xp, Utp, Vp = padded(X, pad), padded(U.T.copy(), pad), padded(V, pad)
+        gotU = eng.mu_left(Xp, Utp, Vp, beta).cpu().numpy()
+        gotV = eng.mu_right(Xp, Utp, Vp, beta).cpu().numpy()
+        wantU = eng.mu_left(dev(X), dev(U.T), dev(V), beta).cpu().numpy()
+        wantV = eng.mu_right(dev(X), dev(U.T), dev(V), beta).cpu().numpy()
+        assert np.isfinite(gotU).all() and np.isfinite(gotV).all()
+        assert rel(gotU, wantU) < 1e-6 and rel(gotV, wantV) < 1e-6
 
 
 @pytest.mark.parametrize("m", [98304, 100000, 131072, 131100])

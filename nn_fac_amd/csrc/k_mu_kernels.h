@@ -131,6 +131,9 @@ __device__ __forceinline__ bool mu_kstep_on(int s4, int c, int KS, bool tail4) {
     else return 4 * s4 + c < KS;
 }
 
+#ifndef MU_WG_PER_CU
+#define MU_WG_PER_CU 2
+#endif
 #ifndef MU_STEP_FENCE
 #define MU_STEP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -163,7 +166,7 @@ __device__ __forceinline__ void mu_elem(float x, float p, float beta, float& r1,
 // groups at the end.  For rank 50 that is 48 + 48 MFMAs + 64 FMAs per 16 x 64 block instead of 56 + 64 MFMAs (fp32 MFMA and
 // fp32 FMA share one pipe: 2048 flops in 32 cycles either way), and 40 fewer registers: no spills at two workgroups per CU.
 template <int MT, int REM, int BM, bool VEC>
-__global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_right_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+__global__ __launch_bounds__(256, (BM == BM_KL ? MU_WG_PER_CU : 1)) void nnf_mu_right_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                               const float* __restrict__ Ut, int64_t ldu,
                                                               const float* __restrict__ V, int64_t ldv, int r, float beta,
                                                               float* __restrict__ snum, float* __restrict__ sden,
@@ -253,6 +256,114 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_right_kerne
     }
     __syncthreads();
 
+    // element-wise phase of one 16-row group: R = op(X, P), masked past the split's last row (0/0 otherwise)
+    auto elementwise = [&](const f32x4 (&x)[4], const f32x4 (&accP)[4], int rowrem, f32x4 (&R1)[4],
+                           f32x4 (&R2)[BM == BM_GEN ? 4 : 1]) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float r1, r2;
+                mu_elem<BM>(x[reg][cc], accP[cc][reg], beta, r1, r2);
+                const bool ok = reg < rowrem;
+                R1[cc][reg] = ok ? r1 : 0.f;
+                if constexpr (BM == BM_GEN) R2[cc][reg] = ok ? r2 : 0.f;
+            }
+    };
+
+    if constexpr (REGF) {
+        // ---- resident fragments in registers: every LDS read of the chunk images is issued by hand, one phase early ----
+        // per 16-row group t:   [uv, ak of t in flight]  seed P from the leftover ranks | MFMA #1 (ak) | issue af |
+        //                       element-wise, leftover numerator rows | issue uv, ak of t+1 | MFMA #2 (af) | refill X
+        constexpr int UVT = MT >= 2 ? MT - 2 : 0;   // MFMA #2 tile after which the next group's leftover-rank rows are read
+        const unsigned kbase = nnf_lds_addr(ldsK) + (unsigned)lane * 16u;
+        const unsigned abase = nnf_lds_addr(ldsA) + (unsigned)lane * 16u;
+        const unsigned ubase = nnf_lds_addr(ldsA) + (unsigned)g * 256u;      // lanes of a row group share one address
+        for (int q = 0; q < nchunk; ++q) {
+            const unsigned kb = kbase + (unsigned)(q & 1) * (MT * 4096u);
+            const unsigned ab = abase + (unsigned)(q & 1) * (MTA * 4096u);
+            const unsigned ub = ubase + (unsigned)(q & 1) * (MTA * 4096u);
+            f32x4 sa[MTA], sk[MT];
+            stageA_bload<MTA>(stg, i_end, i_begin + 64 * (int64_t)(q + 1), a_vec_ok, sa);
+            const int soff_q = q * 64 * ldx4;
+            const int64_t left64 = (i_end - i_begin) - 64 * (int64_t)q;
+            const int rows_left = left64 > 64 ? 64 : (int)left64;          // rows of this chunk inside the split
+            f32x4 ak[MT], af[MT], uv[NR];
+            nnf_static_for<0, REM>([&](auto rr) { nnf_lds_read4<(MT * 4 + 0) * 1024 + rr * 16>(uv[rr], ub); });
+            nnf_static_for<0, MT>([&](auto s4) { nnf_lds_read4<(0 * MT + s4) * 1024>(ak[s4], kb); });
+            nnf_static_for<0, 4>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                f32x4 accP[4];
+                if constexpr (REM > 0) {
+                    nnf_lds_wait<(t == 0 ? MT : MT - 1 - UVT), REM>(uv);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {   // (scalar FMAs: a packed form keeps a splat pair per V value)
+                            float p0 = uv[0][reg] * vrem[0][cc];
+#pragma unroll
+                            for (int rr = 1; rr < REM; ++rr) p0 = fmaf(uv[rr][reg], vrem[rr][cc], p0);
+                            accP[cc][reg] = p0;
+                        }
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) accP[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                nnf_static_for<0, MT>([&](auto s4c) {
+                    constexpr int s4 = decltype(s4c)::value;
+                    nnf_lds_wait<MT - 1 - s4, 1>(&ak[s4]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (mu_kstep_on<MT, true>(s4, c, KS, tail4)) {
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) accP[cc] = MFMA16(ak[s4][c], vfr[4 * s4 + c][cc], accP[cc]);
+                        }
+                    }
+                });
+                nnf_static_for<0, MT>([&](auto mt) { nnf_lds_read4<(mt * 4 + t) * 1024>(af[mt], ab); });
+                const int rowrem = rows_left - 16 * t - 4 * g;
+                f32x4 R1[4], R2[1];
+                elementwise(xb[t & 1], accP, rowrem, R1, R2);
+                if constexpr (REM > 0) {
+#pragma unroll
+                    for (int rr = 0; rr < REM; ++rr)
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) ev[rr][cc] = fmaf(uv[rr][reg], R1[cc][reg], ev[rr][cc]);
+                    // finish the chains HERE: left alone, LLVM sinks them (and every R they consume) to the end of the chunk
+#pragma unroll
+                    for (int rr = 0; rr < REM; ++rr) asm volatile("" : "+v"(ev[rr]));
+                }
+                // MFMA #2: num[rk][j] += Ut[rk][i] * R[i][j], k = the block's 16 rows; tile by tile, and the K-image read of
+                // the next group's rank tile mt goes out as soon as af[mt] is done with (its registers are free again; the
+                // accumulator rides through so that the read stays behind this tile's MFMAs).  The leftover-rank rows of the
+                // next group follow the last tile but one: 16 MFMAs cover their latency, and they are live for those only.
+                nnf_static_for<0, MT>([&](auto mtc) {
+                    constexpr int mt = decltype(mtc)::value;
+                    nnf_lds_wait<(t < 3 ? MT - 1 + (mt > UVT ? REM : 0) : MT - 1 - mt), 1>(&af[mt]);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) num[mt][cc] = MFMA16(af[mt][reg], R1[cc][reg], num[mt][cc]);
+                    if constexpr (t < 3) {
+                        nnf_lds_read4_after<((t + 1) * MT + mt) * 1024>(ak[mt], kb, num[mt][3]);
+                        if constexpr (mt == UVT)
+                            nnf_static_for<0, REM>([&](auto rr) { nnf_lds_read4<(MT * 4 + t + 1) * 1024 + rr * 16>(uv[rr], ub); });
+                    }
+                });
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xb[t & 1][c] = nnf_bload4<VEC>(rs, voff, soff_q + (16 * (t + 2) + c) * ldx4);
+                // next chunk's images: A loaded at the top of the chunk and written here in group 1, K loaded in group 2 and
+                // written after group 3 -- the fences between the groups keep the two staging sets from being live together
+                if constexpr (t == 1) stageA_store<MTA>(ldsA + (size_t)((q + 1) & 1) * MTA * 256, sa);
+                if constexpr (t == 2) stageK_bload<MT>(stg, i_end, i_begin + 64 * (int64_t)(q + 1), sk);
+                MU_STEP_FENCE();
+            });
+            stageK_store<MT>(ldsK + (size_t)((q + 1) & 1) * MT * 256, sk);
+            __syncthreads();
+        }
+    } else {
     for (int q = 0; q < nchunk; ++q) {
         const f32x4* imgA = ldsA + (size_t)(q & 1) * MTA * 256;
         const f32x4* imgK = ldsK + (size_t)(q & 1) * MT * 256;
@@ -266,48 +377,24 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_right_kerne
         for (int t = 0; t < 4; ++t) {
             // MFMA #1: P[i0+16t+4g+reg][jw+4jj+cc]
             f32x4 accP[4];
-            f32x4 uv[NR];     // REM: Ut[16MT+rr][rows 16t+4g .. +3] (one LDS address per row group: broadcast)
-            if constexpr (REM > 0) {
 #pragma unroll
-                for (int rr = 0; rr < REM; ++rr) uv[rr] = imgA[(MT * 4 + t) * 64 + 16 * g + rr];
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    accP[cc] = uv[0] * vrem[0][cc];
-#pragma unroll
-                    for (int rr = 1; rr < REM; ++rr)
-                        accP[cc] = __builtin_elementwise_fma(uv[rr], f32x4{vrem[rr][cc], vrem[rr][cc], vrem[rr][cc], vrem[rr][cc]}, accP[cc]);
-                }
-            } else {
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) accP[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int cc = 0; cc < 4; ++cc) accP[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s4 = 0; s4 < MT; ++s4) {
                 const f32x4 ak = imgK[(t * MT + s4) * 64 + lane];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (mu_kstep_on<MT, REGF>(s4, c, KS, tail4)) {
-                        f32x4 bv;
-                        if constexpr (REGF) bv = vfr[4 * s4 + c];
-                        else bv = ldsVf[(size_t)w * KS * 64 + (4 * s4 + c) * 64 + lane];
+                    if (4 * s4 + c < KS) {
+                        const f32x4 bv = ldsVf[(size_t)w * KS * 64 + (4 * s4 + c) * 64 + lane];
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc) accP[cc] = MFMA16(ak[c], bv[cc], accP[cc]);
                     }
                 }
             }
-            // element-wise, masked past the split's last row (0/0 otherwise)
-            const int64_t rowrem = (i_end - i_begin) - (64 * (int64_t)q + 16 * t + 4 * g);
+            const int64_t left64 = (i_end - i_begin) - 64 * (int64_t)q;
+            const int rowrem = (left64 > 64 ? 64 : (int)left64) - 16 * t - 4 * g;
             f32x4 R1[4], R2[BM == BM_GEN ? 4 : 1];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    float r1, r2;
-                    mu_elem<BM>(xb[t & 1][reg][cc], accP[cc][reg], beta, r1, r2);
-                    const bool ok = reg < rowrem;
-                    R1[cc][reg] = ok ? r1 : 0.f;
-                    if constexpr (BM == BM_GEN) R2[cc][reg] = ok ? r2 : 0.f;
-                }
+            elementwise(xb[t & 1], accP, rowrem, R1, R2);
             // MFMA #2: num[rk][j] += Ut[rk][i] * R[i][j], k = the block's 16 rows
             f32x4 af[MT];
 #pragma unroll
@@ -321,27 +408,15 @@ __global__ __launch_bounds__(256, (BM == BM_KL ? 2 : 1)) void nnf_mu_right_kerne
                         num[mt][cc] = MFMA16(af[mt][reg], R1[cc][reg], num[mt][cc]);
                         if constexpr (BM == BM_GEN) den[mt][cc] = MFMA16(af[mt][reg], R2[cc][reg], den[mt][cc]);
                     }
-            if constexpr (REM > 0) {
-#pragma unroll
-                for (int rr = 0; rr < REM; ++rr)
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) ev[rr][cc] = fmaf(uv[rr][reg], R1[cc][reg], ev[rr][cc]);
-                // finish the chains HERE: left alone, LLVM sinks them (and every R they consume) to the end of the chunk
-#pragma unroll
-                for (int rr = 0; rr < REM; ++rr) asm volatile("" : "+v"(ev[rr]));
-            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) xb[t & 1][c] = nnf_bload4<VEC>(rs, voff, soff_q + (16 * (t + 2) + c) * ldx4);
-            if (t == 1) {
-                stageA_store<MTA>(ldsA + (size_t)((q + 1) & 1) * MTA * 256, sa);
-                stageK_bload<MT>(stg, i_end, i_begin + 64 * (int64_t)(q + 1), sk);
-            }
+            if (t == 1) stageA_store<MTA>(ldsA + (size_t)((q + 1) & 1) * MTA * 256, sa);
+            if (t == 2) stageK_bload<MT>(stg, i_end, i_begin + 64 * (int64_t)(q + 1), sk);
             MU_STEP_FENCE();
         }
         stageK_store<MT>(ldsK + (size_t)((q + 1) & 1) * MT * 256, sk);
         __syncthreads();
+    }
     }
     if (jl < ldp) {
         float* sn = snum + (int64_t)ks * r * ldp;
@@ -488,6 +563,122 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
     }
     __syncthreads();
 
+    // element-wise phase of one 16-column group: R = op(X, P) (+ this group's share of the cost), masked outside the matrix
+    auto elementwise = [&](const f32x4 (&x)[4], const f32x4 (&accP)[4], int colrem, f32x4 (&R1)[4],
+                           f32x4 (&R2)[BM == BM_GEN ? 4 : 1]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const bool rowok = (16 * nt + ii) < rows;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float r1, r2;
+                mu_elem<BM>(x[nt][reg], accP[nt][reg], beta, r1, r2);
+                const bool ok = rowok && (reg < colrem);
+                if constexpr (BM == BM_FROB) {
+                    const float dd = ok ? (x[nt][reg] - accP[nt][reg]) : 0.f;
+                    csum = fmaf(dd, dd, csum);
+                }
+                if constexpr (BM == BM_KLC) {   // beta_divergence(X, UV, 1) of the factors this update starts from
+                    const float term = nnf_cost_term<NNF_COST_KL>(x[nt][reg], accP[nt][reg], 1.f);
+                    csum += ok ? term : 0.f;
+                }
+                R1[nt][reg] = ok ? r1 : 0.f;
+                if constexpr (BM == BM_GEN) R2[nt][reg] = ok ? r2 : 0.f;
+            }
+            // finish this tile's share of the sum HERE: left alone, LLVM sinks the whole dependent chain of a chunk (and the
+            // differences it consumes) to the chunk's last block -- 256 VGPRs + spills instead of ~180; the divergence term
+            // (a 12-term series and a logarithm per entry) is kept to one tile's worth of temporaries the same way
+            if constexpr (BM == BM_KLC) asm volatile("" : "+v"(csum));
+        }
+        if constexpr (BM == BM_FROB) asm volatile("" : "+v"(csum));
+    };
+
+    if constexpr (REGF) {
+        // ---- hand-issued LDS reads, one phase early: same schedule as the right kernel (see there) ----
+        constexpr int UVT = MT >= 2 ? MT - 2 : 0;
+        const unsigned kbase = nnf_lds_addr(ldsK) + (unsigned)lane * 16u;
+        const unsigned abase = nnf_lds_addr(ldsA) + (unsigned)lane * 16u;
+        const unsigned ubase = nnf_lds_addr(ldsA) + (unsigned)g * 256u;      // lanes of a column group share one address
+        for (int q = 0; q < nchunk; ++q) {
+            const unsigned kb = kbase + (unsigned)(q & 1) * (MT * 4096u);
+            const unsigned ab = abase + (unsigned)(q & 1) * (MTA * 4096u);
+            const unsigned ub = ubase + (unsigned)(q & 1) * (MTA * 4096u);
+            f32x4 sa[MTA], sk[MT];
+            stageA_bload<MTA>(stg, n, 64 * (int64_t)(q + 1), a_vec_ok, sa);
+            const int64_t left64 = n - 64 * (int64_t)q;
+            const int cols_left = left64 > 64 ? 64 : (int)left64;            // columns of this chunk inside the matrix
+            f32x4 ak[MT], af[MT], vv[NR];
+            nnf_static_for<0, REM>([&](auto rr) { nnf_lds_read4<(MT * 4 + 0) * 1024 + rr * 16>(vv[rr], ub); });
+            nnf_static_for<0, MT>([&](auto s4) { nnf_lds_read4<(0 * MT + s4) * 1024>(ak[s4], kb); });
+            nnf_static_for<0, 4>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                // MFMA #1 (transposed product): accP[nt][reg] = P[i0w+16nt+ii][64q+16t+4g+reg], seeded with the leftover ranks
+                f32x4 accP[4];
+                if constexpr (REM > 0) {
+                    nnf_lds_wait<(t == 0 ? MT : MT - 1 - UVT), REM>(vv);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            float p0 = vv[0][reg] * urem[0][nt];
+#pragma unroll
+                            for (int rr = 1; rr < REM; ++rr) p0 = fmaf(vv[rr][reg], urem[rr][nt], p0);
+                            accP[nt][reg] = p0;
+                        }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) accP[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                nnf_static_for<0, MT>([&](auto s4c) {
+                    constexpr int s4 = decltype(s4c)::value;
+                    nnf_lds_wait<MT - 1 - s4, 1>(&ak[s4]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (mu_kstep_on<MT, true>(s4, c, KS, tail4)) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) accP[nt] = MFMA16(ak[s4][c], ufr[4 * s4 + c][nt], accP[nt]);
+                        }
+                    }
+                });
+                nnf_static_for<0, MT>([&](auto mt) { nnf_lds_read4<(mt * 4 + t) * 1024>(af[mt], ab); });
+                const int colrem = cols_left - 16 * t - 4 * g;
+                f32x4 R1[4], R2[1];
+                elementwise(xb[t & 1], accP, colrem, R1, R2);
+                if constexpr (REM > 0) {
+#pragma unroll
+                    for (int rr = 0; rr < REM; ++rr)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) ev[rr][nt] = fmaf(vv[rr][reg], R1[nt][reg], ev[rr][nt]);
+#pragma unroll
+                    for (int rr = 0; rr < REM; ++rr) asm volatile("" : "+v"(ev[rr]));   // (see the right kernel)
+                }
+                // MFMA #2: num[rk][i] += V[rk][j] * R[j][i], k = the block's 16 columns; tile by tile (see the right kernel)
+                nnf_static_for<0, MT>([&](auto mtc) {
+                    constexpr int mt = decltype(mtc)::value;
+                    nnf_lds_wait<(t < 3 ? MT - 1 + (mt > UVT ? REM : 0) : MT - 1 - mt), 1>(&af[mt]);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) num[mt][nt] = MFMA16(af[mt][reg], R1[nt][reg], num[mt][nt]);
+                    if constexpr (t < 3) {
+                        nnf_lds_read4_after<((t + 1) * MT + mt) * 1024>(ak[mt], kb, num[mt][NT - 1]);
+                        if constexpr (mt == UVT)
+                            nnf_static_for<0, REM>([&](auto rr) { nnf_lds_read4<(MT * 4 + t + 1) * 1024 + rr * 16>(vv[rr], ub); });
+                    }
+                });
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    xb[t & 1][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * q + 64 * (t + 2));
+                if constexpr (t == 1) stageA_store<MTA>(ldsA + (size_t)((q + 1) & 1) * MTA * 256, sa);
+                if constexpr (t == 2) stageK_bload<MT>(stg, n, 64 * (int64_t)(q + 1), sk);
+                MU_STEP_FENCE();
+            });
+            stageK_store<MT>(ldsK + (size_t)((q + 1) & 1) * MT * 256, sk);
+            __syncthreads();
+        }
+    } else {
     for (int q = 0; q < nchunk; ++q) {
         const f32x4* imgA = ldsA + (size_t)(q & 1) * MTA * 256;
         const f32x4* imgK = ldsK + (size_t)(q & 1) * MT * 256;
@@ -497,60 +688,24 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
         for (int t = 0; t < 4; ++t) {
             // MFMA #1 (transposed product): accP[nt][reg] = P[i0w+16nt+ii][64q+16t+4g+reg]
             f32x4 accP[4];
-            f32x4 vv[NR];     // REM: V[16MT+rr][columns 64q+16t+4g .. +3] (one LDS address per column group: broadcast)
-            if constexpr (REM > 0) {
 #pragma unroll
-                for (int rr = 0; rr < REM; ++rr) vv[rr] = imgA[(MT * 4 + t) * 64 + 16 * g + rr];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    accP[nt] = vv[0] * urem[0][nt];
-#pragma unroll
-                    for (int rr = 1; rr < REM; ++rr)
-                        accP[nt] = __builtin_elementwise_fma(vv[rr], f32x4{urem[rr][nt], urem[rr][nt], urem[rr][nt], urem[rr][nt]}, accP[nt]);
-                }
-            } else {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) accP[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int nt = 0; nt < NT; ++nt) accP[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s4 = 0; s4 < MT; ++s4) {
                 const f32x4 ak = imgK[(t * MT + s4) * 64 + lane];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (mu_kstep_on<MT, REGF>(s4, c, KS, tail4)) {
-                        f32x4 bu;
-                        if constexpr (REGF) bu = ufr[4 * s4 + c];
-                        else bu = ldsUf[(size_t)w * KS * 64 + (4 * s4 + c) * 64 + lane];
+                    if (4 * s4 + c < KS) {
+                        const f32x4 bu = ldsUf[(size_t)w * KS * 64 + (4 * s4 + c) * 64 + lane];
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) accP[nt] = MFMA16(ak[c], bu[nt], accP[nt]);
                     }
                 }
             }
-            const int64_t colrem = n - (64 * (int64_t)q + 16 * t + 4 * g);
+            const int64_t left64 = n - 64 * (int64_t)q;
+            const int colrem = (left64 > 64 ? 64 : (int)left64) - 16 * t - 4 * g;
             f32x4 R1[4], R2[BM == BM_GEN ? 4 : 1];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const bool rowok = (16 * nt + ii) < rows;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    float r1, r2;
-                    mu_elem<BM>(xb[t & 1][nt][reg], accP[nt][reg], beta, r1, r2);
-                    const bool ok = rowok && (reg < colrem);
-                    if constexpr (BM == BM_FROB) {
-                        const float dd = ok ? (xb[t & 1][nt][reg] - accP[nt][reg]) : 0.f;
-                        csum = fmaf(dd, dd, csum);
-                    }
-                    if constexpr (BM == BM_KLC) {   // beta_divergence(X, UV, 1) of the factors this update starts from
-                        const float term = nnf_cost_term<NNF_COST_KL>(xb[t & 1][nt][reg], accP[nt][reg], 1.f);
-                        csum += ok ? term : 0.f;
-                    }
-                    R1[nt][reg] = ok ? r1 : 0.f;
-                    if constexpr (BM == BM_GEN) R2[nt][reg] = ok ? r2 : 0.f;
-                }
-            }
-            // finish this group's residual sum HERE: left alone, LLVM sinks the whole dependent chain of a chunk (and the 48
-            // differences it consumes) to the chunk's last block -- 256 VGPRs + spills instead of ~180
-            if constexpr (BM == BM_FROB || BM == BM_KLC) asm volatile("" : "+v"(csum));
+            elementwise(xb[t & 1], accP, colrem, R1, R2);
             // MFMA #2: num[rk][i] += V[rk][j] * R[j][i], k = the block's 16 columns
             f32x4 af[MT];
 #pragma unroll
@@ -564,27 +719,16 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                         num[mt][nt] = MFMA16(af[mt][reg], R1[nt][reg], num[mt][nt]);
                         if constexpr (BM == BM_GEN) den[mt][nt] = MFMA16(af[mt][reg], R2[nt][reg], den[mt][nt]);
                     }
-            if constexpr (REM > 0) {
-#pragma unroll
-                for (int rr = 0; rr < REM; ++rr)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) ev[rr][nt] = fmaf(vv[rr][reg], R1[nt][reg], ev[rr][nt]);
-#pragma unroll
-                for (int rr = 0; rr < REM; ++rr) asm volatile("" : "+v"(ev[rr]));   // (see the right kernel)
-            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 xb[t & 1][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * q + 64 * (t + 2));
-            if (t == 1) {
-                stageA_store<MTA>(ldsA + (size_t)((q + 1) & 1) * MTA * 256, sa);
-                stageK_bload<MT>(stg, n, 64 * (int64_t)(q + 1), sk);
-            }
+            if (t == 1) stageA_store<MTA>(ldsA + (size_t)((q + 1) & 1) * MTA * 256, sa);
+            if (t == 2) stageK_bload<MT>(stg, n, 64 * (int64_t)(q + 1), sk);
             MU_STEP_FENCE();
         }
         stageK_store<MT>(ldsK + (size_t)((q + 1) & 1) * MT * 256, sk);
         __syncthreads();
+    }
     }
     // epilogue: tile (mt, nt): rk = 16mt+4g+reg, i = i0w+16nt+ii
     auto finish = [&](int rk, int64_t i, float nu, float de) {

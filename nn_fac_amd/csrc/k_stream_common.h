@@ -1,6 +1,7 @@
 // Device helpers shared by the streaming MFMA kernels (k_stream.hip, k_mu.hip, k_mttkrp.hip).
 #pragma once
 #include "nnf_internal.h"
+#include <type_traits>
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
@@ -23,6 +24,44 @@ __device__ __forceinline__ f32x4 nnf_bload4(rsrc_t rs, int voff, int soff) {
 }
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ---------------------------------------------------------------------------------------------------------
+// Hand-issued LDS reads.  hipcc places an LDS read of an MFMA operand right in front of its first use ("read, wait,
+// multiply": the whole LDS latency exposed, once per operand group); issuing the reads a phase early and waiting on the
+// counter keeps them behind MFMAs that are already queued.  Rules that make this safe (k_hals_quad.hip, nnf_cost_kernel):
+//   * every read and every wait is `asm volatile` (they keep their order among themselves);
+//   * a wait names the registers it releases as in/out operands, so no consumer can be scheduled above it;
+//   * LDS operations return in order: extra compiler-issued ones in between only make a wait more conservative;
+//   * nothing is in flight across a barrier or a loop back-edge.
+// ---------------------------------------------------------------------------------------------------------
+template <int I, int N, class F>
+__device__ __forceinline__ void nnf_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        nnf_static_for<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ unsigned nnf_lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }
+template <int OFF>
+__device__ __forceinline__ void nnf_lds_read4(f32x4& d, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF));
+}
+// the same read, kept behind the instructions that produce `ride` (an accumulator rides through as an in/out operand)
+template <int OFF>
+__device__ __forceinline__ void nnf_lds_read4_after(f32x4& d, unsigned addr, f32x4& ride) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %2 offset:%3" : "=&v"(d), "+v"(ride) : "v"(addr), "n"(OFF));
+}
+// wait until at most N LDS operations are outstanding; releases d[0 .. CNT)
+template <int N, int CNT>
+__device__ __forceinline__ void nnf_lds_wait(f32x4* d) {
+    static_assert(CNT >= 1 && CNT <= 4, "");
+    if constexpr (CNT == 1) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d[0]) : "n"(N));
+    else if constexpr (CNT == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(d[0]), "+v"(d[1]) : "n"(N));
+    else if constexpr (CNT == 3) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]) : "n"(N));
+    else asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "n"(N));
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // A-operand staging.  LDS image of one 64-deep chunk of a row-major r x K matrix A:

@@ -229,7 +229,10 @@ class Ctx:
         elif self.cuda:
             torch.cuda.set_device(0)
         self.device = torch.device(f"cuda:{torch.cuda.current_device()}") if self.cuda else torch.device("cpu")
-        self.group = dist.group.WORLD if self.world > 1 else None
+        # NNF_BENCH_FORCE_SHARDED=1 (with NNF_BENCH_INIT_PG=1): the row-sharded protocol on ONE rank -- its chunked solves,
+        # all-reduces and host decisions without any peer: what the protocol itself costs a rank on a one-GPU box
+        self.force_sharded = self.pg and os.environ.get("NNF_BENCH_FORCE_SHARDED") == "1"
+        self.group = dist.group.WORLD if (self.world > 1 or self.force_sharded) else None
         if factory is None:
             from nn_fac_amd.engine import get_engine
             self.eng = get_engine(self.device)
@@ -397,7 +400,7 @@ def bench_nmf(cx, args, cfg, steps, warmup, with_cpu, with_fixed, with_kernels):
     run = NmfRun(cx, X, Ut, V, r, rule, beta)
     dt, cost, start = run.measure(warmup, steps)
     sweeps = list(run.sweeps)
-    if cx.world > 1 and os.environ.get("NNF_BENCH_DEBUG"):
+    if cx.group is not None and os.environ.get("NNF_BENCH_DEBUG"):
         print(f"[rank {cx.rank}] sharded U-side protocol: {run.ws.async_hits} device-side decisions, "
               f"{run.ws.async_misses} redone synchronously; sweeps {sweeps}", file=sys.stderr, flush=True)
     out = {"value": units * steps / dt, "ms_per_step": 1e3 * dt / steps, "final_cost": cost,
@@ -428,7 +431,7 @@ def bench_ntf(cx, args, cfg, steps, warmup, with_cpu, with_kernels):
     if cx.world > 1:
         for f in Ft[1:]:
             cx.dist.broadcast(f, src=0)          # the factors of the unsharded modes are replicated
-    st = ntf_mod._NtfState(cx.eng, T, group=cx.group) if cx.world > 1 else ntf_mod._NtfState(cx.eng, T)
+    st = ntf_mod._NtfState(cx.eng, T, group=cx.group)
     sweeps, last = [], [None]
 
     def retired(it, cost, sw):

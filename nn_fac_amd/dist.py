@@ -25,12 +25,38 @@ import torch
 import torch.distributed as dist
 
 
+import os
+
+# NNF_FORCE_SHARDED=1: a ONE-rank group runs the row-sharded protocol too (its chunked solves, collectives and host decisions,
+# with nobody to exchange with) -- rehearsal and measurement of what the protocol costs a rank on a one-GPU box
+FORCE_SHARDED = os.environ.get("NNF_FORCE_SHARDED") == "1"
+
+
 def world(group):
     return dist.get_world_size(group) if group is not None else 1
 
 
+def is_sharded(group):
+    return group is not None and (dist.get_world_size(group) > 1 or FORCE_SHARDED)
+
+
+def opt_in(name, group):
+    """Switch of the two row-sharded optimisations that need ONE PROCESS PER DEVICE to pay off (device-side stopping decision,
+    NNF_SHARDED_ASYNC; cost under the V-side solve, NNF_SHARDED_OVERLAP): "1" / "0" in the environment force them on / off;
+    unset, they are on exactly when the group runs over RCCL ("nccl") -- which refuses two ranks on one device, so every
+    rank owns its GPU -- and off over gloo, where ranks may time-slice one device and two persistent sweep kernels can
+    starve each other (the only multi-rank rehearsal a one-GPU box offers)."""
+    v = os.environ.get(name)
+    if v in ("0", "1"):
+        return v == "1"
+    try:
+        return group is not None and dist.get_backend(group) == "nccl"
+    except Exception:
+        return False
+
+
 def allreduce_(t, group):
-    if group is not None and dist.get_world_size(group) > 1:
+    if is_sharded(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 

@@ -161,13 +161,13 @@ class _StepBuffers:
         self.select(0)
         self.guess_u = _dist.SweepGuess()
         self.guess_v = _dist.SweepGuess()
-        # Row-sharded U-side solve with the device-side stopping decision (dist.sharded_hals_solve_async): opt-in with
-        # NNF_SHARDED_ASYNC=1.  A missed guess costs a pipeline drain + a redone iteration, and the sweep counts of the first
+        # Row-sharded U-side solve with the device-side stopping decision (dist.sharded_hals_solve_async): on by default over
+        # RCCL, NNF_SHARDED_ASYNC=0/1 forces it (dist.opt_in).  A missed guess costs a pipeline drain + a redone iteration, and the sweep counts of the first
         # outer iterations jump by tens (33, 52, 67, 38, ... at config B), so it is engaged only once two consecutive solves
         # differ by <= 4 sweeps (`async_ready`).  Validated for correctness (gloo world-size-2 tests, one-GPU kernel test);
         # its gain needs one process per GPU to show -- with two ranks time-slicing ONE GPU (the only rehearsal available
-        # here) the unsynchronised ranks starve each other's persistent V-side solves -- hence not the default.
-        self.async_sharded = __import__("os").environ.get("NNF_SHARDED_ASYNC", "0") == "1"
+        # here) the unsynchronised ranks starve each other's persistent V-side solves -- hence off over gloo.
+        self.async_sharded = None         # decided by run_steps from the group (dist.opt_in)
         self.async_ready = False
         self.last_u_count = None
         self.sync_next = False            # row-sharded: the next step uses the host-synchronous U-side protocol (after a redo)
@@ -243,12 +243,13 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
       empty, and everything else of iteration i+1 depends on it.  The cost kernel's waves are small enough (<= 136 VGPRs)
       for a sweep wave to fit on a SIMD they fill, so the order in which the two get their CUs does not matter.  The main
       stream waits for that cost before it launches the next U-side solve (whose 1563 waves should find the chip free).
-      The host then looks at costs two iterations behind the device.  Row-sharded runs keep the cost inside the step
-      unless NNF_SHARDED_OVERLAP=1: the only multi-rank rehearsal available while this was written is two processes
-      sharing ONE GPU, and there two persistent sweep kernels (one per process) plus the extra cost kernels can each end
-      up partially resident and wait for the other's workgroups until the bounded spins expire (0.5 s per step).  With one
-      process per GPU there is only ever one persistent kernel per device and the cost kernel always drains, but that
-      configuration could not be measured here, so it is opt-in.
+      The host then looks at costs two iterations behind the device.  Row-sharded runs do the same over RCCL (one process
+      per device by construction; NNF_SHARDED_OVERLAP=0/1 forces it, dist.opt_in) and keep the cost inside the step over
+      gloo: two processes sharing ONE GPU -- the only multi-rank rehearsal a one-GPU box offers -- run two persistent sweep
+      kernels (one per process) plus the extra cost kernels, which can each end up partially resident and wait for the
+      other's workgroups until the bounded spins expire (0.5 s per step).  Measured on ONE rank running the whole sharded
+      protocol over a 1-rank RCCL group (NNF_FORCE_SHARDED=1, 40 steady-state iterations at config B): 590 iterations/s
+      unsharded, 543 host-synchronous, 552 with the device-side decision, 575 with both.
 
     `retired(iteration, cost, sweeps)` is called once per iteration, in order, and returns True when the loop has to stop
     (nmf.py:320-324); the factors returned are those of the iteration that stopped it -- each step writes fresh factor
@@ -257,11 +258,14 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
     cuda = X.is_cuda
     overlap = (cuda and update_rule == "hals" and 1 not in fixed_modes and isinstance(eng, _engine.Engine)
                and ws.cost_stream is not None
-               and (_dist.world(group) == 1 or __import__("os").environ.get("NNF_SHARDED_OVERLAP") == "1"))
+               and (not _dist.is_sharded(group) or _dist.opt_in("NNF_SHARDED_OVERLAP", group)))
+    if ws.async_sharded is None:
+        ws.async_sharded = _dist.is_sharded(group) and _dist.opt_in("NNF_SHARDED_ASYNC", group)
     # MU, beta = 1: the left update of iteration i+1 forms U_i V_i entry by entry -- the KL cost of iteration i rides along
     # (nnf_mu_left_kl_cost_f32) and the separate cost pass over X (a quarter of a KL iteration at config C) is only run after
     # the last iteration.  Like the overlapped HALS cost, the host then looks at costs two iterations behind the device.
-    fused_mu = (cuda and update_rule == "mu" and float(beta) == 1.0 and 0 not in fixed_modes and _dist.world(group) == 1
+    # (row-sharded: the kernel's sum covers this rank's rows; one scalar all-reduce before the block goes to the host)
+    fused_mu = (cuda and update_rule == "mu" and float(beta) == 1.0 and 0 not in fixed_modes
                 and isinstance(eng, _engine.Engine) and Ut.shape[0] <= eng.MU_FUSED_MAX_RANK)
     depth = PIPELINE_DEPTH + (1 if (overlap or fused_mu) else 0)
     assert ws.blocks.shape[0] > depth
@@ -280,6 +284,7 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
                 # the last step's cost from the SAME kernel as every other cost of the run (an update whose output is
                 # dropped): a run stopped early and a run of exactly that many iterations give bitwise equal costs
                 eng.mu_left(X, step["Ut"], step["V"], beta, cost_out=block[16:17])
+                _dist.allreduce_(block[16:17], group)
             else:
                 _step_cost(ws.cost_eng if stream is not main else eng, X, step["Ut"], step["V"], update_rule, beta,
                            sparsity_coefficients, block[16:17], group)
@@ -345,6 +350,7 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
         ws.sync_next = False
         if fused_mu:
             if owed is not None:          # its cost has just been enqueued with this step's left update
+                _dist.allreduce_(ws.blocks[owed["slot"]][16:17], group)
                 ws.host[owed["slot"]].copy_(ws.blocks[owed["slot"]], non_blocking=True)
                 owed["ev"] = main.record_event()
             owed = step
@@ -436,7 +442,7 @@ def _step_cost_local(eng, X, Ut, V, update_rule, beta, out):
 
 def _step_cost_finish(Ut, V, update_rule, sparsity_coefficients, out, group=None):
     """Sum over the row blocks and the sparsity terms of nmf.py:452."""
-    sharded = _dist.world(group) > 1
+    sharded = _dist.is_sharded(group)
     if sharded:
         _dist.allreduce_(out, group)
     sp = [0 if s is None else s for s in sparsity_coefficients]
@@ -463,7 +469,7 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
     With `group` (torch.distributed process group) X / Ut are this rank's row block and V is replicated (dist.py).
     run_steps' hooks: `before_u_solve` / `before_v_solve` are called right before the U-side / V-side HALS solve is
     launched; with `skip_cost` the cost line is left to the caller (who overlaps it with the next V-side solve)."""
-    sharded = _dist.world(group) > 1
+    sharded = _dist.is_sharded(group)
     if sharded:
         if update_rule == "hals" and normalize[0]:
             raise NotImplementedError("row-sharded HALS runs cannot normalise the sharded factor (a grid-wide reduction per "

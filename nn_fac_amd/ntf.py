@@ -75,7 +75,7 @@ class _NtfState:
         self.nway = self.T.dim()
         t2 = self.T.view(self.T.shape[0], -1)
         self.norm2 = eng.dot(t2, t2)          # float64 device scalar, ||T||^2
-        if _dist.world(group) > 1:
+        if _dist.is_sharded(group):
             _dist.allreduce_(self.norm2, group)
         self.guess0 = _dist.SweepGuess()
         self._unf = {}
@@ -169,7 +169,7 @@ def _krao_t(Ft, skip):
 def _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, cost, fuse_next=False):
     """The cost lines of one_ntf_step (ntf.py:462-475) into the 1-element float64 device tensor `cost`, current stream.
     `fuse_next` (HALS, another iteration follows): the same pass over T leaves the next iteration's partial product."""
-    sharded = _dist.world(st.group) > 1
+    sharded = _dist.is_sharded(st.group)
     if update_rule == "hals" and fuse_next and hasattr(eng, "cp3_partial_cost") \
             and Ft[0].shape[0] <= getattr(eng, "CP3_FUSED_MAX_RANK", 0):
         st.cost_and_partial(Ft, cost)                # ||T - model||^2
@@ -208,7 +208,7 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
     Ft = list(Ft_in)
     dev = st.T.device
     nstat = 0
-    sharded = _dist.world(st.group) > 1
+    sharded = _dist.is_sharded(st.group)
     if sharded and (update_rule != "hals" or not math.isinf(alpha) or normalize[0]):
         raise NotImplementedError("leading-mode-sharded NTF: HALS with alpha = inf and no normalisation of mode 0")
     # Dimension tree: with modes 0 and 1 both updated, their right-hand sides (ntf.py:448-449) are two contractions of the

@@ -353,6 +353,16 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta):
                         us_per_sweep=ms * 1e3, note="latency bound: n/16 single-wave workgroups"))
     else:
         k = 2.0 if float(beta) != 2.0 else 1.0
+        c = torch.zeros(1, dtype=torch.float64, device=X.device)
+        if float(beta) == 1.0 and r <= eng.MU_FUSED_MAX_RANK:
+            # the form the timed loop runs: the left update that also returns the KL divergence of its input factors (the
+            # previous iteration's cost).  Same 4 r m n MFMA flops; the divergence terms (a series + a logarithm per entry)
+            # are VALU work on the same fp32 pipe and are NOT counted as algorithmic flops.
+            ms = eng.time_kernel("mu_left", lambda: eng.mu_left(X, Ut, V, beta, cost_out=c))
+            out.append(roof("nnf_mu_left_kernel<KL + cost> (beta=1: P = U V, num += (X ./ P) V^T and the KL divergence of the "
+                            "input factors in one pass; the kernel of the timed loop)", "mfma", k * flops, ms,
+                            MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=k * flops, algorithmic_bytes=xbytes,
+                            hbm_gbs=xbytes / ms / 1e6))
         ms = eng.time_kernel("mu_left", lambda: eng.mu_left(X, Ut, V, beta))
         out.append(roof(f"nnf_mu_left_kernel (beta={beta:g}: P = U V and num += (X ./ P) V^T in one pass)", "mfma",
                         k * flops, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=k * flops,
@@ -360,7 +370,6 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta):
         ms = eng.time_kernel("mu_right", lambda: eng.mu_right(X, Ut, V, beta))
         out.append(roof(f"nnf_mu_right_kernel (beta={beta:g})", "mfma", k * flops, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
                         algorithmic_flops=k * flops, algorithmic_bytes=xbytes, hbm_gbs=xbytes / ms / 1e6))
-        c = torch.zeros(1, dtype=torch.float64, device=X.device)
         ms = eng.time_kernel("cost", lambda: eng.betadiv(X, Ut, V, beta, out=c))
         out.append(roof(f"nnf_cost_kernel<beta={beta:g}> (divergence fused with the product)", "mfma", flops, ms,
                         MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=flops, algorithmic_bytes=xbytes,

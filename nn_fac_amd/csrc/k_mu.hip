@@ -203,22 +203,29 @@ static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int6
         const int rc = nnf_launch_rowsum(cur, V, ldv, r, n, dvec, st);
         if (rc != NNF_OK) return rc;
     }
-    // rows per workgroup: 256 everywhere, unless one round of resident workgroups covers the matrix with 3 to 4 row tiles
-    // per wave -- then n_hi workgroups of 256 rows and the rest of 192 fill exactly one round
+    // Rows per workgroup (4 waves x 4, 3 or 2 tiles of 16 rows): whole ROUNDS of resident workgroups, all of about the same
+    // length -- R = ceil(T / (16 slots)) rounds of `slots` workgroups, each 8 to 16 tiles, as a mix of two adjacent sizes.
+    // 256-row workgroups everywhere put 977 workgroups on the 768 slots of the 250000-row pass of config D: a second round
+    // that is 27 % full and as long as the first.  Less than one round of 128-row workgroups: 128 rows each (most CUs busy).
     const int64_t slots = (int64_t)(BM == BM_GEN ? 1 : ((MT + (REM > 0) <= 2 && BM == BM_FROB) ? 3 : 2)) * ctx->num_cus, T = nnf_cdiv(m, 16);
-    int64_t n_hi = nnf_cdiv(m, 256), grid = n_hi;
-    if (T > 12 * slots && T <= 16 * slots) {
-        n_hi = nnf_cdiv(T - 12 * slots, 4);
-        grid = slots;
+    const int64_t W = nnf_cdiv(T, 16 * slots) * slots;
+    int64_t n_hi = 0, n_mid = 0, grid = W;
+    if (T <= 8 * slots) {
+        grid = nnf_cdiv(m, 128);
+    } else if (T > 12 * W) {
+        n_hi = nnf_cdiv(T - 12 * W, 4);
+        n_mid = W - n_hi;
+    } else {
+        n_mid = nnf_cdiv(T - 8 * W, 4);
     }
-    if (n_hi * 256 + (grid - n_hi) * 192 < m) return NNF_ERR_UNSUPPORTED;   // (cannot happen)
+    if (n_hi * 256 + n_mid * 192 + (grid - n_hi - n_mid) * 128 < m) return NNF_ERR_UNSUPPORTED;   // (cannot happen)
     if (BM == BM_FROB || BM == BM_KLC) {
         ex.partial = (double*)cur.take((size_t)grid * 8);
         if (!ex.partial || !cost_out) return NNF_ERR_WORKSPACE;
     }
     nnf_probe(ctx, NNF_PROBE_MU_LEFT, 0, st);
     hipLaunchKernelGGL((nnf_mu_left_kernel<MT, REM, BM, VEC>), dim3((int)grid), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, V, ldv, r,
-                       (float)beta, dvec, raw_num ? -1.f : gamma_of(beta), Ut_out, lduo, a_vec_ok, (int)n_hi, ex);
+                       (float)beta, dvec, raw_num ? -1.f : gamma_of(beta), Ut_out, lduo, a_vec_ok, (int)n_hi, (int)n_mid, ex);
     NNF_CHECK_LAUNCH();
     nnf_probe(ctx, NNF_PROBE_MU_LEFT, 1, st);
     if (BM == BM_FROB || BM == BM_KLC) return nnf_launch_sum_f64(ex.partial, grid, 1.0, cost_out, st);

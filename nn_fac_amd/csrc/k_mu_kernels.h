@@ -55,72 +55,6 @@ __device__ __forceinline__ void stageA_direct(const float* __restrict__ A, int64
     stageA_store<MT>(img, regs);
 }
 
-// ---- buffer-addressed staging of the two chunk images -----------------------------------------------------------------
-// One buffer resource spans the whole r x K factor ([r][lda], bytes = ((r-1)*lda + K)*4: rank rows >= r fall outside and read
-// as zero), the lane's share of the address is ONE VGPR and the tile / row / chunk part an SGPR offset.  The pointer form
-// (stageA_load / stageK_load: a 64-bit address per staged row) had its 12-16 row bases hoisted out of the chunk loop, spilled,
-// and reloaded in the middle of it behind s_waitcnt vmcnt(0) -- a full drain of the X prefetch ring once per chunk.
-// Columns >= K are masked per lane (they are allocated padding of the earlier rows, possibly not finite: 0 * NaN in MFMA #2).
-struct mu_stage {
-    rsrc_t rs;
-    int lda4;          // row pitch in bytes
-    int offA, offK;    // lane parts: ((L&15)*lda + 16t + 4(L>>4))*4  and  ((L>>4)*lda + 16t + (L&15))*4,  t = wave index
-    int colA, colK;    // lane's first column inside a chunk: 16t + 4(L>>4)  and  16t + (L&15)
-};
-__device__ __forceinline__ mu_stage mu_stage_make(const float* A, int64_t lda, int r, int64_t K) {
-    mu_stage s;
-    const int t = threadIdx.x >> 6, L = threadIdx.x & 63;
-    s.rs = nnf_make_rsrc(A, (uint32_t)((((int64_t)r - 1) * lda + K) * 4));
-    s.lda4 = (int)(lda * 4);
-    s.colA = 16 * t + 4 * (L >> 4);
-    s.colK = 16 * t + (L & 15);
-    s.offA = (int)(((int64_t)(L & 15) * lda + s.colA) * 4);
-    s.offK = (int)(((int64_t)(L >> 4) * lda + s.colK) * 4);
-    return s;
-}
-#define MU_OOB 0x7ffffff0
-template <int MT>
-__device__ __forceinline__ void stageA_bload(const mu_stage& s, int64_t K, int64_t k0, bool vec_ok, f32x4 (&regs)[MT]) {
-    const int64_t left = K - (k0 + s.colA);                 // columns of this lane's float4 that exist (<= 0: none)
-    const int k04 = (int)(k0 * 4);
-    if (vec_ok) {
-        const int vo = left > 0 ? s.offA : MU_OOB;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rs, vo, 16 * mt * s.lda4 + k04, 0));
-            if (left < 4) {
-                v[1] = left > 1 ? v[1] : 0.f;
-                v[2] = left > 2 ? v[2] : 0.f;
-                v[3] = left > 3 ? v[3] : 0.f;
-            }
-            regs[mt] = v;
-        }
-    } else {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            f32x4 v;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s.rs, left > c ? s.offA + 4 * c : MU_OOB,
-                                                                                      16 * mt * s.lda4 + k04, 0));
-            regs[mt] = v;
-        }
-    }
-}
-template <int MT>
-__device__ __forceinline__ void stageK_bload(const mu_stage& s, int64_t K, int64_t k0, f32x4 (&regs)[MT]) {
-    const int vo = (k0 + s.colK < K) ? s.offK : MU_OOB;
-    const int k04 = (int)(k0 * 4);
-#pragma unroll
-    for (int s4 = 0; s4 < MT; ++s4) {
-        f32x4 v;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s.rs, vo, (16 * s4 + 4 * c) * s.lda4 + k04, 0));
-        regs[s4] = v;
-    }
-}
-
 // Which rank steps (4 ranks each) of MFMA #1 run.  MT = ceil(r / 16), so every 16-rank group but the last is full; with the
 // resident fragments in registers (zero beyond r, like the chunk image) the last group runs 2 or 4 steps behind ONE
 // wave-uniform flag: a test per step (4*s4 + c < KS) splits the product into 16 basic blocks and pins every LDS read of
@@ -785,13 +719,19 @@ __global__ __launch_bounds__(256, (BM == BM_GEN ? 1 : ((MT + (REM > 0) <= 2 && B
                                                              const float* __restrict__ V, int64_t ldv, int r, float beta,
                                                              const double* __restrict__ den_vec, float gamma,
                                                              float* __restrict__ Ut_out, int64_t lduo, int a_vec_ok, int n_hi,
-                                                             mu_left_extra ex) {
+                                                             int n_mid, mu_left_extra ex) {
+    // workgroups [0, n_hi): 256 rows (4 row tiles per wave), [n_hi, n_hi + n_mid): 192 rows (3), the rest: 128 rows (2) --
+    // the host picks the mix that fills whole rounds of resident workgroups (launch_mu_left)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = (int)blockIdx.x;
     if (b < n_hi)
         nnf_mu_left_body<MT, REM, BM, VEC, 4>(X, m, n, ldx, Ut, ldu, V, ldv, r, beta, den_vec, gamma, Ut_out, lduo, a_vec_ok,
                                               (int64_t)b * 256, smem, ex);
-    else
+    else if (b < n_hi + n_mid)
         nnf_mu_left_body<MT, REM, BM, VEC, 3>(X, m, n, ldx, Ut, ldu, V, ldv, r, beta, den_vec, gamma, Ut_out, lduo, a_vec_ok,
                                               (int64_t)n_hi * 256 + (int64_t)(b - n_hi) * 192, smem, ex);
+    else
+        nnf_mu_left_body<MT, REM, BM, VEC, 2>(X, m, n, ldx, Ut, ldu, V, ldv, r, beta, den_vec, gamma, Ut_out, lduo, a_vec_ok,
+                                              (int64_t)n_hi * 256 + (int64_t)n_mid * 192 + (int64_t)(b - n_hi - n_mid) * 128,
+                                              smem, ex);
 }

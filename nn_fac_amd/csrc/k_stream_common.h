@@ -98,6 +98,73 @@ __device__ __forceinline__ void stageA_store(f32x4* __restrict__ img, const f32x
     for (int mt = 0; mt < MT; ++mt) img[(mt * 4 + t) * 64 + L] = regs[mt];
 }
 
+// ---- buffer-addressed staging of the two chunk images -----------------------------------------------------------------
+// One buffer resource spans the whole r x K factor ([r][lda], bytes = ((r-1)*lda + K)*4: rank rows >= r fall outside and read
+// as zero), the lane's share of the address is ONE VGPR and the tile / row / chunk part an SGPR offset.  The pointer form
+// (stageA_load / stageK_load: a 64-bit address per staged row) had its 12-16 row bases hoisted out of the chunk loop, spilled,
+// and reloaded in the middle of it behind s_waitcnt vmcnt(0) -- a full drain of the X prefetch ring once per chunk.
+// Columns >= K are masked per lane (they are allocated padding of the earlier rows, possibly not finite: 0 * NaN in MFMA #2).
+struct mu_stage {
+    rsrc_t rs;
+    int lda4;          // row pitch in bytes
+    int offA, offK;    // lane parts: ((L&15)*lda + 16t + 4(L>>4))*4  and  ((L>>4)*lda + 16t + (L&15))*4,  t = wave index
+    int colA, colK;    // lane's first column inside a chunk: 16t + 4(L>>4)  and  16t + (L&15)
+};
+__device__ __forceinline__ mu_stage mu_stage_make(const float* A, int64_t lda, int r, int64_t K) {
+    mu_stage s;
+    const int t = threadIdx.x >> 6, L = threadIdx.x & 63;
+    s.rs = nnf_make_rsrc(A, (uint32_t)((((int64_t)r - 1) * lda + K) * 4));
+    s.lda4 = (int)(lda * 4);
+    s.colA = 16 * t + 4 * (L >> 4);
+    s.colK = 16 * t + (L & 15);
+    s.offA = (int)(((int64_t)(L & 15) * lda + s.colA) * 4);
+    s.offK = (int)(((int64_t)(L >> 4) * lda + s.colK) * 4);
+    return s;
+}
+#define MU_OOB 0x7ffffff0
+template <int MT>
+__device__ __forceinline__ void stageA_bload(const mu_stage& s, int64_t K, int64_t k0, bool vec_ok, f32x4 (&regs)[MT]) {
+    const int64_t left = K - (k0 + s.colA);                 // columns of this lane's float4 that exist (<= 0: none)
+    const int k04 = (int)(k0 * 4);
+    if (vec_ok) {
+        const int vo = left > 0 ? s.offA : MU_OOB;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rs, vo, 16 * mt * s.lda4 + k04, 0));
+            if (left < 4) {
+                v[1] = left > 1 ? v[1] : 0.f;
+                v[2] = left > 2 ? v[2] : 0.f;
+                v[3] = left > 3 ? v[3] : 0.f;
+            }
+            regs[mt] = v;
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s.rs, left > c ? s.offA + 4 * c : MU_OOB,
+                                                                                      16 * mt * s.lda4 + k04, 0));
+            regs[mt] = v;
+        }
+    }
+}
+template <int MT>
+__device__ __forceinline__ void stageK_bload(const mu_stage& s, int64_t K, int64_t k0, f32x4 (&regs)[MT]) {
+    const int vo = (k0 + s.colK < K) ? s.offK : MU_OOB;
+    const int k04 = (int)(k0 * 4);
+#pragma unroll
+    for (int s4 = 0; s4 < MT; ++s4) {
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s.rs, vo, (16 * s4 + 4 * c) * s.lda4 + k04, 0));
+        regs[s4] = v;
+    }
+}
+
+
 
 static inline bool x_vec_ok(const float* X, int64_t ldx) { return (((uintptr_t)X) & 15) == 0 && (ldx & 3) == 0; }
 
@@ -130,14 +197,37 @@ __device__ __forceinline__ float nnf_h(float t, float q) {
     return fabsf(t) < 0.25f ? series : direct;
 }
 
+// KL term written on the reciprocal of the MODEL entry: x ln(x/p) - x + p = p g(rho), rho = x/p (>= 0 by construction),
+//   g(rho) = rho ln(rho) - rho + 1 = (1 + s) ln(1 + s) - s,  s = (x - p)/p
+//   |s| < 1/4: s^2 sum_k (-s)^k / ((k+1)(k+2))  (coefficients fall like 1/k^2: 10 terms for fp32, no cancellation);
+//   otherwise rho ln(rho) - s directly (rho = 0, a zero data entry: 0 * ln(tiny) - (-1) = 1, the term is p as in the reference).
+// 1/p is the reciprocal the fused KL update needs anyway (R = x/p): one transcendental and three FMAs per entry less than
+// the form on 1/x (x h((p-x)/x)) -- the divergence rides on the same fp32 pipe as the MFMAs of nnf_mu_left_kl_cost_f32.
+__device__ __forceinline__ float nnf_kl_term(float x, float p) {
+    const float rp = __builtin_amdgcn_rcpf(p);
+    const float rho = x * rp, s = (x - p) * rp;
+    float a = -1.f / 110.f;                       // k = 9
+    a = fmaf(a, s, 1.f / 90.f);
+    a = fmaf(a, s, -1.f / 72.f);
+    a = fmaf(a, s, 1.f / 56.f);
+    a = fmaf(a, s, -1.f / 42.f);
+    a = fmaf(a, s, 1.f / 30.f);
+    a = fmaf(a, s, -1.f / 20.f);
+    a = fmaf(a, s, 1.f / 12.f);
+    a = fmaf(a, s, -1.f / 6.f);
+    a = fmaf(a, s, 0.5f);
+    const float series = s * s * a;
+    const float direct = fmaf(rho * 0.69314718056f, __builtin_amdgcn_logf(fmaxf(rho, 1e-37f)), -s);
+    return p * (fabsf(s) < 0.25f ? series : direct);
+}
+
 template <int OP>
 __device__ __forceinline__ float nnf_cost_term(float x, float p, float beta) {
     if constexpr (OP == NNF_COST_FROB) {
         const float d = x - p;
         return d * d;
     } else if constexpr (OP == NNF_COST_KL) {
-        const float rx = __builtin_amdgcn_rcpf(x);
-        return x > 0.f ? x * nnf_h((p - x) * rx, p * rx) : p;
+        return nnf_kl_term(x, p);
     } else if constexpr (OP == NNF_COST_IS) {
         const float rp = __builtin_amdgcn_rcpf(p);
         return nnf_h((x - p) * rp, x * rp);

@@ -49,8 +49,9 @@ for cfg in configs:
         e = {"fetch_size_kib_raw": fetch, "write_size_kib": write, "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
              "launches": len(cs["FETCH_SIZE"])}
         if cs.get("SQ_VALU_MFMA_BUSY_CYCLES") and cs.get("SQ_BUSY_CYCLES"):
+            # SQ_VALU_MFMA_BUSY_CYCLES sums over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines (~ kernel duration each)
             e["mfma_busy_frac"] = (sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(cs["SQ_VALU_MFMA_BUSY_CYCLES"])) / \
-                (4 * sum(cs["SQ_BUSY_CYCLES"]) / len(cs["SQ_BUSY_CYCLES"]))
+                (32 * sum(cs["SQ_BUSY_CYCLES"]) / len(cs["SQ_BUSY_CYCLES"]))
         out[k] = e
     out["_note"] = ("separate --pmc passes of `python3 bench.py --config %s --steps 3 --warmup 1 --no-cpu --no-fixed --no-extra "
                     "--no-kernels` (tools/bench_profile.sh); FETCH_SIZE doubled per the gfx950 correction; means over the "

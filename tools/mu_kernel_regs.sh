@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${OUT:-/tmp/mu_dev_${SIDE}_${MT}_${REM}_${BM}}
 mkdir -p $OUT
 if [ "$SIDE" = left ]; then
-  SIG='(const float*, int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, int, float, const double*, float, float*, int64_t, int, int, mu_left_extra)'
+  SIG='(const float*, int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, int, float, const double*, float, float*, int64_t, int, int, int, mu_left_extra)'
 else
   SIG='(const float*, int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, int, float, float*, float*, int64_t, int, int, int64_t, int)'
 fi

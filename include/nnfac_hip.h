@@ -147,6 +147,13 @@ int nnf_hals_sweeps_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float
                         int r, int64_t ncols, int nsweeps, float sparsity, unsigned flags, double* nodelta_f64,
                         float* snapshots, int64_t snap_stride, void* stream);
 
+/* Columns the register-resident sweep kernel of rank r keeps on this device (one lane per column, all workgroups co-resident).
+ * More columns than that: nnf_hals_solve_f32 / nnf_hals_sweeps_f32 stream the factor through HBM once per sweep and
+ * nnf_hals_sweeps_f32 refuses `snapshots`; a caller that runs blind chunks of sweeps (the row-sharded protocol of nnls.py:156, or
+ * the solve of a 10^6-column factor on one device) splits the columns into blocks of at most this many and adds the blocks'
+ * per-sweep sums. */
+int nnf_hals_resident_columns(nnf_ctx* ctx, int r, int64_t* columns_out);
+
 /* Row-sharded solve, device-side stopping decision (no host round trip): after `nsweeps` blind sweeps of
  * nnf_hals_sweeps_f32 (snapshots for the last nsweeps - head of them) and an all-reduce of their per-sweep sums over the
  * ranks, replay nnls.py:156 over the sums: stop = first s with !(sum[s] >= delta*sum[0]) or s + 1 == budget.  A stop inside the

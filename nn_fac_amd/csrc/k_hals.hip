@@ -384,6 +384,26 @@ __global__ __launch_bounds__(256) void nnf_hals_stop_restore_kernel(const double
     }
 }
 
+// Columns the register-resident sweep kernel of rank r holds on this device (every column = one lane, its V and right-hand
+// side entries in registers, all workgroups co-resident).  Beyond it nnf_hals_solve_f32 / nnf_hals_sweeps_f32 stream the
+// factor through HBM once per sweep and nnf_hals_sweeps_f32 writes no snapshots: callers that run blind chunks of sweeps
+// (the row-sharded protocol, the solve of a 10^6-column factor on one device) split the columns into blocks of this size.
+extern "C" int nnf_hals_resident_columns(nnf_ctx* ctx, int r, int64_t* columns_out) {
+    if (!ctx || r < 1 || !columns_out) return NNF_ERR_ARG;
+    const int RP = pick_rp(r);
+    if (RP < 0) return NNF_ERR_UNSUPPORTED;
+    hals_args a{};
+    a.ncols = -1;
+    int nblocks = 0, rc;
+    if (RP <= 48) rc = nnf_hals_fast_part0(ctx, RP, a, NNF_HALS_MAX_BLOCKS, &nblocks, nullptr);
+    else if (RP <= 64) rc = nnf_hals_fast_part1(ctx, RP, a, NNF_HALS_MAX_BLOCKS, &nblocks, nullptr);
+    else if (RP <= 104) rc = nnf_hals_fast_part2(ctx, RP, a, NNF_HALS_MAX_BLOCKS, &nblocks, nullptr);
+    else rc = nnf_hals_fast_part3(ctx, RP, a, NNF_HALS_MAX_BLOCKS, &nblocks, nullptr);
+    if (rc != NNF_OK) return rc;
+    *columns_out = (int64_t)nblocks * 256;
+    return NNF_OK;
+}
+
 extern "C" int nnf_hals_stop_restore_f32(nnf_ctx* ctx, const double* sums_f64, int nsweeps, int head, int budget, double delta,
                                          float* V, int64_t ldv, int r, int64_t ncols, const float* snapshots,
                                          int64_t snap_stride, double* status_f64, void* stream) {

@@ -392,11 +392,15 @@ static int launch_rp(nnf_ctx* ctx, const hals_args& a, int max_blocks_cap, int* 
         }
         return c;
     };
-    const int64_t need = nnf_cdiv(a.ncols, 256);
     int bpc = bpc_of(true);
     if (bpc < 1) return NNF_ERR_LAUNCH;
     int64_t cap = (int64_t)bpc * ctx->num_cus;
     if (cap > max_blocks_cap) cap = max_blocks_cap;
+    if (a.ncols < 0) {   // capacity query (nnf_hals_resident_columns): workgroups of 256 columns the resident kernel keeps on the chip
+        *nblocks_out = (int)cap;
+        return NNF_OK;
+    }
+    const int64_t need = nnf_cdiv(a.ncols, 256);
     if (need <= cap) {
         *nblocks_out = (int)need;
         hipLaunchKernelGGL((nnf_hals_kernel<RP, true>), dim3((int)need), dim3(256), 0, st, a);

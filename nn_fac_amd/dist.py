@@ -78,8 +78,24 @@ def shard_rows(m, rank, nranks):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def column_blocks(eng, F):
+    """[(lo, hi)] column blocks of the r x m factor F, each small enough for the register-resident sweep kernel (the only one
+    that writes snapshots, and the fast one: Engine.hals_resident_columns): one block for everything the bench's B / C / D
+    shapes need, 8 for the 10^6-column factor of config E on one device, 4 / 2 on two / four.  Block edges are multiples of
+    256 columns (whole workgroups, 1 KB-aligned rows)."""
+    m = int(F.shape[1])
+    cap = getattr(eng, "hals_resident_columns", None)
+    cap = int(cap(F.shape[0])) if cap is not None else 0
+    if cap <= 0 or m <= cap:
+        return [(0, m)]
+    nb = -(-m // cap)
+    size = -(-m // nb)
+    size = -(-size // 256) * 256
+    return [(lo, min(lo + size, m)) for lo in range(0, m, size)]
+
+
 class SweepGuess:
-    """Per-factor state of the sharded solve: chunk length memory and the reusable snapshot buffer."""
+    """Per-factor state of the sharded solve: chunk length memory and the reusable snapshot buffers (one per column block)."""
 
     def __init__(self, first=16, max_chunk=104, window=8):
         self.value = first
@@ -87,12 +103,29 @@ class SweepGuess:
         self.window = window
         self.snap = None
 
-    def snapshots(self, F, W):
-        if self.snap is None or self.snap.shape[0] < W or tuple(self.snap.shape[1:]) != tuple(F.shape) \
-                or self.snap.device != F.device or self.snap.dtype != F.dtype:
-            self.snap = torch.empty((max(W, min(self.max_chunk, self.window)),) + tuple(F.shape), dtype=F.dtype,
-                                    device=F.device)
+    def snapshots(self, F, W, blocks=None):
+        """One (>= W) x r x (block columns) contiguous buffer per column block (a single-block F: one buffer shaped like F)."""
+        blocks = blocks or [(0, int(F.shape[1]))]
+        shapes = [(int(F.shape[0]), hi - lo) for lo, hi in blocks]
+        ok = self.snap is not None and len(self.snap) == len(shapes) and all(
+            s.shape[0] >= W and tuple(s.shape[1:]) == sh and s.device == F.device and s.dtype == F.dtype
+            for s, sh in zip(self.snap, shapes))
+        if not ok:
+            self.snap = None          # release before allocating: eight 400 MB windows at config E's full size
+            self.snap = [torch.empty((max(W, min(self.max_chunk, self.window)),) + sh, dtype=F.dtype, device=F.device)
+                         for sh in shapes]
         return self.snap
+
+
+def _blind_sweeps(eng, cross, gram, F, blocks, nsweeps, sparsity, snaps=None):
+    """`nsweeps` blind sweeps over every column block; the blocks' per-sweep sums of squared steps added in block order."""
+    nd = None
+    for bi, (lo, hi) in enumerate(blocks):
+        whole = lo == 0 and hi == F.shape[1]
+        part = eng.hals_sweeps(cross if whole else cross[:, lo:hi], gram, F if whole else F[:, lo:hi], nsweeps,
+                               sparsity=sparsity, **({} if snaps is None else {"snapshots": snaps[bi]}))
+        nd = part if nd is None else nd + part
+    return nd
 
 
 def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01, sparsity=None):
@@ -107,6 +140,7 @@ def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01
     done, eps0, eps = 0, 0.0, 1.0
     if budget < 1:
         return 1.0, 1, 0.0
+    blocks = column_blocks(eng, F)
     C = max(1, min(int(guess.value), guess.max_chunk, budget))
     while done < budget:
         C = max(1, min(C, budget - done))
@@ -116,9 +150,9 @@ def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01
         F0 = None
         if head > 0:
             F0 = F.clone()
-            parts.append(eng.hals_sweeps(cross, gram, F, head, sparsity=sparsity))
-        snap = guess.snapshots(F, W)
-        parts.append(eng.hals_sweeps(cross, gram, F, W, sparsity=sparsity, snapshots=snap))
+            parts.append(_blind_sweeps(eng, cross, gram, F, blocks, head, sparsity))
+        snap = guess.snapshots(F, W, blocks)
+        parts.append(_blind_sweeps(eng, cross, gram, F, blocks, W, sparsity, snap))
         nd = torch.cat(parts) if len(parts) > 1 else parts[0]
         allreduce_(nd, group)
         ndh = nd.cpu().tolist()                    # one host round trip per chunk
@@ -136,10 +170,11 @@ def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01
             continue
         if stop < C - 1:                           # overshoot
             if stop >= head:                       # inside the window: the snapshot after sweep stop+1
-                F.copy_(snap[stop - head])
+                for (lo, hi), s in zip(blocks, snap):
+                    F[:, lo:hi].copy_(s[stop - head])
             else:                                  # before it: start of the chunk + stop+1 sweeps again
                 F.copy_(F0)
-                eng.hals_sweeps(cross, gram, F, stop + 1, sparsity=sparsity)
+                _blind_sweeps(eng, cross, gram, F, blocks, stop + 1, sparsity)
         done += stop + 1
         break
     guess.value = max(8, min(done + 4, guess.max_chunk))
@@ -157,17 +192,20 @@ def sharded_hals_solve_async(eng, cross, gram, F, group, guess, status, budget=1
     status block an iteration or two later -- redoes that iteration with `sharded_hals_solve` (host-synchronous, exact),
     which also re-centres the guess.  With sweep counts that drift slowly (and saturate at the budget, where the stop is the
     last sweep by construction) that is rare; a wrong guess costs a redo, never a wrong factor."""
+    blocks = column_blocks(eng, F)
     C = max(1, min(int(guess.value), guess.max_chunk, budget))
     W = max(1, min(C, int(guess.window)))
     head = C - W
     parts = []
     if head > 0:
-        parts.append(eng.hals_sweeps(cross, gram, F, head, sparsity=sparsity))
-    snap = guess.snapshots(F, W)
-    parts.append(eng.hals_sweeps(cross, gram, F, W, sparsity=sparsity, snapshots=snap))
+        parts.append(_blind_sweeps(eng, cross, gram, F, blocks, head, sparsity))
+    snap = guess.snapshots(F, W, blocks)
+    parts.append(_blind_sweeps(eng, cross, gram, F, blocks, W, sparsity, snap))
     nd = torch.cat(parts) if len(parts) > 1 else parts[0]
     allreduce_(nd, group)
-    eng.hals_stop_restore(nd, head, budget, delta, F, snap, status)
+    for (lo, hi), s in zip(blocks, snap):          # the same decision for every block (it is a function of `nd` alone)
+        whole = lo == 0 and hi == F.shape[1]
+        eng.hals_stop_restore(nd, head, budget, delta, F if whole else F[:, lo:hi], s, status)
 
 
 def sharded_random_init(m, n, rank, group, seed=0, device=None, exact_stream=False):

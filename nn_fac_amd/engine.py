@@ -49,6 +49,7 @@ class Engine:
         h = C.c_void_p()
         _lib.check(self.lib.nnf_ctx_create(C.byref(h), self.device.index or 0, workspace_bytes), "nnf_ctx_create")
         self.ctx = h
+        self._resident_cols = {}
 
     def __del__(self):
         try:
@@ -203,6 +204,16 @@ class Engine:
                                                 self._hals_flags(sparsity, normalize, nonzero), _ptr(nd), sp, ss,
                                                 self._stream()), "nnf_hals_sweeps_f32")
         return nd[:int(nsweeps)]
+
+    def hals_resident_columns(self, r):
+        """Columns the register-resident sweep kernel of rank r holds on this device (blind chunks with snapshots, and fast
+        sweeps at all, need column blocks of at most this size: dist.sharded_hals_solve)."""
+        hit = self._resident_cols.get(int(r))
+        if hit is None:
+            out = C.c_int64(0)
+            _lib.check(self.lib.nnf_hals_resident_columns(self.ctx, int(r), C.byref(out)), "nnf_hals_resident_columns")
+            hit = self._resident_cols[int(r)] = int(out.value)
+        return hit
 
     def hals_stop_restore(self, sums, head, budget, delta, V, snapshots, status):
         """Device-side replay of the stopping rule over the all-reduced per-sweep sums of a blind chunk (dist.py)."""

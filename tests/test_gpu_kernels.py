@@ -411,6 +411,38 @@ def test_hals_sweep_snapshots(eng, layout, monkeypatch):
         assert torch.equal(ndk, nd[:k])
 
 
+def test_hals_resident_columns_and_blocked_chunks(eng, monkeypatch):
+    """A factor with more columns than the resident sweep kernel holds runs its blind chunks block by block (dist.column_blocks:
+    config E on one, two or four devices).  With the capacity forced down to 768 columns a 50 x 5000 solve must give the factor
+    and the counts of the persistent solve bit for bit, in both forms of the stopping decision; the real capacity is what the
+    occupancy of the kernels says (two 256-column workgroups per CU at ranks 50 and 100 on this device)."""
+    from nn_fac_amd import dist as nd
+    for r in (50, 100):
+        cap = eng.hals_resident_columns(r)
+        assert cap % 256 == 0 and 65536 <= cap <= 2048 * 256
+    rng = np.random.RandomState(12)
+    r, n = 50, 5000
+    A = rng.rand(200, r)
+    UtU, UtM, V0 = dev(A.T @ A), dev(A.T @ (A @ rng.rand(r, n) + 0.3 * rng.rand(200, n))), dev(rng.rand(r, n))
+    want = V0.clone()
+    st = torch.zeros(8, dtype=torch.float64, device="cuda")
+    eng.hals_solve(UtM, UtU, want, 100, delta=0.01, status=st)
+    cnt_want = int(st[1].item())
+    assert 4 < cnt_want < 101
+    monkeypatch.setattr(eng, "hals_resident_columns", lambda rank: 768, raising=False)
+    assert nd.column_blocks(eng, V0) == [(0, 768), (768, 1536), (1536, 2304), (2304, 3072), (3072, 3840), (3840, 4608), (4608, 5000)]
+    for first in (3, cnt_want + 2, 60):                        # chunk too short, window on the stop, stop before the window
+        got = V0.clone()
+        eps, cnt, eps0 = nd.sharded_hals_solve(eng, UtM, UtU, got, None, nd.SweepGuess(first=first, max_chunk=104, window=4),
+                                               budget=100, delta=0.01)
+        assert cnt == cnt_want and torch.equal(got, want)
+    got = V0.clone()
+    status = torch.zeros(8, dtype=torch.float64, device="cuda")
+    nd.sharded_hals_solve_async(eng, UtM, UtU, got, None, nd.SweepGuess(first=cnt_want + 1, max_chunk=104, window=4), status,
+                                budget=100, delta=0.01)
+    assert int(status[1].item()) == cnt_want and int(status[3].item()) == 0 and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("beta", [0.5, 1, 2, 3])
 def test_mu_right_accumulate_then_apply(eng, beta):
     """Row-sharded right update: per-block numerator / denominator, summed, then applied == the one-shot kernel."""

@@ -16,8 +16,16 @@
 // Built for r <= 64 (MT <= 4); larger ranks return NNF_ERR_UNSUPPORTED for beta != 2.
 #include "k_mu_kernels.h"
 
+// One source, three translation units (Makefile: -DMU_PART=0|1|2) so that the ~60 instantiations of the two fused kernels
+// compile side by side: 0 = right update + the small helpers, 1 = left update (beta = 1 and general beta), 2 = the left
+// kernel's cost-carrying forms (KL cost, NTF cost + partial product).  The small kernels and launch templates above the
+// entry points are `static`: every unit sees them, only the units that use them emit them.
+#ifndef MU_PART
+#error "k_mu.hip is compiled per part: -DMU_PART=0|1|2"
+#endif
+
 // F_new = max(F * (num/den)^gamma, 1e-12); num/den summed over slabs in fp64 (fixed order); den_vec: per-row denominator (KL)
-__global__ __launch_bounds__(256) void nnf_mu_finish_kernel(const float* __restrict__ F, int64_t ldf, int r, int64_t cols,
+static __global__ __launch_bounds__(256) void nnf_mu_finish_kernel(const float* __restrict__ F, int64_t ldf, int r, int64_t cols,
                                                             const float* __restrict__ snum, const float* __restrict__ sden,
                                                             int nslab, int64_t slab_stride, int64_t lds,
                                                             const double* __restrict__ den_vec, float gamma,
@@ -38,7 +46,7 @@ __global__ __launch_bounds__(256) void nnf_mu_finish_kernel(const float* __restr
 
 // out[k] = sum_j A[k][j]  (fp64).  Long rows (the r x m factor: one workgroup per row took 112 us at m = 100000) are cut
 // into gridDim.y pieces whose partial sums (part[k][piece]) are added in piece order by a second, tiny launch.
-__global__ __launch_bounds__(256) void nnf_rowsum_kernel(const float* __restrict__ A, int64_t lda, int64_t K,
+static __global__ __launch_bounds__(256) void nnf_rowsum_kernel(const float* __restrict__ A, int64_t lda, int64_t K,
                                                          double* __restrict__ out, int64_t per) {
     __shared__ double red[4];
     const float* p = A + (int64_t)blockIdx.x * lda;
@@ -48,7 +56,7 @@ __global__ __launch_bounds__(256) void nnf_rowsum_kernel(const float* __restrict
     const double t = nnf_block_sum_f64(s, red);
     if (threadIdx.x == 0) out[(int64_t)blockIdx.x * gridDim.y + blockIdx.y] = t;
 }
-__global__ __launch_bounds__(64) void nnf_rowsum_fin_kernel(const double* __restrict__ part, int np, int r,
+static __global__ __launch_bounds__(64) void nnf_rowsum_fin_kernel(const double* __restrict__ part, int np, int r,
                                                             double* __restrict__ out) {
     const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= r) return;
@@ -76,7 +84,7 @@ static int nnf_launch_rowsum(nnf_ws_cursor& cur, const float* A, int64_t lda, in
 
 
 // beta = 2 (Gram form): out[k][j] = max(F[k][j] * num[k][j] / (sum_l G[k][l] F[l][j]), 1e-12)
-__global__ __launch_bounds__(256) void nnf_mu2_finish_kernel(const float* __restrict__ F, int64_t ldf, int r, int64_t cols,
+static __global__ __launch_bounds__(256) void nnf_mu2_finish_kernel(const float* __restrict__ F, int64_t ldf, int r, int64_t cols,
                                                              const float* __restrict__ G, const float* __restrict__ num,
                                                              int64_t ldn, float* __restrict__ out, int64_t ldo) {
     __shared__ float Gs[NNF_MAX_RANK * NNF_MAX_RANK];
@@ -247,6 +255,7 @@ static int mu_args_ok(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_
     return NNF_OK;
 }
 
+#if MU_PART == 1
 extern "C" int nnf_mu_left_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
                                int64_t ldu, const float* V, int64_t ldv, int r, double beta, float* Ut_out, int64_t lduo,
                                void* stream) {
@@ -271,6 +280,8 @@ extern "C" int nnf_mu_left_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t 
     MU_DISPATCH(launch_mu_left, ctx, cur, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, Ut_out, lduo, st);
 }
 
+#endif   // MU_PART == 1
+#if MU_PART == 0
 extern "C" int nnf_mu_right_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
                                 int64_t ldu, const float* V, int64_t ldv, int r, double beta, float* V_out, int64_t ldvo,
                                 void* stream) {
@@ -348,6 +359,8 @@ extern "C" int nnf_mu_apply_f32(nnf_ctx* ctx, const float* F, int64_t ldf, int r
     return NNF_OK;
 }
 
+#endif   // MU_PART == 0
+#if MU_PART == 1
 // Raw KL numerator of the left update, num[k,i] = sum_j (X[i,j] / (UV)[i,j]) V[k,j]  (mu.py:85, before the division by the
 // row sums of V): the `b` term of deep_KL_mu (deep_mu.py:10) is U .* num.  Same fused kernel as nnf_mu_left_f32.
 extern "C" int nnf_mu_left_num_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
@@ -362,6 +375,8 @@ extern "C" int nnf_mu_left_num_f32(nnf_ctx* ctx, const float* X, int64_t m, int6
     MU_DISPATCH(launch_mu_left, ctx, cur, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, num, ldnum, st, 1);
 }
 
+#endif   // MU_PART == 1
+#if MU_PART == 0
 // out[p x cols] = A[p x q] * B[q x cols]: a rank-sized left operand against a wide matrix (deep NMF: (W_{l+1} H_{l+1})^T =
 // H_{l+1}^T W_{l+1}^T, deep_nmf.py:93; the rank-sized links of the NTD chains).  One thread per output, k in order.
 __global__ __launch_bounds__(256) void nnf_small_gemm_rect_kernel(const float* __restrict__ A, int64_t lda, int p, int q,
@@ -481,6 +496,8 @@ extern "C" int nnf_deep_kl_apply_f32(nnf_ctx* ctx, const float* F, int64_t ldf, 
     return NNF_OK;
 }
 
+#endif   // MU_PART == 0
+#if MU_PART == 2
 // One pass over a dense 3-way tensor T (I x J x K) for BOTH the squared residual of the current CP model and the partial
 // product the next iteration's mode-0 / mode-1 right-hand sides are contracted from (nnf_mttkrp3_from_partial_f32):
 //   *cost_f64 = sum_ijk (T[i,j,k] - sum_r F0[i,r] F1[j,r] F2[k,r])^2        (ntf.py:470, evaluated directly)
@@ -522,3 +539,4 @@ extern "C" int nnf_mu_left_kl_cost_f32(nnf_ctx* ctx, const float* X, int64_t m, 
     const bool vec = x_vec_ok(X, ldx);
     MU_CALL(launch_mu_left, BM_KLC, true, r, vec, ctx, cur, X, m, n, ldx, Ut, ldu, V, ldv, r, 1.0, Ut_out, lduo, st, 0, ex, cost_f64);
 }
+#endif   // MU_PART == 2

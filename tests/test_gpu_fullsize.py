@@ -142,6 +142,47 @@ def test_bench_single_rank_rccl_smoke(built_lib):
     assert out["roofline"]["kernel"].startswith("nnf_xty_kernel") and out["roofline"]["launch_ms"] > 0
 
 
+@pytest.mark.parametrize("cfg", ["B", "C"])
+def test_sharded_protocol_on_a_one_rank_rccl_group(built_lib, cfg):
+    """The row-sharded step as the driver's N > 1 runs execute it -- over RCCL, so with the device-side stopping decision,
+    the overlapped cost and (MU) the fused KL cost + scalar all-reduce all switched on (dist.opt_in) -- on the one rank a
+    one-GPU box offers (NNF_FORCE_SHARDED=1): same data, same number of iterations as the unsharded run of the same bench
+    command; HALS iterates and costs agree to the tolerance of two differently ordered fp32 sums of the stopping scalar, the MU
+    line to rounding."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(forced):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, NNF_BENCH_INIT_PG="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NNF_BENCH_DEBUG="1")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NNF_SHARDED_ASYNC", "NNF_SHARDED_OVERLAP"):
+            env.pop(k, None)
+        if forced:
+            env.update(NNF_BENCH_FORCE_SHARDED="1", NNF_FORCE_SHARDED="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--config", cfg, "--gpus", "1", "--steps", "12",
+               "--warmup", "2", "--shape", "30000,600,18", "--no-cpu", "--no-extra", "--no-fixed", "--no-kernels"]
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0]), p.stderr
+
+    plain, _ = run(False)
+    shard, err = run(True)
+    assert shard["n_gpus"] == 1 and "nccl" in shard["config"]["parallelism"]
+    a, b = plain["config"]["final_cost"], shard["config"]["final_cost"]
+    assert abs(a - b) <= (1e-3 if cfg == "B" else 1e-5) * abs(a), (a, b)
+    if cfg == "B":
+        assert plain["config"]["inner_sweeps_per_step_last"] == shard["config"]["inner_sweeps_per_step_last"]
+        assert "sharded U-side protocol" in err          # the protocol really ran (bench.py's debug line)
+
+
 def test_config_e_full_size_on_one_gpu(built_lib):
     """configs[4] at its FULL size on one GPU (10^6 x 4000, rank 100: X is 16 GB, never on the host; bench.py's generator):
     one HALS iteration through the product's step, checked by size-independent properties -- the oracle would need ~50 GB and

@@ -15,46 +15,13 @@ struct mu_left_extra {
 
 // F_K image of a 64-wide chunk of a row-major r x K matrix A (the rank index is the MFMA k index):
 //   img[(t*MT + s4)*64 + lane].c = A[16*s4 + 4*c + (lane>>4)][k0 + 16*t + (lane&15)]       (zero outside r x K)
-template <int MT>
-__device__ __forceinline__ void stageK_load(const float* __restrict__ A, int64_t lda, int r, int64_t K, int64_t k0,
-                                            f32x4 (&regs)[MT]) {
-    const int t = threadIdx.x >> 6, L = threadIdx.x & 63;
-    const int64_t col = k0 + 16 * t + (L & 15);
-#pragma unroll
-    for (int s4 = 0; s4 < MT; ++s4) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (col < K) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int row = 16 * s4 + 4 * c + (L >> 4);
-                if (row < r) v[c] = A[(int64_t)row * lda + col];
-            }
-        }
-        regs[s4] = v;
-    }
-}
+// (loaded by stageK_bload, k_stream_common.h)
 template <int MT>
 __device__ __forceinline__ void stageK_store(f32x4* __restrict__ img, const f32x4 (&regs)[MT]) {
     const int t = threadIdx.x >> 6, L = threadIdx.x & 63;
 #pragma unroll
     for (int s4 = 0; s4 < MT; ++s4) img[(t * MT + s4) * 64 + L] = regs[s4];
 }
-template <int MT>
-__device__ __forceinline__ void stageK(const float* __restrict__ A, int64_t lda, int r, int64_t K, int64_t k0,
-                                       f32x4* __restrict__ img) {
-    f32x4 regs[MT];
-    stageK_load<MT>(A, lda, r, K, k0, regs);
-    stageK_store<MT>(img, regs);
-}
-
-template <int MT>
-__device__ __forceinline__ void stageA_direct(const float* __restrict__ A, int64_t lda, int r, int64_t K, int64_t k0,
-                                              bool vec_ok, f32x4* __restrict__ img) {
-    f32x4 regs[MT];
-    stageA_load<MT>(A, lda, r, K, k0, vec_ok, regs);
-    stageA_store<MT>(img, regs);
-}
-
 // Which rank steps (4 ranks each) of MFMA #1 run.  MT = ceil(r / 16), so every 16-rank group but the last is full; with the
 // resident fragments in registers (zero beyond r, like the chunk image) the last group runs 2 or 4 steps behind ONE
 // wave-uniform flag: a test per step (4*s4 + c < KS) splits the product into 16 basic blocks and pins every LDS read of

@@ -105,12 +105,15 @@ static size_t mu_shm(int MT, int REM, int r, bool regf) {   // two double-buffer
     return ((regf ? 0 : (size_t)4 * ((r + 3) / 4) * 64) + (size_t)2 * (2 * MT + (REM > 0 ? 1 : 0)) * 256) * 16;
 }
 
-#define MU_REM_MAX 2   // leftover ranks handled on the VALU pipe (4 made hipcc spill hundreds of registers: not instantiated)
+// leftover ranks handled on the VALU pipe: up to 4 next to one MFMA tile (ranks 17..20), up to 2 next to two or three (33, 34,
+// 49, 50) -- four leftover ranks at two tiles left scratch reloads inside the right kernel's chunk loop, at three tiles hipcc
+// spilled hundreds of registers (256 per wave at two workgroups per CU)
+#define MU_REM_OF(q, rem) ((rem) <= 2 ? 2 : ((q) == 1 && (rem) <= 4 ? 4 : 0))
 // Rank split of the fused kernels: MT full 16-rank tiles on MFMA, plus -- for 16q+1 .. 16q+4 ranks, aligned X, not the
 // general-beta form -- the leftover ranks on the VALU pipe (REM = 2 or 4) instead of a padded tile.
 static inline void mu_split_rank(int r, bool rem_ok, int& MT, int& REM) {
     const int q = r / 16, rem = r % 16;
-    if (rem_ok && q >= 1 && q <= 3 && rem >= 1 && rem <= MU_REM_MAX) { MT = q; REM = rem <= 2 ? 2 : 4; }
+    if (rem_ok && q >= 1 && q <= 3 && rem >= 1 && MU_REM_OF(q, rem) > 0) { MT = q; REM = MU_REM_OF(q, rem); }
     else { MT = (r + 15) / 16; REM = 0; }
 }
 // FN<MT, REM, BM, VEC>(args) over the instantiated (MT, REM, VEC) combinations; BMV without leftover-rank forms: REMOK = false
@@ -123,11 +126,7 @@ static inline void mu_split_rank(int r, bool rem_ok, int& MT, int& REM) {
             case 2: return FN<2, (REMOK) ? 2 : 0, BMV, true>(__VA_ARGS__);                                   \
             default: return FN<3, (REMOK) ? 2 : 0, BMV, true>(__VA_ARGS__);                                  \
         }                                                                                                    \
-        if (REM_ == 4) switch (MT_) {                                                                        \
-            case 1: return FN<1, (REMOK) ? MU_REM_MAX : 0, BMV, true>(__VA_ARGS__);                          \
-            case 2: return FN<2, (REMOK) ? MU_REM_MAX : 0, BMV, true>(__VA_ARGS__);                          \
-            default: return FN<3, (REMOK) ? MU_REM_MAX : 0, BMV, true>(__VA_ARGS__);                         \
-        }                                                                                                    \
+        if (REM_ == 4) return FN<1, (REMOK) ? 4 : 0, BMV, true>(__VA_ARGS__);                                \
         switch (MT_) {                                                                                       \
             case 1: return (VECF) ? FN<1, 0, BMV, true>(__VA_ARGS__) : FN<1, 0, BMV, false>(__VA_ARGS__);    \
             case 2: return (VECF) ? FN<2, 0, BMV, true>(__VA_ARGS__) : FN<2, 0, BMV, false>(__VA_ARGS__);    \
@@ -215,7 +214,7 @@ static int launch_mu_left(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int6
     // length -- R = ceil(T / (16 slots)) rounds of `slots` workgroups, each 8 to 16 tiles, as a mix of two adjacent sizes.
     // 256-row workgroups everywhere put 977 workgroups on the 768 slots of the 250000-row pass of config D: a second round
     // that is 27 % full and as long as the first.  Less than one round of 128-row workgroups: 128 rows each (most CUs busy).
-    const int64_t slots = (int64_t)(BM == BM_GEN ? 1 : ((MT + (REM > 0) <= 2 && BM == BM_FROB) ? 3 : 2)) * ctx->num_cus, T = nnf_cdiv(m, 16);
+    const int64_t slots = (int64_t)MU_LEFT_WGPC(MT, REM, BM) * ctx->num_cus, T = nnf_cdiv(m, 16);
     const int64_t W = nnf_cdiv(T, 16 * slots) * slots;
     int64_t n_hi = 0, n_mid = 0, grid = W;
     if (T <= 8 * slots) {

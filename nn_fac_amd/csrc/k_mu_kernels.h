@@ -32,6 +32,8 @@ __device__ __forceinline__ bool mu_kstep_on(int s4, int c, int KS, bool tail4) {
     else return 4 * s4 + c < KS;
 }
 
+// resident workgroups per CU of the left kernel: three for the small Frobenius forms (<= 168 VGPRs), one for general beta
+#define MU_LEFT_WGPC(MT, REM, BM) ((BM) == BM_GEN ? 1 : (((MT) + ((REM) > 0) <= 2 && (REM) <= 2 && (BM) == BM_FROB) ? 3 : 2))
 #ifndef MU_WG_PER_CU
 #define MU_WG_PER_CU 2
 #endif
@@ -681,7 +683,7 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
 }
 
 template <int MT, int REM, int BM, bool VEC>
-__global__ __launch_bounds__(256, (BM == BM_GEN ? 1 : ((MT + (REM > 0) <= 2 && BM == BM_FROB) ? 3 : 2))) void nnf_mu_left_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+__global__ __launch_bounds__(256, MU_LEFT_WGPC(MT, REM, BM)) void nnf_mu_left_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                              const float* __restrict__ Ut, int64_t ldu,
                                                              const float* __restrict__ V, int64_t ldv, int r, float beta,
                                                              const double* __restrict__ den_vec, float gamma,

@@ -264,6 +264,7 @@ def test_hals_fixed_sweeps_mode(eng, layout, monkeypatch):
 
 MU_SHAPES = [(200, 100, 10), (73, 25, 9), (1000, 260, 50), (513, 130, 33), (300, 7, 3), (5, 300, 2), (2000, 500, 64),
              (260, 150, 18), (640, 200, 49), (333, 77, 17), (900, 300, 52),   # 16q+1..2 ranks: leftover ranks on the VALU pipe
+             (500, 260, 20), (410, 130, 19), (300, 90, 36),                   # 17..20: four leftover ranks; 36: padded
              (700, 333, 65), (1500, 400, 100), (300, 200, 128)]     # r > 64: ratio kernel + plain contractions
 
 

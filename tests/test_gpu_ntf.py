@@ -164,7 +164,7 @@ def test_mttkrp_from_shared_partial(built_lib, shape, R):
 
 @pytest.mark.parametrize("shape,R", [((12, 10, 8), 4), ((33, 65, 17), 7), ((64, 128, 300), 30), ((5, 700, 3), 2),
                                      ((301, 3, 129), 50), ((40, 41, 42), 64), ((37, 29, 70), 18), ((90, 11, 65), 33),
-                                     ((700, 130, 70), 17)])     # 16q+1..2 ranks: leftover ranks on the VALU pipe; 3/2-tile rounds
+                                     ((700, 130, 70), 17), ((41, 33, 129), 20), ((60, 7, 64), 19)])     # 16q+1..2 ranks: leftover ranks on the VALU pipe; 3/2-tile rounds
 def test_fused_cost_and_partial(built_lib, shape, R):
     """nnf_cp3_partial_cost_f32: ONE pass over T gives ||T - [[F0,F1,F2]]||^2 (ntf.py:470) and the partial product
     Y = T x_2 F2^T of the next iteration -- against fp64 NumPy and against the two separate entry points."""

@@ -78,6 +78,13 @@ class _NtfState:
         if _dist.is_sharded(group):
             _dist.allreduce_(self.norm2, group)
         self.guess0 = _dist.SweepGuess()
+        # leading-mode-sharded runs: the mode-0 solve with the device-side stopping decision (dist.sharded_hals_solve_async),
+        # as in the NMF step -- engaged once two consecutive solves differ by <= 4 sweeps, a missed guess redoes the
+        # iteration with the host-synchronous protocol (run_ntf_steps)
+        self.async_sharded = _dist.is_sharded(group) and _dist.opt_in("NNF_SHARDED_ASYNC", group)
+        self.async_ready = self.sync_next = self.last_step_async = False
+        self.last_cnt0 = None
+        self.async_hits = self.async_misses = 0
         self._unf = {}
         self._Y, self._Y_of, self._grams = None, None, {}
         # per-iteration status: one HALS status block per mode, then the cost at [8 * nway]; a ring with pinned host
@@ -266,9 +273,15 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
             cross = Ga if Gb is None else eng.hadamard(Ga, Gb)
             new = Ft[mode].clone()
             if sharded and mode == 0:
-                eps, cnt, eps0 = _dist.sharded_hals_solve(eng, rhs_t, cross, new, st.group, st.guess0, budget=budget,
-                                                          delta=delta, sparsity=sparsity_coefficients[mode])
-                st.block[8 * nstat:8 * nstat + 4] = torch.tensor([eps, cnt, eps0, 0.0], dtype=torch.float64)
+                if st.async_sharded and st.async_ready and not st.sync_next and hasattr(eng, "hals_stop_restore"):
+                    _dist.sharded_hals_solve_async(eng, rhs_t, cross, new, st.group, st.guess0,
+                                                   st.block[8 * nstat:8 * nstat + 8], budget=budget, delta=delta,
+                                                   sparsity=sparsity_coefficients[mode])
+                    st.last_step_async = True
+                else:
+                    eps, cnt, eps0 = _dist.sharded_hals_solve(eng, rhs_t, cross, new, st.group, st.guess0, budget=budget,
+                                                              delta=delta, sparsity=sparsity_coefficients[mode])
+                    st.block[8 * nstat:8 * nstat + 4] = torch.tensor([eps, cnt, eps0, 0.0], dtype=torch.float64)
                 nstat += 1
                 Ft[mode] = new
                 continue
@@ -310,33 +323,66 @@ def run_ntf_steps(st, rank, Ft, n_iter, update_rule, beta, sparsity_coefficients
 
     def retire():
         nonlocal result, stop
-        step = pending.pop(0)
+        step = pending[0]
         step["ev"].synchronize()
         host = st.host[step["slot"]]
         for i in range(step["nstat"]):
-            if int(host[8 * i + _engine.ST_ERR]) != 0:
+            code = int(host[8 * i + _engine.ST_ERR])
+            if code in (_dist.ERR_BEFORE_WINDOW, _dist.ERR_NOT_STOPPED) and step["async0"]:
+                raise _GuessMissed()
+            if code != 0:
                 raise err.EngineError("hals grid barrier timed out; result invalid")
+        pending.pop(0)
         result = step["Ft"]
+        if _dist.is_sharded(st.group) and update_rule == "hals" and 0 not in fixed_modes and step["nstat"] >= 1:
+            cnt0 = int(host[_engine.ST_CNT]) - 1                  # the sharded mode-0 solve is the first status block
+            st.async_ready = st.last_cnt0 is not None and abs(cnt0 - st.last_cnt0) <= 4
+            st.last_cnt0 = cnt0
+            if step["async0"]:                                    # centre the next blind chunk on this count
+                st.async_hits += 1
+                st.guess0.value = max(8, min(cnt0 + 4, st.guess0.max_chunk))
         stop = bool(retired(step["it"], float(host[st.cost_at]),
                             [int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(step["nstat"])]))
 
-    for iteration in range(n_iter):
+    iteration = 0
+    while iteration < n_iter:
         st.select(iteration % st.blocks.shape[0])
+        st.last_step_async = False
         Ft, nstat = _one_ntf_step_dev(st, rank, Ft, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
                                       alpha, delta, fuse_next=True)   # (also in the last iteration: every cost of a run
         #                                        comes from the same kernel, whatever n_iter_max -- bitwise repeatable)
+        st.sync_next = False
         st.host[st.slot].copy_(st.block, non_blocking=cuda)
-        pending.append(dict(it=iteration, slot=st.slot, Ft=Ft, nstat=nstat,
+        pending.append(dict(it=iteration, slot=st.slot, Ft=Ft, nstat=nstat, async0=st.last_step_async,
                             ev=main.record_event() if cuda else _NoEvent()))
-        if len(pending) > 1:
-            retire()
-            if stop:
-                break
-    while pending and not stop:
-        retire()
+        iteration += 1
+        try:
+            if len(pending) > 1:
+                retire()
+                if stop:
+                    break
+            if iteration == n_iter:
+                while pending and not stop:
+                    retire()
+        except _GuessMissed:
+            # the blind chunk of the device-side protocol missed the stopping sweep: drop what is in flight and redo this
+            # iteration with the exact, host-synchronous protocol (every rank takes this branch: the status is a function
+            # of all-reduced sums)
+            failed = pending[0]["it"]
+            if cuda:
+                main.synchronize()
+            pending.clear()
+            st.sync_next = True
+            st.async_misses += 1
+            Ft = result
+            iteration = failed
     if cuda and pending:
         main.synchronize()
     return result
+
+
+class _GuessMissed(Exception):
+    """Leading-mode-sharded run: the device-side stopping decision of the mode-0 solve missed (status 3 / 4)."""
 
 
 class _NoEvent:

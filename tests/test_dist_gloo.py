@@ -163,7 +163,7 @@ def test_chunked_solve_protocol_single_rank(first, max_chunk, window, delta, bud
         assert len(calls) <= 2, calls
 
 
-def _ntf_worker(rank, nranks, port, shape, R, iters, sparsity, q):
+def _ntf_worker(rank, nranks, port, shape, R, iters, sparsity, q, async_guess=None):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=nranks)
     try:
@@ -172,6 +172,9 @@ def _ntf_worker(rank, nranks, port, shape, R, iters, sparsity, q):
         lo, hi = nd.shard_rows(shape[0], rank, nranks)
         st = ntf_mod._NtfState(OracleEngine(), torch.from_numpy(T[lo:hi].copy()), group=dist.group.WORLD)
         st.guess0 = nd.SweepGuess(first=3, max_chunk=5, window=2)
+        if async_guess is not None:      # the device-side decision from the first iteration on (over gloo it is off by default)
+            st.async_sharded, st.async_ready = True, True
+            st.guess0 = nd.SweepGuess(first=async_guess[0], max_chunk=async_guess[1], window=async_guess[2])
         Ft = [torch.from_numpy(F0[0][lo:hi].T.copy())] + [torch.from_numpy(f.T.copy()) for f in F0[1:]]
         costs, sweeps = [], []
 
@@ -181,20 +184,25 @@ def _ntf_worker(rank, nranks, port, shape, R, iters, sparsity, q):
             return False
 
         Ft = ntf_mod.run_ntf_steps(st, R, Ft, iters, "hals", 2, list(sparsity), [], [False] * 3, math.inf, 0.01, retired)
-        q.put((rank, lo, hi, [f.numpy().T.copy() for f in Ft], costs, sweeps))
+        q.put((rank, lo, hi, [f.numpy().T.copy() for f in Ft], costs, sweeps, (st.async_hits, st.async_misses)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sparsity", [[None, None, None], [0.03, 0.02, None]])
-def test_leading_mode_sharded_ntf_equals_unsharded_oracle(sparsity):
+@pytest.mark.parametrize("sparsity,async_guess", [([None, None, None], None), ([0.03, 0.02, None], None),
+                                                  ([None, None, None], (104, 104, 104)),     # one blind chunk holds every stop
+                                                  ([0.03, 0.02, None], (2, 3, 2))])          # chunks too short: every guess missed
+def test_leading_mode_sharded_ntf_equals_unsharded_oracle(sparsity, async_guess):
     """NTF with the leading mode sharded: mode-0 update local + global stopping scalar, the other modes from
-    the all-reduced MTTKRP output and mode-0 Gram, cost all-reduced -- must reproduce the unsharded oracle (ntf.py:422-477)."""
+    the all-reduced MTTKRP output and mode-0 Gram, cost all-reduced -- must reproduce the unsharded oracle (ntf.py:422-477).
+    `async_guess`: the mode-0 solve with the device-side stopping decision (hits) and its rewind to the host-synchronous
+    protocol (misses), as in the NMF step."""
     shape, R, iters, nranks = (23, 9, 7), 4, 4, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_ntf_worker, args=(k, nranks, port, shape, R, iters, sparsity, q)) for k in range(nranks)]
+    procs = [ctx.Process(target=_ntf_worker, args=(k, nranks, port, shape, R, iters, sparsity, q, async_guess))
+             for k in range(nranks)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(nranks))
@@ -206,11 +214,15 @@ def test_leading_mode_sharded_ntf_equals_unsharded_oracle(sparsity):
     F, costs, _ = orc.compute_ntf(T, R, F0, n_iter_max=iters, tol=0, sparsity_coefficients=list(sparsity),
                                   normalize=[False] * 3, return_costs=True, alpha=math.inf, sweeps=sw)
     np.testing.assert_allclose(np.concatenate([x[3][0] for x in res], axis=0), F[0], rtol=1e-9, atol=1e-12)
-    for rank, lo, hi, Fl, cl, sl in res:
+    for rank, lo, hi, Fl, cl, sl, (hits, misses) in res:
         for k in (1, 2):
             np.testing.assert_allclose(Fl[k], F[k], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(cl, costs, rtol=1e-7, atol=1e-13)
         assert sl == sw
+        if async_guess == (104, 104, 104):
+            assert hits >= 2 and misses == 0      # (the settling rule takes one iteration out: no previous count yet)
+        elif async_guess is not None:
+            assert misses >= 1
 
 
 @pytest.mark.parametrize("config,shape", [("B", "301,40,6"), ("C", "203,30,5"), ("D", "14,14,3")])

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void nnf_hals_sum_sweeps_kernel(const double* 
 
 // ---------------------------------------------------------------------------------------------------------
 static int pick_rp(int r) {
-    static const int opts[] = {8, 16, 24, 32, 40, 48, 50, 52, 56, 64, 80, 96, 104, 112, 128};
+    static const int opts[] = {8, 16, 24, 32, 40, 48, 50, 52, 56, 64, 80, 96, 100, 104, 112, 128};   // 100: config E's rank
     for (int o : opts)
         if (r <= o) return o;
     return -1;

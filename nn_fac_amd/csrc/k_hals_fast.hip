@@ -431,7 +431,7 @@ int nnf_hals_fast_part1(nnf_ctx* ctx, int RP, const hals_args& a, int max_blocks
 }
 #elif HALS_PART == 2
 int nnf_hals_fast_part2(nnf_ctx* ctx, int RP, const hals_args& a, int max_blocks_cap, int* nblocks_out, hipStream_t st) {
-    switch (RP) { HALS_CASE(80) HALS_CASE(96) HALS_CASE(104) default: return NNF_ERR_UNSUPPORTED; }
+    switch (RP) { HALS_CASE(80) HALS_CASE(96) HALS_CASE(100) HALS_CASE(104) default: return NNF_ERR_UNSUPPORTED; }
 }
 #else
 int nnf_hals_fast_part3(nnf_ctx* ctx, int RP, const hals_args& a, int max_blocks_cap, int* nblocks_out, hipStream_t st) {

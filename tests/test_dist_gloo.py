@@ -163,6 +163,42 @@ def test_chunked_solve_protocol_single_rank(first, max_chunk, window, delta, bud
         assert len(calls) <= 2, calls
 
 
+@pytest.mark.parametrize("first,window", [(3, 2), (30, 4), (100, 8)])
+def test_chunked_solve_over_column_blocks(first, window):
+    """dist.column_blocks / _blind_sweeps: an engine whose resident sweep kernel holds fewer columns than the factor has (config E
+    on one, two or four devices) runs the blind chunks block by block, adds the blocks' per-sweep sums in block order, restores
+    from per-block snapshots -- and must return what the one-block run returns, in both forms of the stopping decision."""
+    from nn_fac_amd import dist as nd
+    rng = np.random.RandomState(first)
+    r, n = 5, 700
+    U = rng.rand(60, r)
+    M = U @ rng.rand(r, n) + 1e-2 * rng.rand(60, n)
+    UtU, UtM, V0 = U.T @ U, U.T @ M, rng.rand(r, n)
+    want, eps, cnt, _ = orc.hals_nnls_acc(UtM, UtU, V0, maxiter=100, alpha=math.inf, delta=0.01)
+    seen = []
+
+    class Small(OracleEngine):
+        def hals_resident_columns(self, rank):
+            return 256
+
+        def hals_sweeps(self, UtM, UtU, V, nsweeps, **kw):
+            seen.append(int(V.shape[1]))
+            return super().hals_sweeps(UtM, UtU, V, nsweeps, **kw)
+
+    eng = Small()
+    assert nd.column_blocks(eng, torch.from_numpy(V0)) == [(0, 256), (256, 512), (512, 700)]
+    F = torch.from_numpy(V0.copy())
+    e2, c2, _ = nd.sharded_hals_solve(eng, torch.from_numpy(UtM), torch.from_numpy(UtU), F, None,
+                                      nd.SweepGuess(first=first, max_chunk=104, window=window), budget=100, delta=0.01)
+    assert c2 == cnt and max(seen) == 256 and np.allclose(F.numpy(), want, rtol=1e-12, atol=0) and abs(e2 - eps) <= 1e-12 * eps
+    if cnt - 1 <= first and cnt - 1 > first - window:      # the device-side form needs the stop inside its one chunk's window
+        F = torch.from_numpy(V0.copy())
+        status = torch.zeros(8, dtype=torch.float64)
+        nd.sharded_hals_solve_async(eng, torch.from_numpy(UtM), torch.from_numpy(UtU), F, None,
+                                    nd.SweepGuess(first=first, max_chunk=104, window=window), status, budget=100, delta=0.01)
+        assert int(status[1]) == cnt and int(status[3]) == 0 and np.allclose(F.numpy(), want, rtol=1e-12, atol=0)
+
+
 def _ntf_worker(rank, nranks, port, shape, R, iters, sparsity, q, async_guess=None):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=nranks)

@@ -71,6 +71,38 @@ __device__ __forceinline__ f32x2 sg_pair(const sgbuf<W>& d, int p) {   // floats
     return f32x2{d.r[j3], d.r[j3 + 1]};
 }
 
+// Issue point of the exchange prefetch INSIDE a sweep.  With lag-one speculation the global sum of sweep s-1 is consumed after
+// sweep s; its granule loads used to go out right before sweep s -- when the workgroups running a little behind have not
+// published yet: 46 % of the granules came back stale (counted) and every sweep paid one or two more L2 round trips in the
+// collect (9.4 against 8.05 us per sweep for the blind sweeps, whatever the rank).  Issued half a sweep later everybody's
+// partial is there.  The issue is four hand-written vector loads from addresses prepared BEFORE the sweep: no scalar
+// instruction, no branch, no exec mask in the middle of the hand-scheduled scalar loads (a C++ version there made hipcc
+// shuffle in-flight scalar destinations: tools/check_sweep_spills.py).  Threads without a granule of their own read
+// granule 0 and ignore it.  The consumer waits with vmcnt(0) (hals_mid_wait) before it looks at the registers.
+#ifndef HALS_LATE_ISSUE
+#define HALS_LATE_ISSUE 1      // 0: the exchange prefetch goes out before the sweep (A/B builds)
+#endif
+#ifndef HALS_MID_AT
+#define HALS_MID_AT(R) ((R) - 1)
+#endif
+struct hals_mid_none {
+    __device__ __forceinline__ void operator()() const {}
+};
+struct hals_mid_issue {
+    unsigned long long a0, a1;
+    hals_prefetch& pf;
+    __device__ __forceinline__ void operator()() const {
+        static_assert(HALS_PF == 2, "two granule pairs per thread");
+        asm volatile("global_load_dwordx2 %0, %4, off sc1\n\tglobal_load_dwordx2 %1, %4, off offset:8 sc1\n\t"
+                     "global_load_dwordx2 %2, %5, off sc1\n\tglobal_load_dwordx2 %3, %5, off offset:8 sc1"
+                     : "=&v"(pf.g0[0]), "=&v"(pf.g1[0]), "=&v"(pf.g0[1]), "=&v"(pf.g1[1])
+                     : "v"(a0), "v"(a1));
+    }
+};
+__device__ __forceinline__ void hals_mid_wait(hals_prefetch& pf) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf.g0[0]), "+v"(pf.g1[0]), "+v"(pf.g0[1]), "+v"(pf.g1[1]));
+}
+
 // One Gauss-Seidel sweep for 32 < R <= 64 with the UtM column resident.  Operands are pre-scaled by 1/diag:
 // Gs = diag(1/diag) UtU (rows with a zero diagonal are all zero) and b = (UtM - sp)/diag, so a row update is
 //     x = b[k] - Gs[k,:].v ;  d = max(x, -v[k]) ;  v[k] += d ;  nodelta += d*d          (nnls.py:162-170)
@@ -80,9 +112,9 @@ __device__ __forceinline__ f32x2 sg_pair(const sgbuf<W>& d, int p) {   // floats
 // part and the row bookkeeping -- so the single lgkmcnt(0) per row finds both in (or nearly in) the registers.
 // GUARD: some Gram diagonal is zero (rare).  Such a row must be left alone whatever it holds (nnls.py:160): d is
 // multiplied by the row's nz flag (0/1) fetched with the Y part.  Without GUARD there is no per-row flag at all.
-template <int R, bool GUARD>
+template <int R, bool GUARD, class MID>
 __device__ __forceinline__ float hals_sweep_column_xy(f32x2 (&v2)[R / 2], const float (&b)[R], const float* __restrict__ Gs,
-                                                      const float* __restrict__ nzp) {
+                                                      const float* __restrict__ nzp, const MID& mid) {
     constexpr int RS = 64, P = R / 2, YW = 24, XW = (R - YW + 3) & ~3, XP = XW / 2;
     static_assert(YW == 24, "the Y issue statement below is written for x16 + x8");
     static_assert(R > 32 && R <= 64 && R % 2 == 0 && XW + YW <= RS && XW >= 8, "row split");
@@ -97,6 +129,7 @@ __device__ __forceinline__ float hals_sweep_column_xy(f32x2 (&v2)[R / 2], const 
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int cur = k & 1, nxt = cur ^ 1;
+        if (k == HALS_MID_AT(R)) mid();
         if constexpr (GUARD) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dv[cur]));
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         sg_arrived<XW>(X);
@@ -145,9 +178,9 @@ __device__ __forceinline__ float hals_sweep_column_xy(f32x2 (&v2)[R / 2], const 
 //   v[k] <- max(v[k] + x, 0)            (== v[k] + max(x, -v[k]) of the reference, same rounding)
 //   step  = x if not clipped else -v[k]
 // Gp: padded Gram, row stride RS = 32*ceil(R/32) floats (zeros past r), followed by R pairs (1/diag, nz): (0, 0) = skip row.
-template <int R, bool KEEPB>
+template <int R, bool KEEPB, class MID>
 __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const float (&b)[KEEPB ? R : 1], rsrc_t rb, int voff,
-                                                   int ldm4, const float* __restrict__ Gp, float sp) {
+                                                   int ldm4, const float* __restrict__ Gp, float sp, const MID& mid) {
     constexpr int NBLK = (R + 31) / 32, RS = 32 * NBLK, P = R / 2, DOFF = R * RS;
     const uint64_t base = (uint64_t)Gp;
     f32x16 buf[2][2];
@@ -164,6 +197,7 @@ __device__ __forceinline__ float hals_sweep_column(f32x2 (&v2)[R / 2], const flo
     NNF_SLOAD2D(buf[0][0], buf[0][1], dv[0], base, 0, DOFF);
 #pragma unroll
     for (int k = 0; k < R; ++k) {
+        if (k == HALS_MID_AT(R)) mid();
         f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};   // four chains: FMA latency > 2 issues
         float di = 0.f;
 #pragma unroll
@@ -238,11 +272,11 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
     const int ldv4 = (int)(a.ldv * 4), ldm4 = (int)(a.ldm * 4);
     f32x2 v2[RP / 2];
     float b[KEEPB ? RP : 1];
-    auto sweep = [&](int voff) -> float {
+    auto sweep = [&](int voff, const auto& mid) -> float {
         if constexpr (XY) {
-            return all_live ? hals_sweep_column_xy<RP, false>(v2, b, a.Gs, a.dinv) : hals_sweep_column_xy<RP, true>(v2, b, a.Gs, a.dinv);
+            return all_live ? hals_sweep_column_xy<RP, false>(v2, b, a.Gs, a.dinv, mid) : hals_sweep_column_xy<RP, true>(v2, b, a.Gs, a.dinv, mid);
         } else {
-            return hals_sweep_column<RP, KEEPB>(v2, b, rb, voff, ldm4, a.Gp, a.sp);
+            return hals_sweep_column<RP, KEEPB>(v2, b, rb, voff, ldm4, a.Gp, a.sp, mid);
         }
     };
     auto load_col = [&](int voff) {
@@ -292,15 +326,30 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
             }
         }
         if constexpr (RES) {
-            if constexpr (SPEC)
+            float f;
+            if constexpr (SPEC && (RP > 52 || !HALS_LATE_ISSUE)) {   // (RP > 52: 240+ VGPRs already, no room for the four address registers)
                 if (a.mode == 0 && s >= 2) hals_collect_issue(a.sy, s - 1, nblocks, pf);   // consumed after this sweep
-            const float f = sweep(voff0);
+                f = sweep(voff0, hals_mid_none{});
+            } else if constexpr (SPEC) {
+                // granules of sweep s-1, consumed after this sweep: their loads go out in the middle of it (hals_mid_issue);
+                // nothing to collect (fixed-count mode, first sweep): row 0 of the region is read and ignored (pf.s = 0)
+                const bool want = a.mode == 0 && s >= 2;
+                const unsigned long long* row = reinterpret_cast<const unsigned long long*>(a.sy.sslots) +
+                                                (size_t)(want ? s - 1 : 0) * nblocks * 2;
+                const int b0 = (int)threadIdx.x < nblocks ? (int)threadIdx.x : 0;
+                const int b1 = (int)threadIdx.x + 256 < nblocks ? (int)threadIdx.x + 256 : 0;
+                pf.s = want ? s - 1 : 0;
+                f = sweep(voff0, hals_mid_issue{(unsigned long long)(row + 2 * (size_t)b0), (unsigned long long)(row + 2 * (size_t)b1), pf});
+                hals_mid_wait(pf);
+            } else {
+                f = sweep(voff0, hals_mid_none{});
+            }
             nd = gtid < a.ncols ? (double)f : 0.0;
         } else {
             for (int64_t col = gtid; col < a.ncols; col += gthreads) {
                 const int voff = (int)(col * 4);
                 load_col(voff);
-                nd += (double)sweep(voff);
+                nd += (double)sweep(voff, hals_mid_none{});
                 store_col(voff);
             }
         }

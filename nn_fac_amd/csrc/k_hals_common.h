@@ -152,6 +152,38 @@ __device__ __forceinline__ bool hals_collect(const hals_sync& sy, int s, int nbl
     return ok;
 }
 
+// Issue point of the exchange prefetch INSIDE a sweep.  With lag-one speculation the global sum of sweep s-1 is consumed after
+// sweep s; its granule loads used to go out right before sweep s -- when the workgroups running a little behind have not
+// published yet: 46 % of the granules came back stale (counted) and every sweep paid one or two more L2 round trips in the
+// collect (9.4 against 8.05 us per sweep for the blind sweeps, whatever the rank).  Issued half a sweep later everybody's
+// partial is there.  The issue is four hand-written vector loads from addresses prepared BEFORE the sweep: no scalar
+// instruction, no branch, no exec mask in the middle of the hand-scheduled scalar loads (a C++ version there made hipcc
+// shuffle in-flight scalar destinations: tools/check_sweep_spills.py).  Threads without a granule of their own read
+// granule 0 and ignore it.  The consumer waits with vmcnt(0) (hals_mid_wait) before it looks at the registers.
+#ifndef HALS_LATE_ISSUE
+#define HALS_LATE_ISSUE 1      // 0: the exchange prefetch goes out before the sweep (A/B builds)
+#endif
+#ifndef HALS_MID_AT
+#define HALS_MID_AT(R) ((R) - 1)
+#endif
+struct hals_mid_none {
+    __device__ __forceinline__ void operator()() const {}
+};
+struct hals_mid_issue {
+    unsigned long long a0, a1;
+    hals_prefetch& pf;
+    __device__ __forceinline__ void operator()() const {
+        static_assert(HALS_PF == 2, "two granule pairs per thread");
+        asm volatile("global_load_dwordx2 %0, %4, off sc1\n\tglobal_load_dwordx2 %1, %4, off offset:8 sc1\n\t"
+                     "global_load_dwordx2 %2, %5, off sc1\n\tglobal_load_dwordx2 %3, %5, off offset:8 sc1"
+                     : "=&v"(pf.g0[0]), "=&v"(pf.g1[0]), "=&v"(pf.g0[1]), "=&v"(pf.g1[1])
+                     : "v"(a0), "v"(a1));
+    }
+};
+__device__ __forceinline__ void hals_mid_wait(hals_prefetch& pf) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf.g0[0]), "+v"(pf.g1[0]), "+v"(pf.g0[1]), "+v"(pf.g1[1]));
+}
+
 // Barrier-lean forms for the persistent sweep loop: `red` is a per-sweep-parity slot array ((blockDim/64) doubles each),
 // so a slot is rewritten only two sweeps later, with a barrier in between -- no trailing barrier is needed, and the
 // time-out flag is armed once before the loop instead of per call.  One __syncthreads each.

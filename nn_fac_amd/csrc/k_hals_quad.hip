@@ -91,12 +91,18 @@ __device__ __forceinline__ void quad_row(const f32x4q (&g)[((CH + 3) & ~3) / 4],
 // The hand-issued loads define their registers long before the data lands, which is only safe without control flow
 // between issue and wait (a branch merge lets the register allocator copy a buffer that is still in flight) -- hence no
 // per-row tests here: the <= 3 padding rows k >= r run as no-ops (G' row, b' and v are 0 there).
+#ifndef QUAD_MID_SEL
+#define QUAD_MID_SEL 1     // row at which the exchange prefetch goes out: 1 the last one, 2 the middle one, 0 never (A/B builds)
+#endif
+#define QUAD_MID_AT(RQ) (QUAD_MID_SEL == 1 ? (RQ) - 1 : (QUAD_MID_SEL == 2 ? (RQ) / 2 : 99999))
 template <int CH, int K>
 struct quad_rows {
     static constexpr int RQ = 4 * CH, CHP = (CH + 3) & ~3, NP = CHP / 4, RS4 = 4 * CHP * 4;
+    template <class MID>
     static __device__ __forceinline__ void run(f32x4q (&g)[3][NP], float (&v)[CH], const float (&b)[CH], const float (&own)[4],
-                                               unsigned laddr, float& nd) {
+                                               unsigned laddr, float& nd, const MID& mid) {
         constexpr int cur = K % 3, nx2 = (K + 2) % 3;
+        if constexpr (K == QUAD_MID_AT(RQ)) mid();   // exchange prefetch of the previous sweep's sums (k_hals_common.h)
         if constexpr (K + 1 < RQ) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(NP) : "memory");   // row K+1 may be in flight
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -107,11 +113,12 @@ struct quad_rows {
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(g[nx2][i]) : "v"(laddr), "i"((K + 2) * RS4 + i * 16));
         }
         quad_row<CH, K>(g[cur], v, b, own, nd);
-        if constexpr (K + 1 < RQ) quad_rows<CH, K + 1>::run(g, v, b, own, laddr, nd);
+        if constexpr (K + 1 < RQ) quad_rows<CH, K + 1>::run(g, v, b, own, laddr, nd, mid);
     }
 };
-template <int CH>
-__device__ __forceinline__ float quad_sweep_all_live(float (&v)[CH], const float (&b)[CH], const float (&own)[4], unsigned laddr) {
+template <int CH, class MID>
+__device__ __forceinline__ float quad_sweep_all_live(float (&v)[CH], const float (&b)[CH], const float (&own)[4], unsigned laddr,
+                                                     const MID& mid) {
     constexpr int RQ = 4 * CH, CHP = (CH + 3) & ~3, NP = CHP / 4, RS4 = 4 * CHP * 4;
     f32x4q g[3][NP];
     float nd = 0.f;
@@ -121,7 +128,7 @@ __device__ __forceinline__ float quad_sweep_all_live(float (&v)[CH], const float
 #pragma unroll
         for (int i = 0; i < NP; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(g[1][i]) : "v"(laddr), "i"(RS4 + i * 16));
     }
-    quad_rows<CH, 0>::run(g, v, b, own, laddr, nd);
+    quad_rows<CH, 0>::run(g, v, b, own, laddr, nd, mid);
     return nd;
 }
 
@@ -202,12 +209,24 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
         if (a.mode == 0) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) vb[j] = v[j];
-            if (s >= 2) hals_collect_issue(a.sy, s - 1, nblocks, pf);   // consumed after this sweep
         }
         float f;
-        if (all_live) {
-            f = quad_sweep_all_live<CH>(v, b, own, laddr);
+        if (all_live && HALS_LATE_ISSUE && nblocks <= 128) {
+            // the granules of sweep s-1 (consumed after this sweep) are fetched late IN the sweep: issued before it, most
+            // come back stale -- the other workgroups finish their sweep s-1 at the same moment (k_hals_common.h)
+            const bool want = a.mode == 0 && s >= 2;
+            const unsigned long long* row = reinterpret_cast<const unsigned long long*>(a.sy.sslots) +
+                                            (size_t)(want ? s - 1 : 0) * nblocks * 2;
+            const int b0 = lane < nblocks ? lane : 0, b1 = lane + 64 < nblocks ? lane + 64 : 0;
+            pf.s = want ? s - 1 : 0;
+            f = quad_sweep_all_live<CH>(v, b, own, laddr, hals_mid_issue{(unsigned long long)(row + 2 * (size_t)b0),
+                                                                         (unsigned long long)(row + 2 * (size_t)b1), pf});
+            hals_mid_wait(pf);
+        } else if (all_live) {
+            if (a.mode == 0 && s >= 2) hals_collect_issue(a.sy, s - 1, nblocks, pf);   // consumed after this sweep
+            f = quad_sweep_all_live<CH>(v, b, own, laddr, hals_mid_none{});
         } else {
+            if (a.mode == 0 && s >= 2) hals_collect_issue(a.sy, s - 1, nblocks, pf);
             f = 0.f;
             quad_rows_checked<CH, 0>::run(lg + q * CHP, v, b, own, nz_lo, nz_hi, f);
         }

@@ -518,9 +518,109 @@ __global__ __launch_bounds__(256) void nnf_gram_kernel(const float* __restrict__
     }
 }
 
+// Short factors (the I_mode x R factors of NTF / NTD: K <= 1024, r <= 64): one workgroup of eight waves, wave w owns the
+// k range [w*kpw, (w+1)*kpw) and reads its operand fragments straight from global memory -- ALL of a wave's loads are in
+// flight at once, so the kernel is one memory round trip + <= 128 MFMAs + one LDS reduction in fixed wave order.  (The
+// chunked kernel above walks K in 64-wide LDS-staged chunks: eight dependent round trips for K = 500, 9 us of a 0.5 ms NTF
+// iteration three times over.)  Both MFMA operands are the same registers: lane (i = l&15, g = l>>4) holds
+// A[16*mt + i][k0 + 4g .. +3]; component c of every lane contracts k0 + 4g + c over g, the four components cover 16 k's.
+template <int MT, int KS>
+__global__ __launch_bounds__(512) void nnf_gram_small_kernel(const float* __restrict__ A, int r, int K, int64_t lda,
+                                                             float* __restrict__ G) {
+    __shared__ f32x4 red[4][MT * MT][64];   // 64 KB at MT = 4
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ii = lane & 15, g = lane >> 4;
+    const int kw = w * (16 * KS);
+    f32x4 fr[KS][MT];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = 16 * mt + ii, k = kw + 16 * s + 4 * g;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < r && k < K) {   // K % 4 == 0 (vector path only): a lane's four k's are in or out together
+                v = *reinterpret_cast<const f32x4*>(A + (int64_t)row * lda + k);
+            }
+            fr[s][mt] = v;
+        }
+    f32x4 acc[MT][MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b) acc[a][b] = MFMA16(fr[s][a][c], fr[s][b][c], acc[a][b]);
+    // fixed order: wave w + 4 is added to wave w, then the four sums in order 0..3
+    if (w >= 4) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) red[w - 4][a * MT + b][lane] = acc[a][b];
+    }
+    __syncthreads();
+    if (w < 4) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const f32x4 x = red[w][a * MT + b][lane];
+                f32x4 y = acc[a][b];
+                y[0] += x[0]; y[1] += x[1]; y[2] += x[2]; y[3] += x[3];
+                red[w][a * MT + b][lane] = y;
+            }
+    }
+    __syncthreads();
+    // tile (a, b), lane l, register reg  <->  G[16a + 4(l>>4) + reg][16b + (l&15)]
+    for (int e = threadIdx.x; e < MT * MT * 64; e += 512) {
+        const int t = e >> 6, l = e & 63;
+        f32x4 s = red[0][t][l];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+            const f32x4 x = red[ww][t][l];
+            s[0] += x[0]; s[1] += x[1]; s[2] += x[2]; s[3] += x[3];
+        }
+        const int a = t / MT, b = t - a * MT, col = 16 * b + (l & 15);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 16 * a + 4 * (l >> 4) + reg;
+            if (row < r && col < r) G[row * r + col] = s[reg];
+        }
+    }
+}
+
+template <int MT>
+static int launch_gram_small(const float* A, int r, int64_t K, int64_t lda, float* G, hipStream_t st) {
+    const int ks = (int)nnf_cdiv(K, 128);   // 16-wide k steps per wave (8 waves)
+#define GRAM_SMALL(KS)                                                                                                 \
+    hipLaunchKernelGGL((nnf_gram_small_kernel<MT, KS>), dim3(1), dim3(512), 0, st, A, r, (int)K, lda, G)
+    switch (ks) {
+        case 1: GRAM_SMALL(1); break;
+        case 2: GRAM_SMALL(2); break;
+        case 3: GRAM_SMALL(3); break;
+        case 4: GRAM_SMALL(4); break;
+        case 5: GRAM_SMALL(5); break;
+        case 6: GRAM_SMALL(6); break;
+        case 7: GRAM_SMALL(7); break;
+        default: GRAM_SMALL(8); break;
+    }
+#undef GRAM_SMALL
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+
 template <int MT>
 static int launch_gram(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
                        hipStream_t st) {
+    if constexpr (MT <= 4) {
+        if (K <= 1024 && (K & 3) == 0 && ldg == r && ((((uintptr_t)A) & 15) == 0) && (lda & 3) == 0)
+            return launch_gram_small<MT>(A, r, K, lda, G, st);
+    }
     // one split per CU (the slab reduction spreads every output element over up to 16 threads, so its cost grows slowly
     // with the split count): 64 splits left a 50 x 100000 Gram at 22 us and a 100 x 125000 one at 127 us
     int64_t nsplit = ctx->num_cus > 8 ? ctx->num_cus : 8;

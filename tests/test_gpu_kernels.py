@@ -49,6 +49,25 @@ def test_gram_xty_xht_frob(eng, m, n, r):
     assert abs(got - want) <= 1e-5 * want
 
 
+@pytest.mark.parametrize("K", [4, 60, 124, 128, 132, 500, 512, 772, 1000, 1024, 1028, 501])
+@pytest.mark.parametrize("r", [1, 7, 16, 17, 30, 33, 48, 50, 64, 65])
+def test_gram_of_short_factors(eng, K, r):
+    """Factors of at most 1024 columns and rank <= 64 (NTF / NTD modes) take the one-workgroup Gram whose waves read their
+    fragments straight from global memory (nnf_gram_small_kernel); K % 4 != 0, K > 1024 and r > 64 take the chunked
+    one.  Every k-step count (1..8 per wave), ragged last step, rank tiles 1..4, a padded row stride, NaNs in the padding."""
+    rng = np.random.RandomState(K * 131 + r)
+    ld = K + 4 * (r % 3)
+    buf = np.full((r + 1, ld), np.nan, dtype=np.float32)
+    buf[:r, :K] = rng.rand(r, K).astype(np.float32) - 0.25
+    Ad = torch.from_numpy(buf).cuda()[:r, :K]
+    A64 = buf[:r, :K].astype(np.float64)
+    got = eng.gram(Ad).cpu().numpy()
+    want = A64 @ A64.T
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max() + 1e-30
+    assert np.array_equal(got, eng.gram(Ad).cpu().numpy())      # same bits on a second call
+
+
 @pytest.mark.parametrize("m", [70001, 98304, 100000, 131072, 131075, 300007])
 @pytest.mark.parametrize("n,r", [(70, 50), (129, 64)])
 def test_xht_row_tilings(eng, m, n, r):

@@ -12,6 +12,9 @@
 // Same MFMA / buffer-load / fragment-order machinery as k_stream.hip; partial slabs are summed in fp64 in a fixed order.
 // unfold/khatri_rao index conventions follow tensorly 0.6.0 (first remaining mode slowest), see SURVEY.md appendix B.
 #include "k_stream_common.h"
+#ifndef MTTKRP_ABL
+#define MTTKRP_ABL 0   // timing-only ablations of nnf_mttkrp_rows_kernel (tools/mttkrp_ablate.sh); 0 = the product
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // segmented V X^T:  out[rk][row] = sum_{s in split} Fs[rk][s] * sum_k Fk[rk][k] * T[row*ldrow + s*segstride + k]
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_seg_kernel(
 // ---------------------------------------------------------------------------------------------------------
 // mode 2:  slab[split][rk][k] = sum_{row in split} Fa[rk][row / nb] * Fb[rk][row % nb] * M[row][k],  M = T as (I*J) x K
 // ---------------------------------------------------------------------------------------------------------
-template <int MT, bool VEC>
+template <int MT, bool VEC, bool KRF>
 __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_rows_kernel(
     const float* __restrict__ M, int64_t m, int64_t n, int64_t ldx, const float* __restrict__ Fa, int64_t lda,
     const float* __restrict__ Fb, int64_t ldb, int64_t nb, int r, float* __restrict__ slabs, int64_t ldp, int ncb,
@@ -156,7 +159,28 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_rows_kernel
         for (int cc = 0; cc < 4; ++cc) acc[mt][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 xb[4][4];
     f32x4 areg[MT];
-    auto genA = [&](int q) {   // areg[mt].c = Fa[row][i] * Fb[row][j] for tensor row (i*nb + j) = i_begin + 64q + 16t + 4g + c
+    // Khatri-Rao operand of a chunk: areg[mt].c = Fa[row][i] * Fb[row][j] for tensor row (i*nb + j) = i_begin + 64q + 16t + 4g + c.
+    // Issued as plain loads at the start of the chunk BEFORE (genA_issue), multiplied right before the LDS store
+    // (genA_finish): the raw factor entries sit in registers across the chunk's MFMAs, so the only wait is the in-order
+    // vmcnt(N) in front of the store with the whole X ring still in flight.  (The first form multiplied inside the
+    // generation loop: hipcc turned the per-entry wrap test into real loops, each followed by s_waitcnt vmcnt(0) -- eight
+    // full drains of the X prefetch ring per chunk, 32 of the kernel's 125 us, tools/mttkrp_ablate.sh.)
+    // Buffer loads with hardware bounds checking: rank rows >= r and entries of tensor rows >= i_end read as zero / are
+    // masked; (ia_c, ib_c) = (row / nb, row % nb) of the chunk issued next, carried from chunk to chunk (one division per
+    // thread up front).  nb < 4 (several wraps inside a lane's four rows) or factors beyond 31-bit offsets: the slow form.
+    const rsrc_t rfa = nnf_make_rsrc(Fa, (uint32_t)((((int64_t)r - 1) * lda + (m + nb - 1) / nb) * 4));
+    const rsrc_t rfb = nnf_make_rsrc(Fb, (uint32_t)((((int64_t)r - 1) * ldb + nb) * 4));
+    const int rowa4 = (int)((int64_t)(threadIdx.x & 15) * lda * 4), rowb4 = (int)((int64_t)(threadIdx.x & 15) * ldb * 4);
+    const int lda64 = (int)(lda * 64), ldb64 = (int)(ldb * 64);   // byte step of one 16-row rank tile
+    int64_t ia_c, ib_c;
+    {
+        const int64_t rr0 = i_begin + 16 * (threadIdx.x >> 6) + 4 * ((threadIdx.x & 63) >> 4);
+        ia_c = rr0 / nb;
+        ib_c = rr0 - ia_c * nb;
+    }
+    float fa0[MT], fa1[MT], fb[MT][4];
+    int kr_wrap = 0, kr_valid = 0;   // bit c: row c of the lane's four wrapped into the next i / exists
+    auto genA_slow = [&](int q) {
         const int t = threadIdx.x >> 6, L = threadIdx.x & 63;
         const int64_t rr = i_begin + 64 * (int64_t)q + 16 * t + 4 * (L >> 4);
         const int64_t ia0 = rr / nb, ib0 = rr - ia0 * nb;
@@ -168,7 +192,7 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_rows_kernel
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (rr + c < i_end) {
-                        int64_t ia = ia0, ib = ib0 + c;   // one division per thread and chunk, then carry
+                        int64_t ia = ia0, ib = ib0 + c;
                         while (ib >= nb) { ib -= nb; ++ia; }
                         v[c] = Fa[(int64_t)row * lda + ia] * Fb[(int64_t)row * ldb + ib];
                     }
@@ -177,16 +201,73 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_rows_kernel
             areg[mt] = v;
         }
     };
-    genA(0);
+    auto genA_issue = [&](int q) {
+#if MTTKRP_ABL == 1
+        return;
+#endif
+        if constexpr (!KRF) { genA_slow(q); return; }
+        const int t = threadIdx.x >> 6, L = threadIdx.x & 63;
+        const int64_t rr = i_begin + 64 * (int64_t)q + 16 * t + 4 * (L >> 4);
+        const int ia0 = (int)ia_c, ib0 = (int)ib_c, nbi = (int)nb;
+        if (nb >= 64) {
+            ib_c += 64;
+            if (ib_c >= nb) { ib_c -= nb; ++ia_c; }
+        } else {
+            const int64_t rn = rr + 64;
+            ia_c = rn / nb;
+            ib_c = rn - ia_c * nb;
+        }
+        const int64_t left = i_end - rr;                       // rows of this lane's four that exist (<= 0: none)
+        kr_valid = left >= 4 ? 15 : left <= 0 ? 0 : ((1 << (int)left) - 1);
+        kr_wrap = 0;
+        int offb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int ib = ib0 + c;
+            const bool wr = ib >= nbi;
+            ib -= wr ? nbi : 0;
+            kr_wrap |= wr ? (1 << c) : 0;
+            offb[c] = ((kr_valid >> c) & 1) ? rowb4 + 4 * ib : (int)0x7ffffff0;
+        }
+        const int offa0 = (kr_valid & 1) ? rowa4 + 4 * ia0 : (int)0x7ffffff0;
+        const int offa1 = (kr_valid & kr_wrap) ? rowa4 + 4 * ia0 + 4 : (int)0x7ffffff0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            fa0[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfa, offa0, mt * lda64, 0));
+            fa1[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfa, offa1, mt * lda64, 0));
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                fb[mt][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfb, offb[c], mt * ldb64, 0));
+        }
+    };
+    auto genA_finish = [&]() {
+#if MTTKRP_ABL == 1
+        for (int mt = 0; mt < MT; ++mt) areg[mt] = f32x4{1.f, 1.f, 1.f, 1.f};
+        return;
+#endif
+        if constexpr (!KRF) return;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float fa = ((kr_wrap >> c) & 1) ? fa1[mt] : fa0[mt];
+                v[c] = ((kr_valid >> c) & 1) ? fa * fb[mt][c] : 0.f;
+            }
+            areg[mt] = v;
+        }
+    };
+    genA_issue(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, (16 * t + c) * ldx4);
+    genA_finish();
     stageA_store<MT>(ldsA[0], areg);
     __syncthreads();
     for (int q = 0; q < nchunk; ++q) {
         const f32x4* img = ldsA[q & 1];
-        genA(q + 1);
+        genA_issue(q + 1);
         const int soff_next = (q + 1) * 64 * ldx4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -198,13 +279,24 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_rows_kernel
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) acc[mt][cc] = MFMA16(af[mt][c], xb[t][c][cc], acc[mt][cc]);
+                    for (int cc = 0; cc < 4; ++cc) {
+#if MTTKRP_ABL == 2
+                        if (mt == 0 && cc == 0) acc[0][0] += xb[t][c] * af[0][c];
+#else
+                        acc[mt][cc] = MFMA16(af[mt][c], xb[t][c][cc], acc[mt][cc]);
+#endif
+                    }
+#if MTTKRP_ABL != 3
 #pragma unroll
             for (int c = 0; c < 4; ++c) xb[t][c] = nnf_bload4<VEC>(rs, voff, soff_next + (16 * t + c) * ldx4);
+#endif
             __builtin_amdgcn_sched_barrier(0);   // keep this group's loads inside the group (see nnf_xty_kernel)
         }
+#if MTTKRP_ABL != 4
+        genA_finish();
         stageA_store<MT>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
         __syncthreads();
+#endif
     }
     if (jl < ldp) {
         float* sl = slabs + (int64_t)ks * r * ldp;
@@ -274,8 +366,14 @@ static int launch_rows(nnf_ctx* ctx, const float* M, int64_t m, int64_t n, const
     if (!slabs) return NNF_ERR_WORKSPACE;
     const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * ncb;
     nnf_probe(ctx, NNF_PROBE_MTTKRP, 0, st);
-    hipLaunchKernelGGL((nnf_mttkrp_rows_kernel<MT, VEC>), dim3(grid), dim3(256), 0, st, M, m, n, n, Fa, lda, Fb, ldb, nb, r,
-                       slabs, ldp, ncb, (int)nsplit, rps);
+    // buffer-addressed Khatri-Rao generation: 31-bit byte offsets into both factors, at most one wrap inside four rows
+    const bool kr_fast = nb >= 4 && (int64_t)r * lda * 4 < (int64_t)0x7fff0000 && (int64_t)r * ldb * 4 < (int64_t)0x7fff0000;
+    if (kr_fast)
+        hipLaunchKernelGGL((nnf_mttkrp_rows_kernel<MT, VEC, true>), dim3(grid), dim3(256), 0, st, M, m, n, n, Fa, lda, Fb, ldb, nb,
+                           r, slabs, ldp, ncb, (int)nsplit, rps);
+    else
+        hipLaunchKernelGGL((nnf_mttkrp_rows_kernel<MT, VEC, false>), dim3(grid), dim3(256), 0, st, M, m, n, n, Fa, lda, Fb, ldb, nb,
+                           r, slabs, ldp, ncb, (int)nsplit, rps);
     NNF_CHECK_LAUNCH();
     nnf_probe(ctx, NNF_PROBE_MTTKRP, 1, st);
     return nnf_launch_reduce_slabs(slabs, (int)nsplit, slab_elems, r, n, ldp, out, ldo, st);

@@ -395,28 +395,48 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
     f32x4 ufr[REGF ? 4 * MT : 1];
     f32x4 urem[NR];
     if constexpr (REGF) {
-        int64_t kra[NT], krb[NT];      // Khatri-Rao left factor: row i of the (A*B) x K view = (i / nb, i % nb), once per tile
-        if (ex.Fb != nullptr) {
+        if (BM == BM_FROB && ex.Fb != nullptr) {   // (only the cost + partial pass of NTF brings a second factor)
+            // Khatri-Rao left factor generated on the fly (loop-invariant: once per wave): row i of the (A*B) x K view is
+            // (i / nb, i % nb), entry k of it Ut[k][i / nb] * Fb[k][i % nb].  Buffer loads with hardware bounds checking
+            // (rank rows >= r and tensor rows >= m: offset outside the descriptor -> 0), ALL of them issued before the first
+            // product: the pointer form with its `k < r` / `i < m` branches ended every product in s_waitcnt vmcnt(0) --
+            // two dozen dependent L2 round trips in front of a workgroup's first MFMA.
+            const rsrc_t ra = nnf_make_rsrc(Ut, (uint32_t)((((int64_t)r - 1) * ldu + (m + ex.nb - 1) / ex.nb) * 4));
+            const rsrc_t rb = nnf_make_rsrc(ex.Fb, (uint32_t)((((int64_t)r - 1) * ex.ldb + ex.nb) * 4));
+            const int ldu4 = (int)(ldu * 4), ldb4 = (int)(ex.ldb * 4);
+            int ka4[NT], kb4[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int64_t i = i0w + 16 * nt + ii;
-                kra[nt] = i / ex.nb;
-                krb[nt] = i - kra[nt] * ex.nb;
+                const int64_t a = i / ex.nb;
+                ka4[nt] = (i < m) ? (int)(a * 4) : (int)0x7ffffff0;
+                kb4[nt] = (i < m) ? (int)((i - a * ex.nb) * 4) : (int)0x7ffffff0;
             }
-        }
+            f32x4 fa[4 * MT + NR], fb[4 * MT + NR];
+#pragma unroll
+            for (int s_ = 0; s_ < 4 * MT + (REM > 0 ? NR : 0); ++s_) {
+                const int k = s_ < 4 * MT ? 4 * s_ + g : 16 * MT + (s_ - 4 * MT);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const bool ok = nt < NT && k < r && ka4[nt < NT ? nt : 0] != (int)0x7ffffff0;
+                    const int oa = ok ? k * ldu4 + ka4[nt < NT ? nt : 0] : (int)0x7ffffff0;
+                    const int ob = ok ? k * ldb4 + kb4[nt < NT ? nt : 0] : (int)0x7ffffff0;
+                    fa[s_][nt] = (nt < NT) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, oa, 0, 0)) : 0.f;
+                    fb[s_][nt] = (nt < NT) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, ob, 0, 0)) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < 4 * MT; ++s_) ufr[s_] = fa[s_] * fb[s_];
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) urem[rr] = (REM > 0) ? fa[4 * MT + rr] * fb[4 * MT + rr] : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
         auto u_row = [&](int k) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (k < r) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int64_t i = i0w + 16 * nt + ii;
-                    if (i < m) {
-                        if (ex.Fb != nullptr) {   // Khatri-Rao row generated on the fly (loop-invariant: once per wave)
-                            v[nt] = Ut[(int64_t)k * ldu + kra[nt]] * ex.Fb[(int64_t)k * ex.ldb + krb[nt]];
-                        } else {
-                            v[nt] = Ut[(int64_t)k * ldu + i];
-                        }
-                    }
+                    if (i < m) v[nt] = Ut[(int64_t)k * ldu + i];
                 }
             }
             return v;
@@ -425,6 +445,7 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
         for (int s_ = 0; s_ < 4 * MT; ++s_) ufr[s_] = u_row(4 * s_ + g);
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) urem[rr] = (REM > 0) ? u_row(16 * MT + rr) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     } else {
         for (int e = threadIdx.x; e < 4 * KS * 64; e += 256) {
             const int ww = e / (KS * 64), rem = e - ww * KS * 64, s_ = rem >> 6, L = rem & 63;

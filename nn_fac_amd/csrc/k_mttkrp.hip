@@ -49,20 +49,24 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_seg_kernel(
     f32x4 xb[4][4];
     f32x4 areg[MT];
 
-    // A tile of chunk q: KR values Fs[row][s] * Fk[row][k0 + ...], zero past the segment end
+    // A tile of chunk q: KR values Fs[row][s] * Fk[row][k0 + ...], zero past the segment end.  The loads go out at the start
+    // of the chunk before (genA), the product is formed in front of the LDS store (genA_finish): multiplied at once, the
+    // Fs entry was waited for with s_waitcnt vmcnt(0) -- a drain of the X ring per chunk (tools/check_loop_drains.py).
+    const rsrc_t rfs = nnf_make_rsrc(Fs, (uint32_t)((((int64_t)r - 1) * lds_ + nseg) * 4));   // rank rows >= r: zero
+    const int rows4 = (int)((int64_t)(threadIdx.x & 15) * lds_ * 4), lds64 = (int)(lds_ * 64);
+    float fs[MT];
     auto genA = [&](int q) {
         const int64_t s = s_begin + q / cps;
         const int64_t k0 = (int64_t)(q % cps) * 64;
         stageA_load<MT>(Fk, ldk, r, (q < nchunk) ? klen : 0, k0, fk_vec_ok, areg);
-        if (q < nchunk) {
-            const int L = threadIdx.x & 63;
+        const int off = (q < nchunk) ? rows4 + (int)(s * 4) : (int)0x7ffffff0;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int row = 16 * mt + (L & 15);
-                const float f = (row < r) ? Fs[(int64_t)row * lds_ + s] : 0.f;
-                areg[mt] *= f;
-            }
-        }
+        for (int mt = 0; mt < MT; ++mt)
+            fs[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfs, off, mt * lds64, 0));
+    };
+    auto genA_finish = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) areg[mt] *= fs[mt];
     };
     // one descriptor per segment (32-bit offsets stay inside the wave's 64 rows of one segment)
     auto seg_rsrc = [&](int q) -> rsrc_t {
@@ -82,6 +86,7 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_seg_kernel(
     genA(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) loadX(0, t);
+    genA_finish();
     stageA_store<MT>(ldsA[0], areg);
     __syncthreads();
 
@@ -111,6 +116,7 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_seg_kernel(
                     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(af[mt][c], xb[t][nt][c], acc[mt][nt]);
             loadX(q + 1, t);
         }
+        genA_finish();
         stageA_store<MT>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
         __syncthreads();
     }
@@ -316,7 +322,7 @@ template <int MT, bool VEC>
 static int launch_seg(nnf_ctx* ctx, const float* T, int64_t nrows, int64_t ldrow, int64_t nseg, int64_t segstride,
                       int64_t klen, const float* Fs, int64_t lds_, const float* Fk, int64_t ldk, int r, float* out,
                       int64_t ldo, hipStream_t st) {
-    if ((64 * ldrow + klen + 256) * 4 >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
+    if ((64 * ldrow + klen + 256) * 4 >= (int64_t)0x7fff0000 || (int64_t)r * lds_ * 4 >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
     const int nrb = (int)nnf_cdiv(nrows, 256);
     const int64_t ldp = nnf_rup(nrows, 4);
     int64_t nsplit = 2 * (int64_t)ctx->num_cus / nrb;

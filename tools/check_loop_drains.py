@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Full drains of the vector-memory queue inside MFMA loops: for every kernel of a gfx950 ISA file (hipcc -S
+--cuda-device-only) list the loops that hold >= 8 v_mfma and count the `s_waitcnt vmcnt(0)` between loop header and back
+edge.  A streaming kernel keeps its X prefetch ring in flight across the loop; a vmcnt(0) inside it (hipcc puts one behind
+loads issued under a branch whose result is used at once) stalls the wave for a whole memory round trip per iteration --
+what cost the mode-2 MTTKRP 30 us of 125.
+    python tools/check_loop_drains.py file.s [kernel-name substring]"""
+import re
+import shutil
+import subprocess
+import sys
+
+src = open(sys.argv[1]).read().split("\n")
+want = sys.argv[2] if len(sys.argv) > 2 else ""
+filt = shutil.which("c++filt") or shutil.which("llvm-cxxfilt")
+starts = [(i, l.split(":")[0]) for i, l in enumerate(src) if re.match(r"^_Z\w+:", l)]
+for i, name in starts:
+    end = next((j for j in range(i, len(src)) if "s_endpgm" in src[j]), len(src))
+    body = src[i:end]
+    labels = {m.group(1): j for j, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    out = []
+    for j, l in enumerate(body):
+        m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+        if m and labels.get(m.group(1), j) < j:
+            seg = body[labels[m.group(1)]:j]
+            nm = sum("v_mfma" in x for x in seg)
+            if nm >= 8:
+                out.append(dict(lines=len(seg), mfma=nm, vmcnt0=sum("vmcnt(0)" in x for x in seg),
+                                barriers=sum("s_barrier" in x for x in seg)))
+    if not out:
+        continue
+    dem = subprocess.run([filt, name], capture_output=True, text=True).stdout.strip() if filt else name
+    if want in dem:
+        print(dem[:110])
+        for o in out:
+            print("   ", o)

@@ -655,14 +655,62 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
     }
     }
     // epilogue: tile (mt, nt): rk = 16mt+4g+reg, i = i0w+16nt+ii
-    auto finish = [&](int rk, int64_t i, float nu, float de) {
-        if (BM == BM_FROB || gamma < 0.f) {   // raw numerator (nnf_mu_left_num_f32; wave-uniform flag)
+    // The update needs the old factor entry and the row's denominator per output element.  ALL of them are loaded first,
+    // from addresses clamped into the factor (no branch around a load), and pinned: with a load inside the `i < m` /
+    // `rk < r` branches hipcc waited for each one alone (s_waitcnt vmcnt(0) twice per element: ~100 dependent round trips at
+    // the end of a kernel whose workgroups all finish together -- nothing left to hide them behind).
+    const bool raw = (BM == BM_FROB) || gamma < 0.f;   // raw numerator (nnf_mu_left_num_f32; wave-uniform flag)
+    float uo[MT][NT][4], dn[MT][4], uor[NR][NT], dnr[NR];
+    if (!raw) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rk = 16 * mt + 4 * g + reg, rkc = rk < r ? rk : r - 1;
+                if constexpr (BM != BM_GEN) dn[mt][reg] = (float)den_vec[rkc];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int64_t i = i0w + 16 * nt + ii, ic = i < m ? i : m - 1;
+                    uo[mt][nt][reg] = Ut[(int64_t)rkc * ldu + ic];
+                }
+            }
+        if constexpr (REM > 0) {
+#pragma unroll
+            for (int rr = 0; rr < REM; ++rr) {
+                const int rkc = (16 * MT + rr) < r ? (16 * MT + rr) : r - 1;
+                dnr[rr] = (float)den_vec[rkc];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int64_t i = i0w + 16 * nt + ii, ic = i < m ? i : m - 1;
+                    uor[rr][nt] = Ut[(int64_t)rkc * ldu + ic];
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                if constexpr (BM != BM_GEN) asm volatile("" : "+v"(dn[mt][reg]));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(uo[mt][nt][reg]));
+            }
+        if constexpr (REM > 0) {
+#pragma unroll
+            for (int rr = 0; rr < REM; ++rr) {
+                asm volatile("" : "+v"(dnr[rr]));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(uor[rr][nt]));
+            }
+        }
+    }
+    auto finish = [&](int rk, int64_t i, float nu, float de, float old) {
+        if (raw) {
             Ut_out[(int64_t)rk * lduo + i] = nu;
             return;
         }
         float ratio = nu / de;
         if (gamma != 1.f) ratio = powf(ratio, gamma);
-        Ut_out[(int64_t)rk * lduo + i] = fmaxf(Ut[(int64_t)rk * ldu + i] * ratio, 1e-12f);
+        Ut_out[(int64_t)rk * lduo + i] = fmaxf(old * ratio, 1e-12f);
     };
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -675,8 +723,8 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                     const int rk = 16 * mt + 4 * g + reg;
                     if (rk < r) {
                         float d;
-                        if constexpr (BM == BM_GEN) d = den[mt][nt][reg]; else d = (float)den_vec[rk];
-                        finish(rk, i, num[mt][nt][reg], d);
+                        if constexpr (BM == BM_GEN) d = den[mt][nt][reg]; else d = dn[mt][reg];
+                        finish(rk, i, num[mt][nt][reg], d, uo[mt][nt][reg]);
                     }
                 }
         }
@@ -691,7 +739,7 @@ __device__ __forceinline__ void nnf_mu_left_body(const float* __restrict__ X, in
                 x += __shfl_xor(x, 16, 64);
                 x += __shfl_xor(x, 32, 64);
                 const int64_t i = i0w + 16 * nt + ii;
-                if (g == 0 && rk < r && i < m) finish(rk, i, x, (float)den_vec[rk]);
+                if (g == 0 && rk < r && i < m) finish(rk, i, x, dnr[rr], uor[rr][nt]);
             }
         }
     }

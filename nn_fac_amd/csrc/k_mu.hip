@@ -34,10 +34,23 @@ static __global__ __launch_bounds__(256) void nnf_mu_finish_kernel(const float* 
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t k = e / cols, j = e - k * cols;
         double nu = 0.0, de = 0.0;
-        for (int s = 0; s < nslab; ++s) nu += (double)snum[(int64_t)s * slab_stride + k * lds + j];
+        // slabs eight at a time (loads of a batch in flight together, sums in slab order): one load per trip is a memory
+        // round trip per slab -- ~100 of them in a row behind the right update of config C
+        auto slab_sum = [&](const float* __restrict__ base) {
+            const float* p = base + k * lds + j;
+            double acc = 0.0;
+            for (int s = 0; s < nslab; s += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(s + u < nslab ? s + u : nslab - 1) * slab_stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (s + u < nslab) ? (double)v[u] : 0.0;
+            }
+            return acc;
+        };
+        nu = slab_sum(snum);
         if (den_vec) de = den_vec[k];
-        else
-            for (int s = 0; s < nslab; ++s) de += (double)sden[(int64_t)s * slab_stride + k * lds + j];
+        else de = slab_sum(sden);
         float ratio = (float)(nu / de);
         if (gamma != 1.f) ratio = powf(ratio, gamma);
         out[k * ldo + j] = fmaxf(F[k * ldf + j] * ratio, 1e-12f);
@@ -52,7 +65,13 @@ static __global__ __launch_bounds__(256) void nnf_rowsum_kernel(const float* __r
     const float* p = A + (int64_t)blockIdx.x * lda;
     const int64_t j0 = (int64_t)blockIdx.y * per, j1 = (j0 + per < K) ? (j0 + per) : K;
     double s = 0.0;
-    for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) s += (double)p[j];
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += 8 * 256) {   // eight loads in flight, added in index order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[j + 256 * u < j1 ? j + 256 * u : j1 - 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (j + 256 * u < j1) ? (double)v[u] : 0.0;
+    }
     const double t = nnf_block_sum_f64(s, red);
     if (threadIdx.x == 0) out[(int64_t)blockIdx.x * gridDim.y + blockIdx.y] = t;
 }

@@ -149,7 +149,14 @@ __global__ __launch_bounds__(256) void nnf_reduce_slabs_kernel(const float* __re
         const int64_t row = e / cols, col = e - row * cols;
         const float* p = slabs + row * lds + col;
         double s = 0.0;
-        for (int k = 0; k < nslab; ++k) s += (double)p[(int64_t)k * slab_stride];
+        // eight slabs in flight, added in slab order (a load per trip waited for alone is a memory round trip per slab)
+        for (int k = 0; k < nslab; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u < nslab ? k + u : nslab - 1) * slab_stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (k + u < nslab) ? (double)v[u] : 0.0;
+        }
         out[row * ldo + col] = (float)s;
     }
 }
@@ -163,12 +170,18 @@ __global__ __launch_bounds__(256) void nnf_reduce_slabs4_kernel(const float* __r
         const int64_t row = e / cq, col = 4 * (e - row * cq);
         const float* p = slabs + row * lds + col;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        for (int k = 0; k < nslab; ++k) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p + (int64_t)k * slab_stride);
-            s0 += (double)v[0];
-            s1 += (double)v[1];
-            s2 += (double)v[2];
-            s3 += (double)v[3];
+        for (int k = 0; k < nslab; k += 4) {   // four slabs in flight, added in slab order
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + u < nslab ? k + u : nslab - 1) * slab_stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = k + u < nslab;
+                s0 += in ? (double)v[u][0] : 0.0;
+                s1 += in ? (double)v[u][1] : 0.0;
+                s2 += in ? (double)v[u][2] : 0.0;
+                s3 += in ? (double)v[u][3] : 0.0;
+            }
         }
         float* o = out + row * ldo + col;
         o[0] = (float)s0;
@@ -197,7 +210,15 @@ __global__ __launch_bounds__(256) void nnf_reduce_slabs_par_kernel(const float* 
         if (e < total) {
             const int64_t row = e / cols, col = e - row * cols;
             const float* p = slabs + row * lds + col;
-            for (int k = k0; k < k1; ++k) s += (double)p[(int64_t)k * slab_stride];
+            // this part's slabs eight at a time: all loads of a batch in flight, added in slab order (one load per trip, each
+            // waited for alone, was 12-16 dependent memory round trips: 16 us behind W^T X at config B)
+            for (int k = k0; k < k1; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u < k1 ? k + u : k1 - 1) * slab_stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += (k + u < k1) ? (double)v[u] : 0.0;
+            }
         }
         part_sum[part][el] = s;
         __syncthreads();

@@ -451,13 +451,25 @@ __global__ __launch_bounds__(256) void nnf_partial_last_kernel(const float* __re
         const int64_t k = row / A, a = row - k * A;
         const float* y = Y + row * B;
         const float* f = Ft + k * ldf;
-        float s0 = 0.f, s1 = 0.f;
-        int64_t b = lane;
-        for (; b + 64 < B; b += 128) {
-            s0 = fmaf(y[b], f[b], s0);
-            s1 = fmaf(y[b + 64], f[b + 64], s1);
+        float s0 = 0.f, s1 = 0.f;   // even / odd 64-element pieces of the row, each in increasing order
+        // eight pieces (both operands) in flight per trip, from clamped addresses: a load per trip waited for alone made a
+        // 500-entry row four dependent memory round trips
+        for (int64_t b0 = lane; b0 < B; b0 += 512) {
+            float yv[8], fv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t b = b0 + 64 * u < B ? b0 + 64 * u : B - 1;
+                yv[u] = y[b];
+                fv[u] = f[b];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (b0 + 64 * u < B) {
+                    if (u & 1) s1 = fmaf(yv[u], fv[u], s1);
+                    else s0 = fmaf(yv[u], fv[u], s0);
+                }
+            }
         }
-        if (b < B) s0 = fmaf(y[b], f[b], s0);
         float s = s0 + s1;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
@@ -475,7 +487,18 @@ __global__ __launch_bounds__(256) void nnf_partial_mid_kernel(const float* __res
     const float* y = Y + (k * A) * B + b;
     const float* f = Ft + k * ldf;     // wave-uniform operand
     float s = 0.f;
-    for (int64_t a = a0; a < a1; ++a) s = fmaf(y[a * B], f[a], s);
+    for (int64_t a = a0; a < a1; a += 8) {   // eight rows in flight per trip (clamped addresses), added in row order
+        float yv[8], fv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t aa = a + u < a1 ? a + u : a1 - 1;
+            yv[u] = y[aa * B];
+            fv[u] = f[aa];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (a + u < a1) s = fmaf(yv[u], fv[u], s);
+    }
     slabs[(chunk * r + k) * ldp + b] = s;
 }
 

@@ -112,7 +112,14 @@ static __global__ __launch_bounds__(256) void nnf_mu2_finish_kernel(const float*
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < cols; j += (int64_t)gridDim.x * 256) {
         for (int k = 0; k < r; ++k) {
             float d = 0.f;
-            for (int l = 0; l < r; ++l) d = fmaf(Gs[k * r + l], F[(int64_t)l * ldf + j], d);
+            for (int l = 0; l < r; l += 8) {   // eight factor entries in flight per trip, same order of the sum
+                float fv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) fv[u] = F[(int64_t)(l + u < r ? l + u : r - 1) * ldf + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (l + u < r) d = fmaf(Gs[k * r + l + u], fv[u], d);
+            }
             out[(int64_t)k * ldo + j] = fmaxf(F[(int64_t)k * ldf + j] * (num[(int64_t)k * ldn + j] / d), 1e-12f);
         }
     }
@@ -334,7 +341,18 @@ __global__ __launch_bounds__(256) void nnf_small_gemm_kernel(const float* __rest
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t k = e / n, j = e - k * n;
         float s = 0.f;
-        for (int l = 0; l < r; ++l) s = fmaf(G[k * r + l], V[(int64_t)l * ldv + j], s);   // same order as nnf_mu2_finish_kernel
+        for (int l = 0; l < r; l += 8) {   // same order as nnf_mu2_finish_kernel; eight entries in flight per trip
+            float vv[8], gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int lc = l + u < r ? l + u : r - 1;
+                vv[u] = V[(int64_t)lc * ldv + j];
+                gv[u] = G[k * r + lc];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (l + u < r) s = fmaf(gv[u], vv[u], s);
+        }
         out[k * ldo + j] = s;
     }
 }

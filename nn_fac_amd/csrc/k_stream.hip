@@ -947,7 +947,13 @@ __global__ __launch_bounds__(256) void nnf_sum_partials_kernel(const double* __r
                                                                double scale, double* __restrict__ out) {
     __shared__ double red[4];
     double s = 0.0;
-    for (int64_t e = threadIdx.x; e < count; e += 256) s += partial[e];
+    for (int64_t e = threadIdx.x; e < count; e += 8 * 256) {   // eight loads in flight, added in index order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[e + 256 * u < count ? e + 256 * u : count - 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (e + 256 * u < count) ? v[u] : 0.0;
+    }
     const double t = nnf_block_sum_f64(s, red);
     if (threadIdx.x == 0) out[0] = t * scale;
 }

@@ -719,12 +719,15 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
                                                           float beta, double* __restrict__ partial,
                                                           const float* __restrict__ Ub, int64_t ldub, int64_t nbu,
                                                           float* __restrict__ R1, float* __restrict__ R2, int64_t ldr,
-                                                          int u_vec_ok) {
+                                                          int u_vec_ok, int vdb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KS = (r + 3) >> 2;                               // k-steps of 4
     float* ldsU = reinterpret_cast<float*>(smem);              // [wave 4][rt 2][KS][64]
-    f32x4* ldsV = reinterpret_cast<f32x4*>(smem + (size_t)4 * 2 * KS * 64 * 4);  // [2][KS][64] float4
-    double* red = reinterpret_cast<double*>(smem + (size_t)4 * 2 * KS * 64 * 4 + (size_t)2 * KS * 64 * 16);
+    // V image: two buffers (vdb = 1: the next block is written while this one is read, one barrier per block) or ONE (vdb = 0:
+    // ranks 77..104, where the second buffer is what keeps a second workgroup off the CU -- 100 KB against 75 KB of the
+    // 160 KB; with a single wave per SIMD the rank-100 cost pass of config E ran at 0.34 of the MFMA peak)
+    f32x4* ldsV = reinterpret_cast<f32x4*>(smem + (size_t)4 * 2 * KS * 64 * 4);  // [vdb ? 2 : 1][KS][64] float4
+    double* red = reinterpret_cast<double*>(smem + (size_t)4 * 2 * KS * 64 * 4 + (size_t)(vdb ? 2 : 1) * KS * 64 * 16);
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int jj = lane & 15, g = lane >> 4;
     const int64_t i0w = (int64_t)blockIdx.x * 128 + 32 * w;
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
         }
     };
     stageV_load(blk0);
-    stageV_store(ldsV + (size_t)(blk0 & 1) * KS * 64);
+    stageV_store(ldsV + (size_t)(vdb ? (blk0 & 1) : 0) * KS * 64);
     // X one block ahead.  (A two-block ring was tried: same time, 12 more registers -- and at <= 136 registers three of these
     // waves leave room on a SIMD for a wave of the persistent V-side sweep kernel, which the outer loop overlaps this
     // kernel with.)  The block past the workgroup's column range is "read" through an out-of-range offset: zeros, no
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
     double dsum = 0.0;
     const float* uf = ldsU + (size_t)(w * 2) * KS * 64 + lane;
     for (int blk = blk0; blk < nblk; ++blk) {
-        const f32x4* img = ldsV + (size_t)(blk & 1) * KS * 64;
+        const f32x4* img = ldsV + (size_t)(vdb ? (blk & 1) : 0) * KS * 64;
         stageV_load(blk + 1);   // past the last block every entry is masked to zero (j >= n)
         f32x4 acc[2][4];
 #pragma unroll
@@ -935,7 +938,8 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
         }
         dsum += (double)loc;
         xload(blk + 1);
-        stageV_store(ldsV + (size_t)((blk + 1) & 1) * KS * 64);
+        if (!vdb) __syncthreads();   // single buffer: every wave is past its last read of this block's image
+        stageV_store(ldsV + (size_t)(vdb ? ((blk + 1) & 1) : 0) * KS * 64);
         __syncthreads();
     }
     const double bs = nnf_block_sum_f64(dsum, red);
@@ -1082,14 +1086,18 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
         NNF_CHECK_LAUNCH();
     }
     const int u_vec_ok = ((((uintptr_t)Ut) & 15) == 0 && (ldu & 3) == 0) ? 1 : 0;
-    const size_t shm = (size_t)4 * 2 * KS * 64 * 4 + (size_t)2 * KS * 64 * 16 + 64;
+    // two V buffers unless dropping one is what lets a second workgroup onto the CU (ranks 77..104: see the kernel)
+    const size_t shm2 = (size_t)4 * 2 * KS * 64 * 4 + (size_t)2 * KS * 64 * 16 + 64, shm1 = shm2 - (size_t)KS * 64 * 16;
+    const size_t lds_cu = 160 * 1024;
+    const int vdb = (2 * shm2 > lds_cu && 2 * shm1 <= lds_cu) ? 0 : 1;
+    const size_t shm = vdb ? shm2 : shm1;
 #define NNF_COST_LAUNCH(VV, NN)                                                                                              \
     do {                                                                                                                     \
         if (shm > 48 * 1024)                                                                                                 \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_cost_kernel<OP, VV, NN>),                           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                 \
         hipLaunchKernelGGL((nnf_cost_kernel<OP, VV, NN>), dim3(grid, csplit), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, Vf, r, \
-                           beta, partial, Ub, ldub, nbu, R1, R2, ldr, u_vec_ok);                                             \
+                           beta, partial, Ub, ldub, nbu, R1, R2, ldr, u_vec_ok, vdb);                                        \
     } while (0)
     nnf_probe(ctx, NNF_PROBE_COST, 0, st);
     if (x_vec_ok(X, ldx)) {

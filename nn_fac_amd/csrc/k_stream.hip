@@ -20,6 +20,9 @@
 //   * Register double buffering: the loads of the next 64-deep chunk are issued right after the MFMAs that free the
 //     registers, so ~16 KB per wave stay in flight (hipcc's in-order vmcnt bookkeeping keeps them counted).
 #include "k_stream_common.h"
+#ifndef XHT_ABL
+#define XHT_ABL 0   // timing-only ablations of nnf_xht_kernel (tools/xht_ablate.sh); 0 = the product
+#endif
 
 // =========================================================================================================
 // xty: slab[ks][rk][j] = sum_{i in split ks} Ut[rk][i] * X[i][j]
@@ -362,6 +365,7 @@ __device__ __forceinline__ void nnf_xht_body(const float* __restrict__ X, int64_
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) af[mt] = img[(mt * 4 + t) * 64 + lane];
             // ragged k tail: never multiply a staged zero by out-of-row data
+#if XHT_ABL != 5
             const int64_t nrem = n - (64 * (int64_t)q + 16 * t + 4 * g);
             if (nrem < 4) {
 #pragma unroll
@@ -370,13 +374,20 @@ __device__ __forceinline__ void nnf_xht_body(const float* __restrict__ X, int64_
                     for (int c = 0; c < 4; ++c)
                         if (c >= nrem) xb[t][nt][c] = 0.f;
             }
+#endif
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(af[mt][c], xb[t][nt][c], acc[mt][nt]);
-            if constexpr (REM > 0) {
+                    for (int nt = 0; nt < NT; ++nt) {
+#if XHT_ABL == 2
+                        if (mt == 0) acc[0][nt][c] += af[0][c] * xb[t][nt][c];
+#else
+                        acc[mt][nt] = MFMA16(af[mt][c], xb[t][nt][c], acc[mt][nt]);
+#endif
+                    }
+            if constexpr (REM > 0 && XHT_ABL != 3) {
 #pragma unroll
                 for (int rr = 0; rr < REM; ++rr) {
                     const f32x4 uv = img[(MT * 4 + t) * 64 + 16 * g + rr];   // V[16MT+rr][64q+16t+4g+c], c = 0..3
@@ -389,12 +400,16 @@ __device__ __forceinline__ void nnf_xht_body(const float* __restrict__ X, int64_
                     }
                 }
             }
+#if XHT_ABL != 1
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * (q + 1) + 64 * t);
+#endif
         }
+#if XHT_ABL != 4
         stageA_store<MTA>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
         __syncthreads();
+#endif
     }
 
     // epilogue: tile (mt, nt): out[16mt + 4g + reg][i0w + 16nt + ii]

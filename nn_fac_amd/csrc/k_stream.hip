@@ -20,6 +20,7 @@
 //   * Register double buffering: the loads of the next 64-deep chunk are issued right after the MFMAs that free the
 //     registers, so ~16 KB per wave stay in flight (hipcc's in-order vmcnt bookkeeping keeps them counted).
 #include "k_stream_common.h"
+#include <type_traits>
 #ifndef XHT_ABL
 #define XHT_ABL 0   // timing-only ablations of nnf_xht_kernel (tools/xht_ablate.sh); 0 = the product
 #endif
@@ -789,20 +790,52 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
                 dstw[(1 * KS + (k >> 2)) * 64 + (k & 3) * 16 + (lane & 15)] = 0.f;
             }
         }
-    } else
-    for (int e = lane; e < 2 * KS * 64; e += 64) {
-        const int rt = e / (KS * 64), rem = e - rt * KS * 64, s = rem >> 6, L = rem & 63;
-        const int k = 4 * s + (L >> 4);
-        const int64_t i = i0w + 16 * rt + (L & 15);
-        float uval = 0.f;
-        if (k < r && i < m) {
-            if (Ub == nullptr) uval = Ut[(int64_t)k * ldu + i];
-            else {  // Khatri-Rao row i = (ia, ib), ib fastest
-                const int64_t ia = i / nbu, ib = i - ia * nbu;
-                uval = Ut[(int64_t)k * ldu + ia] * Ub[(int64_t)k * ldub + ib];
-            }
+    } else {
+        // element-wise staging (ragged last workgroup, unaligned U, Khatri-Rao rows of the CP cost): a lane's entries are
+        // (rt, s) -> Ut[4s + (lane>>4)][i0w + 16rt + (lane&15)], i.e. only TWO tensor rows per lane (one division each for the
+        // Khatri-Rao split), and the loads go out eight at a time from clamped addresses.  (One entry per trip with its
+        // loads under the `k < r && i < m` test was 2 KS dependent round trips + divisions in front of the first MFMA --
+        // longer than the MFMA work of a CP-cost workgroup: 4 column blocks.)
+        const int L = lane;
+        int64_t ia0, ib0, ia1, ib1;
+        const int64_t i_0 = i0w + (L & 15), i_1 = i_0 + 16;
+        const bool ok0 = i_0 < m, ok1 = i_1 < m;
+        if (Ub == nullptr) { ia0 = ok0 ? i_0 : 0; ia1 = ok1 ? i_1 : 0; ib0 = ib1 = 0; }
+        else {
+            const int64_t c0 = ok0 ? i_0 : 0, c1 = ok1 ? i_1 : 0;
+            ia0 = c0 / nbu; ib0 = c0 - ia0 * nbu;
+            ia1 = c1 / nbu; ib1 = c1 - ia1 * nbu;
         }
-        ldsU[(w * 2 + rt) * KS * 64 + s * 64 + L] = uval;
+        float* dstw = ldsU + (size_t)(w * 2) * KS * 64 + L;
+        auto stage = [&](auto kr) {   // kr: with / without the second (Khatri-Rao) factor -- no per-entry branch either way
+            constexpr bool KR = decltype(kr)::value;
+            for (int j0 = 0; j0 < 2 * KS; j0 += 8) {
+                float ua[8], ub[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u < 2 * KS ? j0 + u : 0;
+                    const bool rt = j >= KS;
+                    const int k = 4 * (j - (rt ? KS : 0)) + (L >> 4);
+                    const bool ok = k < r && (rt ? ok1 : ok0);
+                    const int64_t kc = ok ? k : 0;
+                    ua[u] = Ut[kc * ldu + (ok ? (rt ? ia1 : ia0) : 0)];
+                    if constexpr (KR) ub[u] = Ub[kc * ldub + (ok ? (rt ? ib1 : ib0) : 0)];
+                    else ub[u] = 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u;
+                    if (j < 2 * KS) {
+                        const bool rt = j >= KS;
+                        const int k = 4 * (j - (rt ? KS : 0)) + (L >> 4);
+                        const bool ok = k < r && (rt ? ok1 : ok0);
+                        dstw[j * 64] = ok ? ua[u] * ub[u] : 0.f;
+                    }
+                }
+            }
+        };
+        if (Ub != nullptr) stage(std::true_type{});
+        else stage(std::false_type{});
     }
     // V fragments of one 64-column block: img[s][lane] = float4 V[4s + (lane>>4)][j0 + 4(lane&15) .. +3].
     // Staged in two halves: global loads into registers before the MFMAs of the current block, LDS writes after them.

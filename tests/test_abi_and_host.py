@@ -109,3 +109,30 @@ def test_sweep_kernels_never_touch_a_load_destination_before_its_wait(built_lib)
     bad, blocks = mod.check_all()
     assert blocks >= 60, blocks          # every rank instantiation of both kernels was seen
     assert not bad, bad[:3]
+
+
+def test_streaming_kernels_keep_their_prefetch_ring_in_flight(built_lib):
+    """tools/check_loop_drains.py on the ISA the build kept for k_stream / k_mttkrp: the chunk loops of the streaming MFMA
+    kernels of the BASELINE configurations hold no `s_waitcnt vmcnt(0)` -- a full drain of the X prefetch ring per trip is
+    what hipcc emits when a load sits under a branch and its value is used at once (round 2: 30 of the mode-2 MTTKRP's
+    125 us).  A regression shows up here, on the CPU, instead of as a slower bench line."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_loop_drains", os.path.join(ROOT, "tools", "check_loop_drains.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    build = os.path.join(ROOT, "nn_fac_amd", "csrc", "build")
+    want = {"k_stream.s": ["nnf_xty_kernel<3, 2, true>", "nnf_xht_kernel<3, 2, true, 4>", "nnf_xty_kernel<6, 4, true>",
+                           "nnf_xht_kernel<6, 4, true, 4>", "nnf_xty_kernel<2, 0, true>"],
+            "k_mttkrp.s": ["nnf_mttkrp_rows_kernel<2, true, true>", "nnf_mttkrp_seg_kernel<2, true>",
+                           "nnf_mttkrp_rows_kernel<4, true, true>", "nnf_mttkrp_seg_kernel<4, true>"]}
+    for fname, kernels in want.items():
+        path = os.path.join(build, fname)
+        assert os.path.exists(path), f"{path}: the Makefile keeps the ISA of the streaming kernels next to the objects"
+        found = mod.scan(path)
+        for k in kernels:
+            hits = [loops for name, loops in found.items() if k + "(" in name]
+            assert hits, f"{k} not found in {fname}"
+            for loops in hits:
+                main = [l for l in loops if l["mfma"] >= 90]
+                assert main, (k, loops)
+                assert all(l["vmcnt0"] == 0 for l in main), (k, main)

@@ -3,34 +3,47 @@
 --cuda-device-only) list the loops that hold >= 8 v_mfma and count the `s_waitcnt vmcnt(0)` between loop header and back
 edge.  A streaming kernel keeps its X prefetch ring in flight across the loop; a vmcnt(0) inside it (hipcc puts one behind
 loads issued under a branch whose result is used at once) stalls the wave for a whole memory round trip per iteration --
-what cost the mode-2 MTTKRP 30 us of 125.
+what cost the mode-2 MTTKRP 30 us of 125.  tests/test_abi_and_host.py runs `scan` over the streaming
+kernels of the BASELINE configurations.
     python tools/check_loop_drains.py file.s [kernel-name substring]"""
 import re
 import shutil
 import subprocess
 import sys
 
-src = open(sys.argv[1]).read().split("\n")
-want = sys.argv[2] if len(sys.argv) > 2 else ""
-filt = shutil.which("c++filt") or shutil.which("llvm-cxxfilt")
-starts = [(i, l.split(":")[0]) for i, l in enumerate(src) if re.match(r"^_Z\w+:", l)]
-for i, name in starts:
-    end = next((j for j in range(i, len(src)) if "s_endpgm" in src[j]), len(src))
-    body = src[i:end]
-    labels = {m.group(1): j for j, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
-    out = []
-    for j, l in enumerate(body):
-        m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
-        if m and labels.get(m.group(1), j) < j:
-            seg = body[labels[m.group(1)]:j]
-            nm = sum("v_mfma" in x for x in seg)
-            if nm >= 8:
-                out.append(dict(lines=len(seg), mfma=nm, vmcnt0=sum("vmcnt(0)" in x for x in seg),
-                                barriers=sum("s_barrier" in x for x in seg)))
-    if not out:
-        continue
-    dem = subprocess.run([filt, name], capture_output=True, text=True).stdout.strip() if filt else name
-    if want in dem:
-        print(dem[:110])
-        for o in out:
-            print("   ", o)
+
+def scan(path):
+    """{demangled kernel name: [ {lines, mfma, vmcnt0, barriers} per loop holding >= 8 MFMAs ]}"""
+    src = open(path).read().split("\n")
+    filt = shutil.which("c++filt") or shutil.which("llvm-cxxfilt")
+    starts = [(i, l.split(":")[0]) for i, l in enumerate(src) if re.match(r"^_Z\w+:", l)]
+    names = [n for _, n in starts]
+    dem = names
+    if filt and names:
+        dem = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True).stdout.strip().split("\n")
+    res = {}
+    for (i, name), dn in zip(starts, dem):
+        end = next((j for j in range(i, len(src)) if "s_endpgm" in src[j]), len(src))
+        body = src[i:end]
+        labels = {m.group(1): j for j, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+        out = []
+        for j, l in enumerate(body):
+            m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+            if m and labels.get(m.group(1), j) < j:
+                seg = body[labels[m.group(1)]:j]
+                nm = sum("v_mfma" in x for x in seg)
+                if nm >= 8:
+                    out.append(dict(lines=len(seg), mfma=nm, vmcnt0=sum("vmcnt(0)" in x for x in seg),
+                                    barriers=sum("s_barrier" in x for x in seg)))
+        if out:
+            res[dn] = out
+    return res
+
+
+if __name__ == "__main__":
+    want = sys.argv[2] if len(sys.argv) > 2 else ""
+    for dn, loops in scan(sys.argv[1]).items():
+        if want in dn:
+            print(dn[:110])
+            for o in loops:
+                print("   ", o)

@@ -12,6 +12,9 @@
 // Same MFMA / buffer-load / fragment-order machinery as k_stream.hip; partial slabs are summed in fp64 in a fixed order.
 // unfold/khatri_rao index conventions follow tensorly 0.6.0 (first remaining mode slowest), see SURVEY.md appendix B.
 #include "k_stream_common.h"
+#ifndef SEG_ABL
+#define SEG_ABL 0      // the same for nnf_mttkrp_seg_kernel (tools/mttkrp_ablate.sh seg)
+#endif
 #ifndef MTTKRP_ABL
 #define MTTKRP_ABL 0   // timing-only ablations of nnf_mttkrp_rows_kernel (tools/mttkrp_ablate.sh); 0 = the product
 #endif
@@ -58,6 +61,9 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_seg_kernel(
     auto genA = [&](int q) {
         const int64_t s = s_begin + q / cps;
         const int64_t k0 = (int64_t)(q % cps) * 64;
+#if SEG_ABL == 1
+        return;
+#endif
         stageA_load<MT>(Fk, ldk, r, (q < nchunk) ? klen : 0, k0, fk_vec_ok, areg);
         const int off = (q < nchunk) ? rows4 + (int)(s * 4) : (int)0x7ffffff0;
 #pragma unroll
@@ -65,6 +71,10 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_seg_kernel(
             fs[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rfs, off, mt * lds64, 0));
     };
     auto genA_finish = [&]() {
+#if SEG_ABL == 1
+        for (int mt = 0; mt < MT; ++mt) areg[mt] = f32x4{1.f, 1.f, 1.f, 1.f};
+        return;
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) areg[mt] *= fs[mt];
     };
@@ -76,23 +86,26 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_seg_kernel(
         const uint32_t bytes = live ? (uint32_t)(((rows - 1) * ldrow + klen) * 4) : 0u;
         return nnf_make_rsrc(base, bytes);
     };
-    auto loadX = [&](int q, int t) {
+    // X of a whole chunk is requested at ONE point of the loop -- 16 loads back to back, the four 64-byte pieces of a row's
+    // 256 bytes by consecutive instructions -- into the register set the previous chunk has finished with (two sets,
+    // ping-pong).  Refilling each 16-column group right after its MFMAs (one set) spread the four pieces of a row over a
+    // whole chunk of MFMAs: tools/mttkrp_ablate.sh seg showed the kernel bound by its X stream alone (142 us, 141 without its
+    // MFMAs, 81 without the stream: 3.5 TB/s from 64-byte pieces of rows a megabyte apart).
+    auto loadX = [&](f32x4 (&dst)[4][4], int q) {
         const rsrc_t rs = seg_rsrc(q);
-        const int kb = (q % cps) * 256 + 64 * t;            // byte offset of the k-group inside the segment
+        const int kb0 = (q % cps) * 256;                     // byte offset of the chunk inside the segment
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldr4 + kb);
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dst[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldr4 + kb0 + 64 * t);
     };
-
-    genA(0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) loadX(0, t);
-    genA_finish();
-    stageA_store<MT>(ldsA[0], areg);
-    __syncthreads();
-
-    for (int q = 0; q < nchunk; ++q) {
+    f32x4 xb2[4][4];
+    auto chunk = [&](int q, f32x4 (&cur)[4][4], f32x4 (&nxt)[4][4]) {
         const f32x4* img = ldsA[q & 1];
         genA(q + 1);
+#if SEG_ABL != 3
+        loadX(nxt, q + 1);
+#endif
         const int64_t kbase = (int64_t)(q % cps) * 64;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -100,25 +113,45 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_seg_kernel(
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) af[mt] = img[(mt * 4 + t) * 64 + lane];
             // ragged segment tail: the bytes past klen belong to the next tensor row
+#if SEG_ABL != 5
             const int64_t krem = klen - (kbase + 16 * t + 4 * g);
             if (krem < 4) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (c >= krem) xb[t][nt][c] = 0.f;
+                        if (c >= krem) cur[t][nt][c] = 0.f;
             }
+#endif
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = MFMA16(af[mt][c], xb[t][nt][c], acc[mt][nt]);
-            loadX(q + 1, t);
+                    for (int nt = 0; nt < 4; ++nt) {
+#if SEG_ABL == 2
+                        if (mt == 0) acc[0][nt][c] += af[0][c] * cur[t][nt][c];
+#else
+                        acc[mt][nt] = MFMA16(af[mt][c], cur[t][nt][c], acc[mt][nt]);
+#endif
+                    }
         }
+#if SEG_ABL != 4
         genA_finish();
         stageA_store<MT>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
         __syncthreads();
+#endif
+    };
+
+    genA(0);
+    loadX(xb, 0);
+    genA_finish();
+    stageA_store<MT>(ldsA[0], areg);
+    __syncthreads();
+
+    for (int q = 0; q < nchunk; q += 2) {
+        chunk(q, xb, xb2);
+        if (q + 1 < nchunk) chunk(q + 1, xb2, xb);
     }
     float* sl = slabs + (int64_t)sp * r * ldp;
 #pragma unroll

@@ -99,12 +99,15 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_seg_kernel(
 #pragma unroll
             for (int t = 0; t < 4; ++t) dst[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldr4 + kb0 + 64 * t);
     };
-    f32x4 xb2[4][4];
+    // (two sets only while they fit: rank tiles MT <= 2 -- 226 VGPRs at rank 30; with the 64 accumulators of MT = 4 the second
+    //  set spills, tests/test_abi_and_host.py -- larger ranks refill each group's registers right after its MFMAs)
+    constexpr bool PP = MT <= 2;
+    f32x4 xb2[PP ? 4 : 1][4];
     auto chunk = [&](int q, f32x4 (&cur)[4][4], f32x4 (&nxt)[4][4]) {
         const f32x4* img = ldsA[q & 1];
         genA(q + 1);
 #if SEG_ABL != 3
-        loadX(nxt, q + 1);
+        if constexpr (PP) loadX(nxt, q + 1);
 #endif
         const int64_t kbase = (int64_t)(q % cps) * 64;
 #pragma unroll
@@ -135,6 +138,14 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_seg_kernel(
                         acc[mt][nt] = MFMA16(af[mt][c], cur[t][nt][c], acc[mt][nt]);
 #endif
                     }
+#if SEG_ABL != 3
+            if constexpr (!PP) {   // one register set: this group's registers are free again
+                const rsrc_t rs = seg_rsrc(q + 1);
+                const int kb = ((q + 1) % cps) * 256 + 64 * t;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) cur[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldr4 + kb);
+            }
+#endif
         }
 #if SEG_ABL != 4
         genA_finish();
@@ -149,9 +160,14 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 2 : 1)) void nnf_mttkrp_seg_kernel(
     stageA_store<MT>(ldsA[0], areg);
     __syncthreads();
 
-    for (int q = 0; q < nchunk; q += 2) {
-        chunk(q, xb, xb2);
-        if (q + 1 < nchunk) chunk(q + 1, xb2, xb);
+    if constexpr (PP) {
+        auto& other = reinterpret_cast<f32x4 (&)[4][4]>(xb2);
+        for (int q = 0; q < nchunk; q += 2) {
+            chunk(q, xb, other);
+            if (q + 1 < nchunk) chunk(q + 1, other, xb);
+        }
+    } else {
+        for (int q = 0; q < nchunk; ++q) chunk(q, xb, xb);
     }
     float* sl = slabs + (int64_t)sp * r * ldp;
 #pragma unroll

@@ -1065,6 +1065,9 @@ int nnf_xht_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, in
     if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
     int MT, REM;
     split_rank(r, MT, REM);
+    // ranks 51, 52: three tiles + four leftover ranks next to the 4-row-tile body do not fit 256 registers (84 bytes of scratch,
+    // drains inside the chunk loop: 292 us against 238 us for the padded four tiles at 100000 x 2000, tools/probes/rank_step_probe.py)
+    if (MT == 3 && REM == 4) { MT = 4; REM = 0; }
     if (!x_vec_ok(X, ldx)) {
         MT = (r + 15) / 16;
         DISPATCH_MT(launch_xht, 0, false, ctx, cur, X, m, n, ldx, V, r, ldv, out, ldo, st)

@@ -28,7 +28,8 @@ def rel(a, b):
 
 # shapes: (m, n, r) -- aligned, ragged, tiny, rank not a multiple of 16/4, one column / one row
 SHAPES = [(200, 100, 10), (73, 25, 9), (1000, 260, 50), (513, 130, 33), (64, 64, 16), (300, 7, 3), (5, 300, 2),
-          (257, 1, 1), (1, 257, 1), (2000, 500, 50), (777, 333, 100), (130, 70, 128), (4096, 1024, 64)]
+          (257, 1, 1), (1, 257, 1), (2000, 500, 50), (777, 333, 100), (130, 70, 128), (4096, 1024, 64),
+          (1000, 260, 52), (513, 132, 51), (900, 128, 36), (600, 64, 20), (700, 96, 68)]   # leftover-rank forms 16q + 3..4
 
 
 @pytest.mark.parametrize("m,n,r", SHAPES)

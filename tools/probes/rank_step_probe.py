@@ -7,7 +7,7 @@ eng = get_engine("cuda:0")
 m, n = 100000, 2000
 g = torch.Generator(device="cuda").manual_seed(1)
 X = torch.rand(m, n, device="cuda", generator=g)
-for r in (18, 20, 21, 34, 36, 37, 50, 52, 53, 66, 68, 69):
+for r in (18, 20, 21, 34, 36, 37, 50, 52, 53, 66, 68, 69, 80, 100, 112, 128):
     Ut = torch.rand(r, m, device="cuda", generator=g)
     V = torch.rand(r, n, device="cuda", generator=g)
     for _ in range(2): eng.xty(X, Ut); eng.xht(X, V)

@@ -371,7 +371,7 @@ template <int MT, bool VEC>
 static int launch_seg(nnf_ctx* ctx, const float* T, int64_t nrows, int64_t ldrow, int64_t nseg, int64_t segstride,
                       int64_t klen, const float* Fs, int64_t lds_, const float* Fk, int64_t ldk, int r, float* out,
                       int64_t ldo, hipStream_t st) {
-    if ((64 * ldrow + klen + 256) * 4 >= (int64_t)0x7fff0000 || (int64_t)r * lds_ * 4 >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
+    if ((64 * ldrow + klen + 256) * 4 >= (int64_t)0x7fff0000 || (int64_t)(16 * MT) * lds_ * 4 >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
     const int nrb = (int)nnf_cdiv(nrows, 256);
     const int64_t ldp = nnf_rup(nrows, 4);
     int64_t nsplit = 2 * (int64_t)ctx->num_cus / nrb;
@@ -422,7 +422,7 @@ static int launch_rows(nnf_ctx* ctx, const float* M, int64_t m, int64_t n, const
     const int grid = 8 * (int)nnf_cdiv(nsplit, 8) * ncb;
     nnf_probe(ctx, NNF_PROBE_MTTKRP, 0, st);
     // buffer-addressed Khatri-Rao generation: 31-bit byte offsets into both factors, at most one wrap inside four rows
-    const bool kr_fast = nb >= 4 && (int64_t)r * lda * 4 < (int64_t)0x7fff0000 && (int64_t)r * ldb * 4 < (int64_t)0x7fff0000;
+    const bool kr_fast = nb >= 4 && (int64_t)(16 * MT) * lda * 4 < (int64_t)0x7fff0000 && (int64_t)(16 * MT) * ldb * 4 < (int64_t)0x7fff0000;   // (padded rank rows: their offsets must not wrap either)
     if (kr_fast)
         hipLaunchKernelGGL((nnf_mttkrp_rows_kernel<MT, VEC, true>), dim3(grid), dim3(256), 0, st, M, m, n, n, Fa, lda, Fb, ldb, nb,
                            r, slabs, ldp, ncb, (int)nsplit, rps);

@@ -127,6 +127,9 @@ def test_streaming_kernels_keep_their_prefetch_ring_in_flight(built_lib):
                            "nnf_mttkrp_rows_kernel<4, true, true>", "nnf_mttkrp_seg_kernel<4, true>"]}
     for fname, kernels in want.items():
         path = os.path.join(build, fname)
+        if not os.path.exists(path):     # a library that came without its build directory: make recreates objects and ISA
+            import __graft_entry__
+            __graft_entry__.build()
         assert os.path.exists(path), f"{path}: the Makefile keeps the ISA of the streaming kernels next to the objects"
         found = mod.scan(path)
         for k in kernels:

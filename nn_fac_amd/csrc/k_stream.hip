@@ -1137,10 +1137,11 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
         NNF_CHECK_LAUNCH();
     }
     const int u_vec_ok = ((((uintptr_t)Ut) & 15) == 0 && (ldu & 3) == 0) ? 1 : 0;
-    // two V buffers unless dropping one is what lets a second workgroup onto the CU (ranks 77..104: see the kernel)
+    // two V buffers unless dropping one lets another workgroup onto the CU (ranks 53..64: a third, 77..104: a second; see the kernel)
     const size_t shm2 = (size_t)4 * 2 * KS * 64 * 4 + (size_t)2 * KS * 64 * 16 + 64, shm1 = shm2 - (size_t)KS * 64 * 16;
     const size_t lds_cu = 160 * 1024;
-    const int vdb = (2 * shm2 > lds_cu && 2 * shm1 <= lds_cu) ? 0 : 1;
+    auto wg_per_cu = [&](size_t b) { const size_t w = lds_cu / b; return w > 3 ? (size_t)3 : w; };   // (launch bound: 3)
+    const int vdb = wg_per_cu(shm1) > wg_per_cu(shm2) ? 0 : 1;
     const size_t shm = vdb ? shm2 : shm1;
 #define NNF_COST_LAUNCH(VV, NN)                                                                                              \
     do {                                                                                                                     \

@@ -263,16 +263,43 @@ class Ctx:
         return self.max_over_ranks(time.perf_counter() - t0), out
 
 
+class InLoop:
+    """HIP events recorded by the library right around the launches of ONE main kernel (nnf_ctx_set_probe_ring) INSIDE a
+    region of the product's own loop -- next to whatever shares the chip with that kernel there (side-stream Grams and
+    copies, the cost kernel under the V-side solve).  `times()` afterwards: one duration (ms) per launch, in launch order."""
+
+    def __init__(self, cx, eng, kernel, npairs):
+        self.eng, self.kernel = eng, kernel
+        self.on = bool(cx.cuda) and hasattr(eng, "set_probe_ring") and npairs > 0
+        self.pairs = eng.probe_pairs(npairs, cx.torch.cuda.current_stream(cx.device)) if self.on else []
+        self.used = 0
+
+    def __enter__(self):
+        if self.on:
+            self.eng.set_probe_ring(self.pairs, self.kernel)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.used = self.eng.probe_ring_count()
+            self.eng.set_probe_ring(None, self.kernel)
+        return False
+
+    def times(self):
+        return [a.elapsed_time(b) for a, b in self.pairs[:self.used]]
+
+
 class NmfRun:
     """The product's own outer loop (nn_fac_amd.nmf.run_steps = the `for iteration` loop of compute_nmf) on one rank's
     row block; every iteration's cost + status block is read back and handed to a recorder that never stops."""
 
-    def __init__(self, cx, X, Ut, V, r, rule, beta):
+    def __init__(self, cx, X, Ut, V, r, rule, beta, deterministic=True):
         from nn_fac_amd import nmf as nmf_mod
         self.cx, self.mod = cx, nmf_mod
         self.X, self.Ut, self.V, self.r, self.rule, self.beta = X, Ut, V, r, rule, beta
         self.ws = nmf_mod._StepBuffers(X, r, dtype=cx.dtype)
         self.sweeps, self.cost = [], None
+        self.deterministic = deterministic
 
     def run(self, k):
         def retired(it, cost, sw):
@@ -280,15 +307,30 @@ class NmfRun:
             self.cost = cost
             return False
         self.Ut, self.V = self.mod.run_steps(self.cx.eng, self.ws, self.X, self.r, self.Ut, self.V, k, self.rule, self.beta,
-                                             [None, None], [], [False, False], True, retired, group=self.cx.group)
+                                             [None, None], [], [False, False], self.deterministic, retired,
+                                             group=self.cx.group)
         return self.cost
 
-    def measure(self, warmup, steps):
+    def measure(self, warmup, steps, probe=None):
+        """`probe` = (kernel name, launches per step): that kernel's launches of the TIMED region are bracketed by events
+        (InLoop); returns their durations as the fourth value."""
         self.run(warmup)
         self.sweeps.clear()
         start = (self.Ut.clone(), self.V.clone())
-        dt, cost = self.cx.timed(lambda: self.run(steps))
-        return dt, cost, start
+        with InLoop(self.cx, self.cx.eng, probe[0] if probe else "xty", steps * probe[1] if probe else 0) as il:
+            dt, cost = self.cx.timed(lambda: self.run(steps))
+        return dt, cost, start, il.times()
+
+    def inloop(self, eng, kernel, per_step, steps):
+        """`steps` more iterations of the same loop (not timed) with `kernel`'s launches on `eng` bracketed by events."""
+        n0 = len(self.sweeps)
+        with InLoop(self.cx, eng, kernel, steps * per_step + 2) as il:
+            self.run(steps)
+            if self.cx.cuda:
+                self.cx.torch.cuda.synchronize()
+        sw = self.sweeps[n0:]
+        del self.sweeps[n0:]
+        return il.times(), sw
 
     def fixed_work(self):
         """10 sweeps per inner solve whatever the data (delta = 0, maxiter = 10)."""
@@ -307,15 +349,40 @@ def roof(kernel, bound, algo, ms, peak, unit, **more):
     """One roofline entry: `algo` algorithmic flops (bound mfma / valu) or bytes (bound hbm) per launch, `ms` mean launch."""
     achieved = algo / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
     d = {"kernel": kernel, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-         "traffic": None, "launch_ms": ms}
+         "traffic": None, "launch_ms": float(ms)}
+    if hasattr(ms, "stats"):          # nothing is trimmed: mean over all samples + their spread
+        d["launch_stats"] = ms.stats()
     d.update(more)
     return d
 
 
-def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta):
+def with_inloop(entry, times, algo, peak, unit, where):
+    """Re-price a roofline entry on the launches of the product's loop: `launch_ms` / `achieved` / `frac` become the in-loop
+    figures (mean over every launch recorded, nothing trimmed); the stand-alone figures move to `standalone`."""
+    if not times:
+        return entry
+    from nn_fac_amd.engine import KernelTime
+    kt = KernelTime.of(times)
+    entry["standalone"] = {"launch_ms": entry["launch_ms"], "achieved": entry["achieved"], "frac": entry["frac"],
+                           "launch_stats": entry.pop("launch_stats", None)}
+    ach = algo / (float(kt) * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
+    entry.update(launch_ms=float(kt), achieved=ach, frac=ach / peak, launch_stats=kt.stats(), measured=where)
+    if "hbm_gbs" in entry and "algorithmic_bytes" in entry:
+        entry["hbm_gbs"] = entry["algorithmic_bytes"] / float(kt) / 1e6
+        if "hbm_frac_of_8TBs" in entry:
+            entry["hbm_frac_of_8TBs"] = entry["hbm_gbs"] / HBM_PEAK_GBS
+    return entry
+
+
+def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta, loop_times=None, steps=20):
     """Per-kernel launch durations, HIP events recorded by the library on the launch stream immediately around each main
-    kernel (Engine.time_kernel / nnf_ctx_set_probe_kernel), on the factors the timed region ended with."""
+    kernel.  Every entry is measured twice: stand-alone (Engine.time_kernel: back-to-back launches on the factors the timed
+    region ended with) and on the launches INSIDE the product's loop (InLoop) -- `loop_times`: the dominant kernel's launches
+    of the timed region itself; the other kernels: `steps` more iterations of the same loop per kernel, right after it.  The
+    figures of an entry (`launch_ms`, `achieved`, `frac`) are the in-loop ones, the stand-alone ones sit under `standalone`."""
     eng, X, Ut, V, ws = cx.eng, run.X, run.Ut, run.V, run.ws
+    where_timed = f"HIP events around this kernel's {len(loop_times or [])} launches inside the timed region"
+    where_more = f"HIP events around this kernel's launches in {steps} further iterations of the same loop"
     torch = cx.torch
     flops = 2.0 * r * m * n
     xbytes = (m * n + r * m + r * n) * 4.0
@@ -325,14 +392,29 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta):
         out.append(roof("nnf_xty_kernel (W^T X, main kernel of nnf_xty_f32; the fixed-order slab reduction that follows is "
                         "not included)", "mfma", flops, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=flops,
                         algorithmic_bytes=xbytes, hbm_gbs=xbytes / ms / 1e6, hbm_frac_of_8TBs=xbytes / ms / 1e6 / HBM_PEAK_GBS))
+        with_inloop(out[-1], loop_times, flops, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", where_timed)
         ms = eng.time_kernel("xht", lambda: eng.xht(X, V, out=ws.VMt))
         out.append(roof("nnf_xht_kernel (X H^T)", "mfma", flops, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
                         algorithmic_flops=flops, algorithmic_bytes=xbytes, hbm_gbs=xbytes / ms / 1e6))
+        with_inloop(out[-1], run.inloop(eng, "xht", 1, steps)[0], flops, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", where_more)
         c = torch.zeros(1, dtype=torch.float64, device=X.device)
         ms = eng.time_kernel("cost", lambda: eng.frob_resid(X, Ut, V, out=c))
         out.append(roof("nnf_cost_kernel<FROB> (||X - UV||^2 fused with the product)", "mfma", flops, ms,
                         MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=flops, algorithmic_bytes=xbytes,
                         hbm_gbs=xbytes / ms / 1e6))
+        # (the cost of iteration i runs beside the V-side solve of iteration i+1, on the cost stream's own context)
+        ceng = ws.cost_eng if getattr(ws, "cost_eng", None) is not None else eng
+        with_inloop(out[-1], run.inloop(ceng, "cost", 1, steps)[0], flops, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
+                    where_more + " (beside the V-side solve)")
+        # the two persistent solves as the loop runs them (stopping rule on the device): launches alternate U side, V side
+        ts, sw = run.inloop(eng, "hals", 2, steps)
+        solves = {}
+        if sw and len(ts) >= 2 * len(sw) and all(len(x) == 2 for x in sw):
+            for side, name in ((0, "U"), (1, "V")):
+                dur = [ts[2 * i + side] for i in range(len(sw))]
+                cnt = [x[side] for x in sw]
+                solves[name] = {"us_per_sweep": 1e3 * sum(dur) / max(1, sum(cnt)), "mean_launch_ms": sum(dur) / len(dur),
+                                "mean_sweeps": sum(cnt) / len(cnt), "launches": len(dur)}
         # the sweep kernels: fixed 20 sweeps from the current factors (time / sweep is what the VALU roofline prices)
         ns = 20
         G = eng.gram(V)
@@ -341,16 +423,17 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta):
         ms = eng.time_kernel("hals", lambda: eng.hals_sweeps(ws.VMt, G, F, ns), reps=5) / ns
         out.append(roof(f"nnf_hals_kernel (U side: {m} columns, rank {r}; one lane per column, per sweep over {ns} fixed "
                         f"sweeps)", "valu", 2.0 * r * r * m, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
-                        algorithmic_flops=2.0 * r * r * m, us_per_sweep=ms * 1e3,
+                        algorithmic_flops=2.0 * r * r * m, us_per_sweep=ms * 1e3, in_loop_solve=solves.get("U"),
                         note="Gauss-Seidel row dependence: issue bound of this formulation is ~2.4x the 2r^2m/peak time "
-                             "(DESIGN.md 3)"))
+                             "(DESIGN.md 3); in_loop_solve: the persistent solve of the loop, stopping rule included"))
         G2 = eng.gram(Ut)
         eng.xty(X, Ut, out=ws.UtM)
         F2 = V.clone()
         ms = eng.time_kernel("hals", lambda: eng.hals_sweeps(ws.UtM, G2, F2, ns), reps=5) / ns
-        out.append(roof(f"nnf_hals_quad_kernel (V side: {n} columns, rank {r}; four lanes per column, per sweep)", "valu",
+        out.append(roof(f"V-side sweep kernel ({n} columns, rank {r}; few-column layout, per sweep over {ns} fixed sweeps)", "valu",
                         2.0 * r * r * n, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=2.0 * r * r * n,
-                        us_per_sweep=ms * 1e3, note="latency bound: n/16 single-wave workgroups"))
+                        us_per_sweep=ms * 1e3, in_loop_solve=solves.get("V"),
+                        note="latency bound; in_loop_solve: the persistent solve of the loop, beside the cost kernel"))
     else:
         k = 2.0 if float(beta) != 2.0 else 1.0
         c = torch.zeros(1, dtype=torch.float64, device=X.device)
@@ -363,6 +446,8 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta):
                             "input factors in one pass; the kernel of the timed loop)", "mfma", k * flops, ms,
                             MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=k * flops, algorithmic_bytes=xbytes,
                             hbm_gbs=xbytes / ms / 1e6))
+            # (the first launch of a run has no previous cost to form: the plain kernel; every later one is this form)
+            with_inloop(out[-1], (loop_times or [])[1:], k * flops, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", where_timed)
         ms = eng.time_kernel("mu_left", lambda: eng.mu_left(X, Ut, V, beta))
         out.append(roof(f"nnf_mu_left_kernel (beta={beta:g}: P = U V and num += (X ./ P) V^T in one pass)", "mfma",
                         k * flops, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=k * flops,
@@ -370,6 +455,7 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta):
         ms = eng.time_kernel("mu_right", lambda: eng.mu_right(X, Ut, V, beta))
         out.append(roof(f"nnf_mu_right_kernel (beta={beta:g})", "mfma", k * flops, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
                         algorithmic_flops=k * flops, algorithmic_bytes=xbytes, hbm_gbs=xbytes / ms / 1e6))
+        with_inloop(out[-1], run.inloop(eng, "mu_right", 1, steps)[0], k * flops, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", where_more)
         ms = eng.time_kernel("cost", lambda: eng.betadiv(X, Ut, V, beta, out=c))
         out.append(roof(f"nnf_cost_kernel<beta={beta:g}> (divergence fused with the product)", "mfma", flops, ms,
                         MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=flops, algorithmic_bytes=xbytes,
@@ -407,7 +493,8 @@ def bench_nmf(cx, args, cfg, steps, warmup, with_cpu, with_fixed, with_kernels):
         units = float(cx.world)          # 100000-row blocks per step
 
     run = NmfRun(cx, X, Ut, V, r, rule, beta)
-    dt, cost, start = run.measure(warmup, steps)
+    probe = ("xty" if rule == "hals" else "mu_left", 1) if (with_kernels and cx.cuda and cx.rank == 0) else None
+    dt, cost, start, loop_times = run.measure(warmup, steps, probe=probe)
     sweeps = list(run.sweeps)
     if cx.group is not None and os.environ.get("NNF_BENCH_DEBUG"):
         print(f"[rank {cx.rank}] sharded U-side protocol: {run.ws.async_hits} device-side decisions, "
@@ -416,12 +503,32 @@ def bench_nmf(cx, args, cfg, steps, warmup, with_cpu, with_fixed, with_kernels):
            "inner_sweeps_per_step_last": sweeps[-1] if sweeps else None,
            "inner_sweeps_mean": (sum(sum(x) for x in sweeps) / len(sweeps)) if sweeps and sweeps[0] else None,
            "rows_per_rank": int(X.shape[0]), "rule": rule, "beta": beta}
+    if cx.group is not None:
+        from nn_fac_amd import dist as nd
+        out["sharded_protocol"] = {
+            "u_side_stopping_decision": "device (NNF_SHARDED_ASYNC=1)" if run.ws.async_sharded else "host-synchronous (default)",
+            "cost": "overlapped with the next V-side solve (NNF_SHARDED_OVERLAP=1)"
+                    if nd.opt_in("NNF_SHARDED_OVERLAP", cx.group) else "inside the step (default)",
+            "device_decisions": run.ws.async_hits, "redone_synchronously": run.ws.async_misses,
+            "fell_back_to_chunked_solves": bool(run.ws.safe_solve)}
     if with_fixed and rule == "hals":
         f = run.fixed_work()
         f["iterations_per_s"] *= units
         out["fixed_work"] = f
     if with_kernels and cx.cuda and cx.rank == 0:
-        out["rooflines"] = nmf_kernel_rooflines(cx, run, int(X.shape[0]), n, r, rule, beta)
+        out["rooflines"] = nmf_kernel_rooflines(cx, run, int(X.shape[0]), n, r, rule, beta, loop_times, steps)
+    if with_fixed and rule == "hals" and cx.world == 1 and cfg["scaling"] == "weak":
+        # the reference's DEFAULT call, nmf(..., deterministic=False) (nn_fac/nmf.py:19-22): the inner solves stop on the
+        # wall-clock rule cnt <= 1 + 0.5 * rho (nnls.py:156,190-194) -- per HALS solve two device syncs around the Gram + cross
+        # launches and a one-sweep probe on a scratch copy -- so the result is time dependent by design, as in the reference
+        nd_run = NmfRun(cx, X, start[0].clone(), start[1].clone(), r, rule, beta, deterministic=False)
+        nsteps = min(steps, 10)
+        ndt, ncost, _, _ = nd_run.measure(2, nsteps)
+        out["nondeterministic"] = {"what": "the same data through deterministic=False, the reference's default (wall-clock sweep budget)",
+                                   "iterations_per_s": units * nsteps / ndt, "ms_per_step": 1e3 * ndt / nsteps,
+                                   "steps": nsteps, "warmup": 2, "final_cost": ncost,
+                                   "inner_sweeps_per_step_last": nd_run.sweeps[-1] if nd_run.sweeps else None}
+        del nd_run
     if host is not None:
         U_s, V_s = start[0].t().contiguous().cpu().numpy(), start[1].cpu().numpy()
         del run, X
@@ -456,7 +563,12 @@ def bench_ntf(cx, args, cfg, steps, warmup, with_cpu, with_kernels):
     run(warmup)
     sweeps.clear()
     start = [f.clone() for f in Ft]
-    dt, cost = cx.timed(lambda: run(steps))
+    probing = with_kernels and cx.cuda and cx.rank == 0
+    # the mode-2 MTTKRP launches of the timed region itself (one per iteration) are bracketed by events; the fused pass's in
+    # `steps` further iterations right after it
+    # (a run's first iteration has no partial product yet and forms modes 0 / 1 directly: two more launches, dropped below)
+    with InLoop(cx, cx.eng, "mttkrp", steps + 2 if probing else 0) as il_m:
+        dt, cost = cx.timed(lambda: run(steps))
     out = {"value": cx.world * steps / dt, "ms_per_step": 1e3 * dt / steps, "final_cost": cost,
            "inner_sweeps_per_step_last": sweeps[-1] if sweeps else None,
            "inner_sweeps_mean": (sum(sum(x) for x in sweeps) / len(sweeps)) if sweeps else None,
@@ -471,6 +583,12 @@ def bench_ntf(cx, args, cfg, steps, warmup, with_cpu, with_kernels):
         rl.append(roof("nnf_mttkrp_rows_kernel (mode-2 MTTKRP, Khatri-Rao operand generated on the fly; slab reduction not "
                        "included)", "hbm", tb, ms, HBM_PEAK_GBS, "GB/s", algorithmic_bytes=tb, algorithmic_flops=fl,
                        tflops=fl / ms / 1e9))
+        with_inloop(rl[-1], il_m.times()[-steps:], tb, HBM_PEAK_GBS, "GB/s",
+                    f"HIP events around this kernel's {len(il_m.times()[-steps:])} launches inside the timed region")
+        rl[-1]["tflops"] = fl / rl[-1]["launch_ms"] / 1e9
+        with InLoop(cx, eng, "mu_left", steps + 2) as il_f:
+            run(steps)
+            torch.cuda.synchronize()
         c = torch.zeros(1, dtype=torch.float64, device=T.device)
         Y = torch.empty((R, I, I), dtype=torch.float32, device=T.device)
         ms = eng.time_kernel("mu_left", lambda: eng.cp3_partial_cost(T, Ft, Y, c))
@@ -478,6 +596,8 @@ def bench_ntf(cx, args, cfg, steps, warmup, with_cpu, with_kernels):
                        "iteration's mode-0 / mode-1 right-hand sides are contracted from)", "mfma", 2 * fl, ms,
                        MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=2 * fl, algorithmic_bytes=tb + R * I * I * 4.0,
                        hbm_gbs=(tb + R * I * I * 4.0) / ms / 1e6))
+        with_inloop(rl[-1], il_f.times()[-steps:], 2 * fl, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
+                    f"HIP events around this kernel's launches in {steps} further iterations of the same loop")
         # the kernels the fused pass replaces / the first iteration and one_ntf_step use
         for mode in range(2):
             ms = eng.time_kernel("mttkrp", lambda: eng.mttkrp3(T, Ft, mode))
@@ -572,6 +692,10 @@ def main():
         }
         if "fixed_work" in res:
             out["fixed_work"] = res["fixed_work"]
+        if "nondeterministic" in res:
+            out["nondeterministic"] = res["nondeterministic"]
+        if "sharded_protocol" in res:
+            out["config"]["sharded_protocol"] = res["sharded_protocol"]
         if extra is not None:
             out["extra_configs"] = extra
         if "cpu_baseline" in res:

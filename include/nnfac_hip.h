@@ -55,6 +55,11 @@ typedef struct nnf_ctx nnf_ctx;
 #define NNF_HALS_ST_WORDS 8
 
 int nnf_version(void);
+/* The values the timing-only ablation / A-B switches of the kernel sources were COMPILED with, one "unit: NAME=value ..."
+ * entry per translation unit, sorted by unit, separated by "; " (e.g. "k_stream: XHT_ABL=0; ...").  Every switch has a
+ * product default; a stray -D in a build would silently ship a kernel that skips work, so tests/test_abi_and_host.py
+ * compares this string with the defaults.  Writes at most `cap` bytes (NUL-terminated), returns the full length. */
+size_t nnf_build_flags(char* buf, size_t cap);
 const char* nnf_status_string(int status);
 
 /* Create a context on HIP device `device` with `workspace_bytes` of scratch (0 = default 256 MiB). */
@@ -78,6 +83,14 @@ int nnf_ctx_set_probe(nnf_ctx* ctx, void* ev_begin, void* ev_end);
 #define NNF_PROBE_MTTKRP 6
 #define NNF_PROBE_COUNT 7
 int nnf_ctx_set_probe_kernel(nnf_ctx* ctx, int kernel_id);
+/* The same hook for a whole timed region: `npairs` (begin, end) pairs of caller-owned events, events[2i], events[2i + 1];
+ * the i-th launch of the selected kernel after this call records pair i, launches beyond `npairs` record nothing (no wrap).
+ * The library copies the pointers.  NULL / 0 removes the ring.  While a ring is set it takes precedence over the single pair.
+ * This is how bench.py times the dominant kernel on the launches INSIDE its timed loop (next to whatever shares the chip
+ * with it there) rather than in a stand-alone loop. */
+int nnf_ctx_set_probe_ring(nnf_ctx* ctx, void* const* events, int npairs);
+/* Number of pairs of the current ring that have been recorded so far (0 without a ring). */
+int nnf_ctx_probe_ring_count(const nnf_ctx* ctx);
 
 /* ---- multi-GPU exchange of the row-sharded path: RCCL all-reduce (sum, in place) over xGMI -------------
  * One process per GPU.  Rank 0 draws a 128-byte id (nnf_comm_unique_id) and hands it to the other ranks by any channel of

@@ -17,6 +17,7 @@ _p, _f32, _f64 = C.c_void_p, C.c_float, C.c_double
 # name -> (restype, argtypes); mirrors include/nnfac_hip.h one to one
 SIGNATURES = {
     "nnf_version": (_i32, []),
+    "nnf_build_flags": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "nnf_status_string": (C.c_char_p, [_i32]),
     "nnf_ctx_create": (_i32, [C.POINTER(_p), _i32, C.c_size_t]),
     "nnf_ctx_destroy": (_i32, [_p]),
@@ -42,6 +43,8 @@ SIGNATURES = {
     "nnf_hals_sweeps_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _f32, _u32, _p, _p, _i64, _p]),
     "nnf_ctx_set_probe": (_i32, [_p, _p, _p]),
     "nnf_ctx_set_probe_kernel": (_i32, [_p, _i32]),
+    "nnf_ctx_set_probe_ring": (_i32, [_p, C.POINTER(_p), _i32]),
+    "nnf_ctx_probe_ring_count": (_i32, [_p]),
     "nnf_mu_left_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _i64, _p]),
     "nnf_mu_left_kl_cost_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _p]),
     "nnf_mu_right_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _f64, _p, _i64, _p]),

@@ -7,6 +7,8 @@
 #error "compile with -DHALS_PART=0..3"
 #endif
 
+NNF_BUILD_FLAGS(NNF_CAT(k_hals_fast, HALS_PART), "HALS_LATE_ISSUE=" NNF_STR(HALS_LATE_ISSUE) " HALS_MID_AT(R)=" NNF_STR(HALS_MID_AT(R)))
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 

@@ -305,6 +305,7 @@ static int quad_cap(nnf_ctx* ctx) {   // workgroups that can be co-resident (all
 #ifndef QUAD_PART
 #define QUAD_PART 0
 #endif
+NNF_BUILD_FLAGS(NNF_CAT(k_hals_quad, QUAD_PART), "QUAD_MID_SEL=" NNF_STR(QUAD_MID_SEL) " HALS_LATE_ISSUE=" NNF_STR(HALS_LATE_ISSUE))
 #if QUAD_PART == 0
 #define QUAD_CASES(FN, ...)                                                                                             \
     QUAD_CASE(1, FN, __VA_ARGS__) QUAD_CASE(2, FN, __VA_ARGS__) QUAD_CASE(3, FN, __VA_ARGS__) QUAD_CASE(4, FN, __VA_ARGS__)     \
@@ -378,7 +379,14 @@ int nnf_hals_quad_run(nnf_ctx* ctx, const float* UtU, const float* UtU2, int64_t
     hipLaunchKernelGGL(nnf_hals_prep_quad_kernel, dim3(4 * ch), dim3(64), 0, st, UtU, UtU2, ldg, a.r, ch, Gq, dinvq, counter,
                        (a.mode == 0 && a.sweep0 == 0) ? a.status : (double*)nullptr);
     NNF_CHECK_LAUNCH();
-    if (a.max_sweeps == 0) return NNF_OK;
+    if (a.max_sweeps == 0) {
+        // no sweep: the result is the start value (nnls.py:147 returns in_V.copy() when the loop does not run); the other
+        // layouts have made that copy already, this one reads its start values inside the sweep kernel, which is not launched
+        if (a.Vsrc != a.V && hipMemcpy2DAsync(a.V, (size_t)a.ldv * 4, a.Vsrc, (size_t)a.ldvs * 4, (size_t)a.ncols * 4, (size_t)a.r,
+                                               hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return NNF_ERR_LAUNCH;
+        return NNF_OK;
+    }
     a.Gp = Gq;
     a.dinv = dinvq;
     const int nblocks = (int)nnf_cdiv(a.ncols, 16);

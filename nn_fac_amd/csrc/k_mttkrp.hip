@@ -18,6 +18,7 @@
 #ifndef MTTKRP_ABL
 #define MTTKRP_ABL 0   // timing-only ablations of nnf_mttkrp_rows_kernel (tools/mttkrp_ablate.sh); 0 = the product
 #endif
+NNF_BUILD_FLAGS(k_mttkrp, "SEG_ABL=" NNF_STR(SEG_ABL) " MTTKRP_ABL=" NNF_STR(MTTKRP_ABL))
 
 // ---------------------------------------------------------------------------------------------------------
 // segmented V X^T:  out[rk][row] = sum_{s in split} Fs[rk][s] * sum_k Fk[rk][k] * T[row*ldrow + s*segstride + k]

@@ -23,6 +23,7 @@
 #ifndef MU_PART
 #error "k_mu.hip is compiled per part: -DMU_PART=0|1|2"
 #endif
+NNF_BUILD_FLAGS(NNF_CAT(k_mu, MU_PART), "MU_WG_PER_CU=" NNF_STR(MU_WG_PER_CU) " MU_STEP_FENCE()=" NNF_STR(MU_STEP_FENCE()))
 
 // F_new = max(F * (num/den)^gamma, 1e-12); num/den summed over slabs in fp64 (fixed order); den_vec: per-row denominator (KL)
 static __global__ __launch_bounds__(256) void nnf_mu_finish_kernel(const float* __restrict__ F, int64_t ldf, int r, int64_t cols,

@@ -24,6 +24,7 @@
 #ifndef XHT_ABL
 #define XHT_ABL 0   // timing-only ablations of nnf_xht_kernel (tools/xht_ablate.sh); 0 = the product
 #endif
+NNF_BUILD_FLAGS(k_stream, "XHT_ABL=" NNF_STR(XHT_ABL))
 
 // =========================================================================================================
 // xty: slab[ks][rk][j] = sum_{i in split ks} Ut[rk][i] * X[i][j]

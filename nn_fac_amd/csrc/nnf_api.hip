@@ -2,7 +2,31 @@
 #include "nnf_internal.h"
 #include <new>
 
-extern "C" int nnf_version(void) { return 100; }  // 0.1.0
+#include <map>
+#include <string>
+#include <string.h>
+
+extern "C" int nnf_version(void) { return 101; }  // 0.1.1
+
+static std::map<std::string, std::string>& build_flag_registry() {
+    static std::map<std::string, std::string> r;   // constructed on first use: safe from any unit's static initialiser
+    return r;
+}
+void nnf_register_build_flags(const char* unit, const char* flags) { build_flag_registry()[unit] = flags; }
+
+extern "C" size_t nnf_build_flags(char* buf, size_t cap) {
+    std::string all;
+    for (const auto& kv : build_flag_registry()) {
+        if (!all.empty()) all += "; ";
+        all += kv.first + ": " + kv.second;
+    }
+    if (buf && cap > 0) {
+        const size_t n = all.size() < cap - 1 ? all.size() : cap - 1;
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return all.size();
+}
 
 extern "C" const char* nnf_status_string(int status) {
     switch (status) {
@@ -35,6 +59,8 @@ extern "C" int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_by
     c->hals_epoch = 0u;
     c->probe[0] = c->probe[1] = nullptr;
     c->probe_id = NNF_PROBE_XTY;
+    c->ring = nullptr;
+    c->ring_n = c->ring_pos = 0;
     c->xch = nullptr;
     c->xch_bytes = (size_t)(NNF_HALS_MAX_SWEEPS + 2) * NNF_HALS_MAX_BLOCKS * 16;
     hipError_t e = hipMalloc((void**)&c->ws, c->ws_bytes);
@@ -56,6 +82,7 @@ extern "C" int nnf_ctx_destroy(nnf_ctx* ctx) {
     if (!ctx) return NNF_ERR_ARG;
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->xch) (void)hipFree(ctx->xch);
+    delete[] ctx->ring;
     delete ctx;
     return NNF_OK;
 }
@@ -68,6 +95,23 @@ extern "C" int nnf_ctx_set_probe(nnf_ctx* ctx, void* ev_begin, void* ev_end) {
     ctx->probe[1] = (hipEvent_t)ev_end;
     return NNF_OK;
 }
+
+extern "C" int nnf_ctx_set_probe_ring(nnf_ctx* ctx, void* const* events, int npairs) {
+    if (!ctx || npairs < 0 || (npairs > 0 && !events)) return NNF_ERR_ARG;
+    delete[] ctx->ring;
+    ctx->ring = nullptr;
+    ctx->ring_n = ctx->ring_pos = 0;
+    if (npairs == 0) return NNF_OK;
+    for (int i = 0; i < 2 * npairs; ++i)
+        if (!events[i]) return NNF_ERR_ARG;
+    ctx->ring = new (std::nothrow) hipEvent_t[2 * (size_t)npairs];
+    if (!ctx->ring) return NNF_ERR_DEVICE;
+    for (int i = 0; i < 2 * npairs; ++i) ctx->ring[i] = (hipEvent_t)events[i];
+    ctx->ring_n = npairs;
+    return NNF_OK;
+}
+
+extern "C" int nnf_ctx_probe_ring_count(const nnf_ctx* ctx) { return (ctx && ctx->ring) ? ctx->ring_pos : 0; }
 
 extern "C" int nnf_ctx_set_probe_kernel(nnf_ctx* ctx, int kernel_id) {
     if (!ctx || kernel_id < 0 || kernel_id >= NNF_PROBE_COUNT) return NNF_ERR_ARG;

@@ -7,6 +7,8 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "nnf_internal.h"
 
 typedef struct ncclComm* ncclComm_t;
@@ -30,19 +32,31 @@ struct rccl_api {
 };
 rccl_api& api() {
     static rccl_api a;
-    if (a.handle == nullptr) {
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
-            a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the copy that is ALREADY in the process answers (PyTorch's bundled library has the SONAME librccl.so.1; a plain
+        // dlopen("librccl.so") would not match it and could map a second RCCL from /opt/rocm next to it): RTLD_NOLOAD over
+        // the known names first, a fresh load only when nothing is resident (a host that never imported torch)
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* name : names) {
+            a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
             if (a.handle) break;
         }
-        if (a.handle) {
+        // resident under another name (a statically named copy inside the host): the global scope answers (RTLD_DEFAULT == 0)
+        bool found = a.handle != nullptr || dlsym(RTLD_DEFAULT, "ncclAllReduce") != nullptr;
+        for (const char* name : names) {
+            if (found) break;
+            a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            found = a.handle != nullptr;
+        }
+        if (found) {
             a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.handle, "ncclGetUniqueId");
             a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
             a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
             a.AllReduce = (decltype(a.AllReduce))dlsym(a.handle, "ncclAllReduce");
             a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
         }
-    }
+    });
     return a;
 }
 }   // namespace

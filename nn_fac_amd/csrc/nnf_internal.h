@@ -16,14 +16,38 @@ struct nnf_ctx {
                            // and whenever the epoch wraps
     hipEvent_t probe[2];   // optional caller-owned events recorded around ONE main kernel (nnf_ctx_set_probe[_kernel])
     int probe_id;          // which kernel the probe brackets (NNF_PROBE_*, include/nnfac_hip.h); default: W^T X
+    hipEvent_t* ring;      // nnf_ctx_set_probe_ring: ring_n (begin, end) pairs, the next launch records pair ring_pos
+    int ring_n, ring_pos;
 };
+
+// Build-switch registry (nnf_build_flags): every translation unit that has timing-only ablation / A-B macros records the
+// values it was compiled with at load time.
+void nnf_register_build_flags(const char* unit, const char* flags);
+#define NNF_STR2(x) #x
+#define NNF_STR(x) NNF_STR2(x)
+#define NNF_CAT2(a, b) a##b
+#define NNF_CAT(a, b) NNF_CAT2(a, b)
+#define NNF_BUILD_FLAGS_I(unit, str)                                                      \
+    namespace {                                                                           \
+    struct nnf_bf_##unit { nnf_bf_##unit() { nnf_register_build_flags(#unit, str); } };  \
+    static nnf_bf_##unit nnf_bf_inst_##unit;                                              \
+    }
+#define NNF_BUILD_FLAGS(unit, str) NNF_BUILD_FLAGS_I(unit, str)   /* (arguments are macro-expanded first: NNF_CAT(base, PART)) */
 
 #define NNF_HALS_MAX_SWEEPS 1000   // per launch: the exchange tag holds the sweep index in 10 bits (k_hals_common.h)
 #define NNF_HALS_MAX_BLOCKS 2048   // workgroups of one persistent solve (3 * 256 CUs fits)
 
 // measurement hook: record the caller's event `which` (0 begin, 1 end) if the probe is armed for kernel `id`
 static inline void nnf_probe(nnf_ctx* c, int id, int which, hipStream_t st) {
-    if (c->probe[which] && c->probe_id == id) (void)hipEventRecord(c->probe[which], st);
+    if (c->probe_id != id) return;
+    if (c->ring) {
+        if (c->ring_pos < c->ring_n) {
+            (void)hipEventRecord(c->ring[2 * c->ring_pos + which], st);
+            if (which == 1) ++c->ring_pos;
+        }
+        return;
+    }
+    if (c->probe[which]) (void)hipEventRecord(c->probe[which], st);
 }
 
 #define NNF_CHECK_LAUNCH()                                   \

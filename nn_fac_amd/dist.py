@@ -42,23 +42,41 @@ def is_sharded(group):
 
 def opt_in(name, group):
     """Switch of the two row-sharded optimisations that need ONE PROCESS PER DEVICE to pay off (device-side stopping decision,
-    NNF_SHARDED_ASYNC; cost under the V-side solve, NNF_SHARDED_OVERLAP): "1" / "0" in the environment force them on / off;
-    unset, they are on exactly when the group runs over RCCL ("nccl") -- which refuses two ranks on one device, so every
-    rank owns its GPU -- and off over gloo, where ranks may time-slice one device and two persistent sweep kernels can
-    starve each other (the only multi-rank rehearsal a one-GPU box offers)."""
-    v = os.environ.get(name)
-    if v in ("0", "1"):
-        return v == "1"
-    try:
-        return group is not None and dist.get_backend(group) == "nccl"
-    except Exception:
-        return False
+    NNF_SHARDED_ASYNC; cost under the V-side solve, NNF_SHARDED_OVERLAP): "1" in the environment turns one on, anything else
+    (or unset) leaves it OFF.  Both are validated for correctness (gloo world-size-2 tests, a one-rank RCCL group on the GPU)
+    and measured on one rank (-2.5 % instead of -8 % for the protocol at config B), but no run with more than
+    one rank on real GPUs has exercised them yet -- the overlap path issues collectives from a second stream next to a
+    resident persistent kernel -- so the default is the host-synchronous protocol until such a run exists.  bench.py records
+    which mode ran and the hit / miss counts of the device-side decision in its JSON line."""
+    return os.environ.get(name) == "1"
 
 
 def allreduce_(t, group):
     if is_sharded(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def allreduce_cost_(block, group):
+    """The cost word of an iteration's 24-double status block ([16]) summed over the row blocks -- and, in the same
+    collective, copies of the error words of the iteration's two solves ([3], [11] -> [17], [18]).  A solve's error word is
+    identical on every rank except for one code: 1, "the persistent kernel gave up waiting for its workgroups", which is a
+    rank-local event.  The sums let every rank decode the same code (`agreed_code`) and take the same branch of
+    nmf.run_steps -- a rank falling back to chunked solves alone would stop matching its peers' collectives."""
+    if is_sharded(group):
+        block[17:19].copy_(block[3:12:8])
+        dist.all_reduce(block[16:19], op=dist.ReduceOp.SUM, group=group)
+    return block
+
+
+def agreed_code(host, i, nranks):
+    """Error code of solve i from the summed copies made by allreduce_cost_: 0 if no rank reported anything; the common code
+    when every rank reported the same one (3 / 4: the device-side stopping decision missed -- a function of all-reduced sums;
+    2: a zero row of the replicated factor); otherwise some ranks timed out and others did not: 1 for everybody."""
+    total = int(round(float(host[17 + i])))
+    if total == 0:
+        return 0
+    return total // nranks if total % nranks == 0 else 1
 
 
 def agree_int(value, group, device=None):

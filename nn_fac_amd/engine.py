@@ -18,6 +18,19 @@ ST_EPS, ST_CNT, ST_EPS0, ST_ERR, ST_WORDS = 0, 1, 2, 3, 8
 _engines = {}
 _lock = threading.Lock()
 
+MAX_RANK = 128      # NNF_MAX_RANK of include/nnfac_hip.h: the sweep / Gram / cross / cost / MTTKRP kernels hold a rank-long
+#                     column or operand tile per lane or per LDS image
+
+
+def check_rank(r, where):
+    """The reference accepts any rank up to min(shape) (nn_fac/nmf.py:175-178; nnls.py:156-170 loops `range(r)`); the
+    kernels here are built for rank <= 128.  Said at the boundary, before anything is uploaded or launched, instead of an
+    NNF_ERR_UNSUPPORTED status from deep inside an iteration."""
+    r = int(r)
+    if r > MAX_RANK:
+        raise EngineError(f"{where}: rank {r} is above the {MAX_RANK} the MI355X kernels of nn_fac_amd are built for "
+                          f"(register-resident sweep columns, LDS operand tiles); factorise with rank <= {MAX_RANK}")
+
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr())
@@ -36,6 +49,20 @@ def _chk2d(t, name):
         raise EngineError(f"{name}: expected a 2-D float32 device tensor with unit inner stride, got "
                           f"{tuple(t.shape)} {t.dtype} {t.device} strides {t.stride()}")
     return t
+
+
+class KernelTime(float):
+    """Mean launch duration in ms (the float) + the spread of the samples it came from."""
+
+    @classmethod
+    def of(cls, samples):
+        ts = sorted(float(t) for t in samples)
+        k = cls(sum(ts) / len(ts))
+        k.n, k.median, k.min, k.max = len(ts), ts[len(ts) // 2], ts[0], ts[-1]
+        return k
+
+    def stats(self):
+        return {"samples": self.n, "mean_ms": float(self), "median_ms": self.median, "min_ms": self.min, "max_ms": self.max}
 
 
 class Engine:
@@ -370,29 +397,46 @@ class Engine:
         _lib.check(self.lib.nnf_ctx_set_probe_kernel(self.ctx, self.PROBE_KERNELS[kernel]), "nnf_ctx_set_probe_kernel")
         _lib.check(self.lib.nnf_ctx_set_probe(self.ctx, b, e), "nnf_ctx_set_probe")
 
-    def time_kernel(self, kernel, fn, reps=20):
-        """Mean duration (ms) of the main kernel `kernel` over `reps` calls of `fn` (which must launch it exactly once on the
-        current stream), measured with HIP events recorded by the library immediately around that kernel."""
-        stream = torch.cuda.current_stream(self.device)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    def set_probe_ring(self, pairs=None, kernel="xty"):
+        """Measurement hook for a whole timed region (bench.py): `pairs` = [(begin, end), ...] of already recorded
+        torch.cuda.Event(enable_timing=True); the i-th launch of `kernel` from now on records pair i on its launch stream
+        (launches beyond the list record nothing).  None removes the ring (nnf_ctx_set_probe_ring)."""
+        _lib.check(self.lib.nnf_ctx_set_probe_kernel(self.ctx, self.PROBE_KERNELS[kernel]), "nnf_ctx_set_probe_kernel")
+        if not pairs:
+            _lib.check(self.lib.nnf_ctx_set_probe_ring(self.ctx, None, 0), "nnf_ctx_set_probe_ring")
+            return
+        arr = (C.c_void_p * (2 * len(pairs)))(*[C.c_void_p(e.cuda_event) for pr in pairs for e in pr])
+        _lib.check(self.lib.nnf_ctx_set_probe_ring(self.ctx, arr, len(pairs)), "nnf_ctx_set_probe_ring")
+
+    def probe_ring_count(self):
+        """Pairs of the current ring recorded so far."""
+        return int(self.lib.nnf_ctx_probe_ring_count(self.ctx))
+
+    @staticmethod
+    def probe_pairs(n, stream):
+        """n (begin, end) pairs of timing events, each recorded once on `stream` (torch creates the hipEvent_t lazily)."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for a, b in evs:
             a.record(stream)
             b.record(stream)
+        return evs
+
+    def time_kernel(self, kernel, fn, reps=20):
+        """Duration (ms) of the main kernel `kernel` over `reps` calls of `fn` (which must launch it exactly once on the
+        current stream), measured with HIP events recorded by the library immediately around that kernel.  Returns a
+        `KernelTime`: the plain MEAN over all samples as a float (nothing is dropped), with .median / .min / .max / .n."""
+        stream = torch.cuda.current_stream(self.device)
+        evs = self.probe_pairs(reps, stream)
         fn()
         stream.synchronize()
         try:
-            for a, b in evs:
-                self.set_probe(a, b, kernel)
+            self.set_probe_ring(evs, kernel)
+            for _ in range(reps):
                 fn()
         finally:
-            self.set_probe()
+            self.set_probe_ring(None, kernel)
         stream.synchronize()
-        ts = sorted(a.elapsed_time(b) for a, b in evs)
-        # mean launch duration; a launch that took more than twice the median (the box's GPU is shared with the driver's own
-        # monitoring: one 2 ms hiccup in 20 launches of a 170 us kernel moved a mean by 60 %) is not this kernel's time
-        med = ts[len(ts) // 2]
-        kept = [t for t in ts if t <= 2.0 * med]
-        return sum(kept) / len(kept)
+        return KernelTime.of([a.elapsed_time(b) for a, b in evs])
 
     # ---- NTD -----------------------------------------------------------------------------------------
     def mttkrp3_from_partial(self, Y, Ft, axis, out=None):

@@ -39,6 +39,7 @@ def nmf(data, rank, init="random", U_0=None, V_0=None, n_iter_max=100, tol=1e-8,
         rank = min_data
         warnings.warn(f"The rank is too high for the input matrix. It was set to {min_data} instead.")
 
+    _engine.check_rank(rank, "nmf")
     if deterministic:
         np.random.seed(seed)
 
@@ -63,6 +64,7 @@ def compute_nmf(data, rank, U_in, V_in, n_iter_max=100, tol=1e-8,
     row-sharded problem (contiguous blocks, nn_fac_amd.dist.shard_rows), `V_in` is replicated; the Gram / cross terms, the
     stopping scalars and the cost are all-reduced over the group (RCCL over xGMI) and every rank returns its
     block of U, the whole V and the global costs (start values: nn_fac_amd.dist.sharded_random_init)."""
+    _engine.check_rank(V_in.shape[0], "compute_nmf")
     dev = device_of(data, U_in, V_in)
     eng = _engine.get_engine(dev)
     X = to_dev(data, dev)
@@ -117,6 +119,7 @@ def compute_nmf(data, rank, U_in, V_in, n_iter_max=100, tol=1e-8,
 def one_nmf_step(data, rank, U_in, V_in, norm_data, update_rule, beta,
                  sparsity_coefficients, fixed_modes, normalize, deterministic):
     """One pass of updates on U then V, then the cost (nmf.py:387-458).  Returns (U, V, cost)."""
+    _engine.check_rank(V_in.shape[0], "one_nmf_step")
     dev = device_of(data, U_in, V_in)
     eng = _engine.get_engine(dev)
     X = to_dev(data, dev)
@@ -217,9 +220,13 @@ class _GuessMissed(Exception):
     (status words 3 / 4 of nnf_hals_stop_restore_f32): the iteration is redone with the host-synchronous protocol."""
 
 
-def _raise_on_status(host, nstat, timeout_ok=False):
+def _raise_on_status(host, nstat, timeout_ok=False, nranks=0):
+    """`nranks` > 0: a row-sharded run -- the error words are read from the copies that travelled with the cost's all-reduce
+    (dist.allreduce_cost_), so every rank sees the same code for the same iteration and takes the same branch: a time-out
+    is a rank-local event (the replicated V-side solve of ONE rank found the chip shared), and a rank that fell back to
+    chunked solves alone would issue a different sequence of collectives than its peers (a hang over RCCL)."""
     for i in range(nstat):
-        code = int(host[8 * i + _engine.ST_ERR])
+        code = _dist.agreed_code(host, i, nranks) if nranks else int(host[8 * i + _engine.ST_ERR])
         if code == 2:
             raise err.ZeroColumnWhenUnautorized("A column of U is zero with nonzero condition")
         if code in (_dist.ERR_BEFORE_WINDOW, _dist.ERR_NOT_STOPPED):
@@ -284,10 +291,10 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
                 # the last step's cost from the SAME kernel as every other cost of the run (an update whose output is
                 # dropped): a run stopped early and a run of exactly that many iterations give bitwise equal costs
                 eng.mu_left(X, step["Ut"], step["V"], beta, cost_out=block[16:17])
-                _dist.allreduce_(block[16:17], group)
+                _dist.allreduce_cost_(block, group)
             else:
                 _step_cost(ws.cost_eng if stream is not main else eng, X, step["Ut"], step["V"], update_rule, beta,
-                           sparsity_coefficients, block[16:17], group)
+                           sparsity_coefficients, block, group)
             ws.host[step["slot"]].copy_(block, non_blocking=True)
             step["ev"] = stream.record_event()
 
@@ -297,7 +304,8 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
         if step["ev"] is not None:
             step["ev"].synchronize()
         host = ws.host[step["slot"]]
-        _raise_on_status(host, step["nstat"], timeout_ok=not getattr(ws, "safe_solve", False))
+        _raise_on_status(host, step["nstat"], timeout_ok=not getattr(ws, "safe_solve", False),
+                         nranks=_dist.world(group) if _dist.is_sharded(group) else 0)
         pending.pop(0)                     # (a step that timed out stays at the head: run_steps resumes from it)
         result = (step["Ut"], step["V"])
         if group is not None and update_rule == "hals" and step["nstat"] >= 1 and 0 not in fixed_modes:
@@ -350,7 +358,7 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
         ws.sync_next = False
         if fused_mu:
             if owed is not None:          # its cost has just been enqueued with this step's left update
-                _dist.allreduce_(ws.blocks[owed["slot"]][16:17], group)
+                _dist.allreduce_cost_(ws.blocks[owed["slot"]], group)
                 ws.host[owed["slot"]].copy_(ws.blocks[owed["slot"]], non_blocking=True)
                 owed["ev"] = main.record_event()
             owed = step
@@ -447,11 +455,13 @@ def _step_cost_local(eng, X, Ut, V, update_rule, beta, out):
         eng.betadiv(X, Ut, V, beta, out=out)                      # nmf.py:455
 
 
-def _step_cost_finish(Ut, V, update_rule, sparsity_coefficients, out, group=None):
-    """Sum over the row blocks and the sparsity terms of nmf.py:452."""
+def _step_cost_finish(Ut, V, update_rule, sparsity_coefficients, block, group=None):
+    """Sum over the row blocks (the error words of the iteration's solves ride along: dist.allreduce_cost_) and the sparsity
+    terms of nmf.py:452.  `block`: the iteration's 24-double status block, cost at [16]."""
     sharded = _dist.is_sharded(group)
+    out = block[16:17]
     if sharded:
-        _dist.allreduce_(out, group)
+        _dist.allreduce_cost_(block, group)
     sp = [0 if s is None else s for s in sparsity_coefficients]
     if update_rule == "hals" and (sp[0] or sp[1]):
         # matrix 1-norm (max column abs-sum, np.linalg.norm(., ord=1)) -- NOT the entry-wise l1 (nmf.py:452)
@@ -463,10 +473,10 @@ def _step_cost_finish(Ut, V, update_rule, sparsity_coefficients, out, group=None
         out.add_(2 * (sp[0] * nU + sp[1] * nV))
 
 
-def _step_cost(eng, X, Ut, V, update_rule, beta, sparsity_coefficients, out, group=None):
-    """The cost line of one_nmf_step (nmf.py:449-455) into the 1-element float64 device tensor `out`, on the current stream."""
-    _step_cost_local(eng, X, Ut, V, update_rule, beta, out)
-    _step_cost_finish(Ut, V, update_rule, sparsity_coefficients, out, group)
+def _step_cost(eng, X, Ut, V, update_rule, beta, sparsity_coefficients, block, group=None):
+    """The cost line of one_nmf_step (nmf.py:449-455) into word 16 of the float64 status block `block`, on the current stream."""
+    _step_cost_local(eng, X, Ut, V, update_rule, beta, block[16:17])
+    _step_cost_finish(Ut, V, update_rule, sparsity_coefficients, block, group)
 
 
 def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
@@ -572,5 +582,5 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                 V = eng.mu_right(X, Ut, V_in, beta)     # nmf.py:447
 
     if not skip_cost:
-        _step_cost(eng, X, Ut, V, update_rule, beta, sparsity_coefficients, ws.cost, group)
+        _step_cost(eng, X, Ut, V, update_rule, beta, sparsity_coefficients, ws.block, group)
     return Ut, V, nstat

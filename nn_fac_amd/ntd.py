@@ -51,6 +51,7 @@ def ntd(tensor, ranks, init="random", core_0=None, factors_0=[], n_iter_max=100,
         if ranks[i] > tensor.shape[i]:
             ranks[i] = tensor.shape[i]
             warnings.warn(f"The {i}-th mode rank was larger than the shape of the tensor, which is incorrect (rank: {ranks[i]}, tensor shape: {tensor.shape[i]}). The rank was then set to the shape of the tensor.")
+    _engine.check_rank(max(ranks), "ntd")
     if update_rule == "hals":
         assert beta == 2, f"Beta parameter is only used for MU update rule. Please set update_rule to 'mu' to use another beta value than 2. (Current setting: beta = {beta} and update_rule = {update_rule})."
     if init.lower() == "custom":
@@ -353,6 +354,7 @@ def compute_ntd(tensor_in, ranks, core_in, factors_in, n_iter_max=100, tol=1e-6,
                 verbose=False, return_costs=False, deterministic=False, seed=0, sweep_log=None, pg_log=None):
     """Outer loop of ntd.py:355-433.  Returns (core, factors) [, costs, toc]; sweep_log / pg_log (not in the reference)
     collect the inner sweep counts and projected-gradient iteration counts."""
+    _engine.check_rank(max(ranks), "compute_ntd")
     dev = device_of(tensor_in, core_in, *factors_in)
     eng = _engine.get_engine(dev)
     st = _NtdState(eng, to_dev(tensor_in, dev))
@@ -448,6 +450,7 @@ def one_ntd_step(tensor, ranks, in_core, in_factors, norm_tensor,
     """One HALS pass over the modes + projected-gradient core update (ntd.py:436-645).
     Returns (core, factors, normalised cost).  `norm_tensor` is accepted for signature parity; ||T||^2 is recomputed on
     the device."""
+    _engine.check_rank(max(ranks), "one_ntd_step")
     dev = device_of(tensor, in_core, *in_factors)
     eng = _engine.get_engine(dev)
     st = _NtdState(eng, to_dev(tensor, dev))
@@ -465,6 +468,7 @@ def one_ntd_step(tensor, ranks, in_core, in_factors, norm_tensor,
 def one_ntd_step_mu(tensor, ranks, in_core, in_factors, beta, norm_tensor,
                     fixed_modes, normalize, mode_core_norm):
     """One MU pass over the modes and the core (ntd.py:658-698).  Returns (core, factors, beta-divergence)."""
+    _engine.check_rank(max(ranks), "one_ntd_step_mu")
     dev = device_of(tensor, in_core, *in_factors)
     eng = _engine.get_engine(dev)
     st = _NtdState(eng, to_dev(tensor, dev))

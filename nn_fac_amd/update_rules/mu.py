@@ -17,6 +17,7 @@ def mu_betadivmin(U, V, M, beta):
     """U <- max(U * ((K^(beta-2) .* M) V^T / (K^(beta-1) V^T))^gamma(beta), 1e-12), K = U V   (mu.py:79-97)."""
     if beta < 0:
         raise err.InvalidArgumentValue("Invalid value for beta: negative one.") from None
+    _engine.check_rank(V.shape[0], "mu_betadivmin")
     dev = device_of(U, V, M)
     eng = _engine.get_engine(dev)
     X = to_dev(M, dev)
@@ -33,6 +34,7 @@ def switch_alternate_mu(data, U, V, beta, matrix):
     elif matrix in ["V", "H"]:
         if beta < 0:
             raise err.InvalidArgumentValue("Invalid value for beta: negative one.") from None
+        _engine.check_rank(V.shape[0], "switch_alternate_mu")
         dev = device_of(U, V, data)
         eng = _engine.get_engine(dev)
         out = eng.mu_right(to_dev(data, dev), to_dev_t(U, dev), to_dev(V, dev), beta)
@@ -49,6 +51,7 @@ def mu_tensorial(G, factors, tensor, beta):
     from ..ntd import _NtdState, _mu_tensorial_dev
     if beta < 0:
         raise err.InvalidArgumentValue("Invalid value for beta: negative one.") from None
+    _engine.check_rank(max(G.shape), "mu_tensorial")
     dev = device_of(tensor, G, *factors)
     eng = _engine.get_engine(dev)
     st = _NtdState(eng, to_dev(tensor, dev))

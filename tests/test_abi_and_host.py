@@ -33,6 +33,48 @@ def test_binding_table_matches_header(built_lib):
     assert b"not supported" in lib.nnf_status_string(-3)
 
 
+def test_built_library_carries_the_default_build_switches(built_lib):
+    """The timing-only ablation / A-B macros of the kernel sources (XHT_ABL, SEG_ABL, MTTKRP_ABL, HALS_LATE_ISSUE, ...): a stray
+    -D in a build would silently ship a kernel that skips work.  Every translation unit records the values it was compiled
+    with (nnf_build_flags); the library under test must carry the product defaults in every unit."""
+    from nn_fac_amd import _lib
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(8192)
+    n = lib.nnf_build_flags(buf, 8192)
+    assert 0 < n < 8192
+    got = dict(u.split(": ", 1) for u in buf.value.decode().split("; "))
+    hals = "HALS_LATE_ISSUE=1 HALS_MID_AT(R)=((R) - 1)"
+    quad = "QUAD_MID_SEL=1 HALS_LATE_ISSUE=1"
+    mu = "MU_WG_PER_CU=2 MU_STEP_FENCE()=__builtin_amdgcn_sched_barrier(0)"
+    want = {"k_stream": "XHT_ABL=0", "k_mttkrp": "SEG_ABL=0 MTTKRP_ABL=0",
+            **{f"k_hals_fast{i}": hals for i in range(4)}, **{f"k_hals_quad{i}": quad for i in range(4)},
+            **{f"k_mu{i}": mu for i in range(3)}}
+    for unit, flags in want.items():
+        assert got.get(unit) == flags, (unit, got.get(unit))
+
+
+def test_rank_above_the_kernels_limit_is_refused_at_the_boundary():
+    """The reference takes any rank up to min(shape) (nn_fac/nmf.py:175-178); the kernels here stop at 128.  Every drop-in entry
+    says so before anything is uploaded or launched (also without a GPU), not as a bare status code from inside an iteration."""
+    from nn_fac_amd.utils.errors import EngineError
+    from nn_fac_amd.update_rules.nnls import hals_nnls_acc, hals_coupling_nnls_acc
+    from nn_fac_amd.update_rules.mu import mu_betadivmin, switch_alternate_mu
+    from nn_fac_amd.nmf import nmf, compute_nmf
+    from nn_fac_amd.ntf import ntf
+    from nn_fac_amd.ntd import ntd
+    rng = np.random.RandomState(0)
+    r = 129
+    X, U, V = rng.rand(140, 150), rng.rand(140, r), rng.rand(r, 150)
+    calls = [lambda: hals_nnls_acc(rng.rand(r, 9), rng.rand(r, r), rng.rand(r, 9)),
+             lambda: hals_coupling_nnls_acc(rng.rand(r, 9), rng.rand(r, r), rng.rand(r, 9), rng.rand(r, 9), 0.5),
+             lambda: mu_betadivmin(U, V, X, 1), lambda: switch_alternate_mu(X, U, V, 1, "V"),
+             lambda: nmf(X, r, n_iter_max=2, deterministic=True), lambda: compute_nmf(X, r, U, V, n_iter_max=2),
+             lambda: ntf(rng.rand(130, 131, 132), r, n_iter_max=1), lambda: ntd(rng.rand(130, 131, 132), [r, 4, 4], n_iter_max=1)]
+    for f in calls:
+        with pytest.raises(EngineError, match="rank 129 is above the 128"):
+            f()
+
+
 def test_no_gpu_means_loud_failure(built_lib):
     import torch
     if torch.cuda.is_available():

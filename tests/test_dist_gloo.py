@@ -331,6 +331,78 @@ def test_run_steps_falls_back_to_chunked_solves_after_a_timeout():
     assert s1 == s0
 
 
+def _flaky_worker(rank, nranks, port, m, n, r, iters, flaky_rank, q):
+    """One rank of a row-sharded run whose replicated V-side solve reports a time-out on `flaky_rank` ONLY."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=nranks)
+    try:
+        import warnings
+        from nn_fac_amd import nmf as nmf_mod, dist as nd
+        X, U0, V0 = orc.synth_nmf(m, n, r, seed=4, dtype=np.float64)
+        lo, hi = nd.shard_rows(m, rank, nranks)
+        Xl = torch.from_numpy(X[lo:hi].copy())
+
+        class Flaky(OracleEngine):
+            calls = 0
+
+            def hals_solve(self, *a, **kw):
+                Flaky.calls += 1
+                st = super().hals_solve(*a, **kw)
+                if Flaky.calls == 3 and rank == flaky_rank:      # the V-side solve of the third iteration, on one rank
+                    st[3] = 1.0
+                return st
+
+        eng, ws = Flaky(), nmf_mod._StepBuffers(Xl, r, dtype=torch.float64)
+        ws.guess_u = nd.SweepGuess(first=3, max_chunk=5, window=2)
+        ws.guess_v = nd.SweepGuess(first=3, max_chunk=5, window=2)
+        costs, sweeps = [], []
+
+        def retired(it, cost, sw):
+            costs.append((it, cost))
+            sweeps.extend(sw)
+            return False
+
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            Ut, V = nmf_mod.run_steps(eng, ws, Xl, r, torch.from_numpy(U0[lo:hi].T.copy()), torch.from_numpy(V0.copy()), iters,
+                                      "hals", 2, [None, None], [], [False, False], True, retired, group=dist.group.WORLD)
+        q.put((rank, Ut.numpy().T.copy(), V.numpy().copy(), costs, sweeps, bool(ws.safe_solve),
+               any("timed out" in str(x.message) for x in w)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("flaky_rank", [0, 1])
+def test_row_sharded_timeout_fall_back_is_taken_by_every_rank(flaky_rank):
+    """A persistent solve that times out is a rank-local event (ONE rank's replicated V-side solve found the chip shared).
+    The error word travels with the cost's all-reduce (dist.allreduce_cost_), so BOTH ranks drop what is in flight, rewind
+    to the same iteration and switch to chunked solves together -- the collectives keep matching -- and the run ends with
+    the factors, costs and sweep counts of the undisturbed unsharded oracle."""
+    m, n, r, iters, nranks = 121, 30, 5, 6, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flaky_worker, args=(k, nranks, port, m, n, r, iters, flaky_rank, q)) for k in range(nranks)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(nranks))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    X, U0, V0 = orc.synth_nmf(m, n, r, seed=4, dtype=np.float64)
+    sw = []
+    U, V, costs, _ = orc.compute_nmf(X, r, U0, V0, n_iter_max=iters, tol=0, update_rule="hals", return_costs=True,
+                                     deterministic=True, sweeps=sw)
+    np.testing.assert_allclose(np.concatenate([x[1] for x in res], axis=0), U, rtol=1e-9, atol=1e-12)
+    for rank, Ul, Vl, cl, sl, safe, warned in res:
+        assert safe and warned, (rank, safe, warned)       # the rank that did NOT time out fell back as well
+        assert [i for i, _ in cl] == list(range(iters))     # every iteration retired exactly once, in order
+        np.testing.assert_allclose(Vl, V, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose([c for _, c in cl], costs, rtol=1e-9)
+        assert sl == sw
+    assert np.array_equal(res[0][2], res[1][2])
+
+
 def test_sharded_random_init_reproduces_the_reference_stream():
     """dist.sharded_random_init(exact_stream=True): the blocks of all ranks concatenated are the unsharded start values of the
     reference (initialize_factors.py:40-46: np.random.seed(seed); rand(m, r); rand(r, n)) = the oracle's nmf_random_init;

@@ -142,11 +142,11 @@ def test_bench_single_rank_rccl_smoke(built_lib):
     assert out["roofline"]["kernel"].startswith("nnf_xty_kernel") and out["roofline"]["launch_ms"] > 0
 
 
-@pytest.mark.parametrize("cfg", ["B", "C"])
-def test_sharded_protocol_on_a_one_rank_rccl_group(built_lib, cfg):
-    """The row-sharded step as the driver's N > 1 runs execute it -- over RCCL, so with the device-side stopping decision,
-    the overlapped cost and (MU) the fused KL cost + scalar all-reduce all switched on (dist.opt_in) -- on the one rank a
-    one-GPU box offers (NNF_FORCE_SHARDED=1): same data, same number of iterations as the unsharded run of the same bench
+@pytest.mark.parametrize("cfg,switches", [("B", False), ("B", True), ("C", True)])
+def test_sharded_protocol_on_a_one_rank_rccl_group(built_lib, cfg, switches):
+    """The row-sharded step over RCCL with the device-side stopping decision, the overlapped cost (both opt-in:
+    NNF_SHARDED_ASYNC=1, NNF_SHARDED_OVERLAP=1 -- off by default until an N > 1 run on real GPUs has exercised them) and (MU)
+    the fused KL cost + scalar all-reduce switched on -- on the one rank a one-GPU box offers (NNF_FORCE_SHARDED=1): same data, same number of iterations as the unsharded run of the same bench
     command; HALS iterates and costs agree to the tolerance of two differently ordered fp32 sums of the stopping scalar, the MU
     line to rounding."""
     import json
@@ -166,6 +166,8 @@ def test_sharded_protocol_on_a_one_rank_rccl_group(built_lib, cfg):
             env.pop(k, None)
         if forced:
             env.update(NNF_BENCH_FORCE_SHARDED="1", NNF_FORCE_SHARDED="1")
+            if switches:   # both opt-in switches on: the paths with the most moving parts; off: what the driver's N > 1 runs use
+                env.update(NNF_SHARDED_ASYNC="1", NNF_SHARDED_OVERLAP="1")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(root, "bench.py"), "--config", cfg, "--gpus", "1", "--steps", "12",
                "--warmup", "2", "--shape", "30000,600,18", "--no-cpu", "--no-extra", "--no-fixed", "--no-kernels"]
@@ -181,6 +183,8 @@ def test_sharded_protocol_on_a_one_rank_rccl_group(built_lib, cfg):
     if cfg == "B":
         assert plain["config"]["inner_sweeps_per_step_last"] == shard["config"]["inner_sweeps_per_step_last"]
         assert "sharded U-side protocol" in err          # the protocol really ran (bench.py's debug line)
+        sp = shard["config"]["sharded_protocol"]
+        assert sp["u_side_stopping_decision"].startswith("device" if switches else "host-synchronous") and not sp["fell_back_to_chunked_solves"]
 
 
 def test_config_e_full_size_on_one_gpu(built_lib):

@@ -1,16 +1,44 @@
 """Randomised end-to-end parity sweep (HALS and MU drivers vs the CPU oracle) over odd shapes and ranks.  Test
-infrastructure: imports oracle/.  python tools/stress_parity.py [seed] [cases]"""
-import math, os, sys
-import numpy as np, torch
+infrastructure: imports oracle/.  python tools/stress_parity.py [seed] [cases]
+
+Tolerances are DESIGN.md section 4's: HALS factors rel_fro <= 5e-4, cost <= 1e-3, inner sweep counts equal; MU
+factors <= 2e-4 (general beta over odd shapes), cost <= 1e-3.  Two documented exceptions, both decided from the ORACLE's own
+numbers, never from the device's:
+
+* threshold noise -- the inner loop stops at the first sweep with eps < delta * eps0 (nnls.py:156).  When the fp64 oracle's
+  own eps / (delta * eps0) at the sweep where the counts part is within THRESH_BAND of 1, the fp32 history of the operands
+  (a state that differs by ~2e-4 from the oracle's after a few outer iterations moves that ratio by about as much) decides
+  on which side of the threshold the sweep falls: the counts of that solve may then differ by one (seed 81, case 43:
+  ratio 0.99968 in the oracle, 1.00002 on the device -- with the oracle run on the device's own operands the ratio is
+  1.00010 and the counts agree, tools/probes/seed81_probe.py).  From that solve on the two runs are one sweep apart, so the
+  rest of the case is compared with the looser bound LOOSE (one sweep of a solve that still moves by 1 % of its first
+  sweep) and later counts are not compared.
+* rank = the smaller dimension -- the NNLS Gram is then close to singular and differences are amplified by its condition
+  number: factors are compared with LOOSE (the cost, which is what is well determined there, keeps its bound).
+"""
+import os, sys
+import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import nnfac_oracle as orc
 from nn_fac_amd.nmf import compute_nmf
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+verbose = len(sys.argv) > 3
+TOL_HALS, TOL_MU, TOL_COST, LOOSE, THRESH_BAND, DELTA = 5e-4, 2e-4, 1e-3, 2e-3, 2e-3, 0.01
 rng = np.random.RandomState(seed)
 def rel(a, b): return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
-bad = 0
+
+_orig, solve_logs = orc.hals_nnls_acc, []
+def _logged(*a, **kw):                       # every inner solve of the oracle leaves its per-sweep sums of squared steps
+    log = []
+    kw["sweep_log"] = log
+    out = _orig(*a, **kw)
+    solve_logs.append(log)
+    return out
+orc.hals_nnls_acc = _logged
+
+bad = notes = 0
 for c in range(cases):
     r = int(rng.choice([1, 2, 3, 5, 16, 17, 31, 32, 33, 48, 50, 63, 64, 65, 100, 127, 128]))
     m = int(rng.choice([r, r + 1, 64, 97, 255, 256, 257, 700, 1500]))
@@ -28,6 +56,7 @@ for c in range(cases):
     kw = dict(n_iter_max=4, tol=0, update_rule=rule, beta=beta, sparsity_coefficients=sp, normalize=nz, return_costs=True,
               deterministic=True)
     sw, swo = [], []
+    solve_logs.clear()
     try:
         U, V, costs, _ = compute_nmf(X, r, U0, V0, sweep_log=sw, **kw)
         Uo, Vo, co, _ = orc.compute_nmf(X.astype(np.float64), r, U0.astype(np.float64), V0.astype(np.float64), sweeps=swo, **kw)
@@ -35,9 +64,27 @@ for c in range(cases):
         print("CASE", c, (m, n, r, rule, beta, sp, nz), "raised", type(e).__name__, e); bad += 1; continue
     eu, ev = rel(U, Uo), rel(V, Vo)
     ec = max(abs(a - b) / max(abs(b), 1e-30) for a, b in zip(costs, co))
-    tol_f = 2e-3 if rule == "hals" else 2e-4
-    flag = (not np.all(np.isfinite(costs))) or eu > tol_f or ev > tol_f or ec > 2e-3 or (rule == "hals" and sw != swo)
+    tol_f, tol_c, why = (TOL_HALS if rule == "hals" else TOL_MU), TOL_COST, ""
+    counts_ok = True
+    if rule == "hals":
+        if r >= min(m, n):
+            tol_f, why = LOOSE, "rank = smaller dimension"
+        if sw != swo:
+            j = next(i for i, (a, b) in enumerate(zip(sw, swo)) if a != b)
+            log, s = solve_logs[j], min(sw[j], swo[j])          # the oracle's sums of that solve; s = the earlier stop
+            ratio = log[s - 1] / (DELTA * log[0]) if 1 <= s <= len(log) and log[0] > 0 else float("inf")
+            if abs(sw[j] - swo[j]) == 1 and abs(ratio - 1.0) < THRESH_BAND:
+                tol_f, tol_c = LOOSE, 2 * LOOSE
+                why = f"threshold noise at solve {j}: oracle eps/(delta eps0) = {ratio:.6f} at sweep {s}"
+            else:
+                counts_ok = False
+    flag = (not np.all(np.isfinite(costs))) or eu > tol_f or ev > tol_f or ec > tol_c or not counts_ok
     if flag:
         bad += 1
-        print("CASE", c, (m, n, r, rule, beta, sp, nz), f"relU {eu:.1e} relV {ev:.1e} cost {ec:.1e} sweeps {sw} vs {swo}")
-print(f"stress seed {seed}: {cases} cases, {bad} flagged")
+        print("CASE", c, (m, n, r, rule, beta, sp, nz), f"relU {eu:.1e} relV {ev:.1e} cost {ec:.1e} sweeps {sw} vs {swo}", why)
+    elif why and (sw != swo or max(eu, ev) > TOL_HALS):
+        notes += 1
+        print("NOTE", c, (m, n, r, rule, beta), f"relU {eu:.1e} relV {ev:.1e} cost {ec:.1e} [{why}] sweeps {sw} vs {swo}")
+    elif verbose:
+        print("ok  ", c, (m, n, r, rule, beta), f"relU {eu:.1e} relV {ev:.1e} cost {ec:.1e}")
+print(f"stress seed {seed}: {cases} cases, {bad} flagged ({notes} within a documented exception)")

@@ -404,8 +404,12 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta, loop_times=None, steps=20
                         hbm_gbs=xbytes / ms / 1e6))
         # (the cost of iteration i runs beside the V-side solve of iteration i+1, on the cost stream's own context)
         ceng = ws.cost_eng if getattr(ws, "cost_eng", None) is not None else eng
-        with_inloop(out[-1], run.inloop(ceng, "cost", 1, steps)[0], flops, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
-                    where_more + " (beside the V-side solve)")
+        ctimes = run.inloop(ceng, "cost", 1, steps)[0]
+        with_inloop(out[-1], ctimes, flops, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", where_more + " (beside the V-side solve)")
+        if not ctimes:
+            out[-1]["measured"] = ("stand-alone only: the loop does not launch this kernel -- its cost comes from the Gram identity "
+                                   "||X||^2 - 2<V,U^T X> + sum_j v_j^T (U^T U) v_j on the V update's operands (nnf_nmf_gram_cost_f32; "
+                                   "this kernel is the fall-back for an almost exact fit, and NNF_COST=direct)")
         # the two persistent solves as the loop runs them (stopping rule on the device): launches alternate U side, V side
         ts, sw = run.inloop(eng, "hals", 2, steps)
         solves = {}
@@ -511,6 +515,9 @@ def bench_nmf(cx, args, cfg, steps, warmup, with_cpu, with_fixed, with_kernels):
                     if nd.opt_in("NNF_SHARDED_OVERLAP", cx.group) else "inside the step (default)",
             "device_decisions": run.ws.async_hits, "redone_synchronously": run.ws.async_misses,
             "fell_back_to_chunked_solves": bool(run.ws.safe_solve)}
+    if rule == "hals" and cx.cuda:
+        out["cost_evaluation"] = ("streaming kernel (nnf_frob_resid_f32)" if (run.ws.direct_cost or os.environ.get("NNF_COST") == "direct")
+                                  else "Gram identity (nnf_nmf_gram_cost_f32), fp64 inner products, guarded by its own error estimate")
     if with_fixed and rule == "hals":
         f = run.fixed_work()
         f["iterations_per_s"] *= units
@@ -694,6 +701,8 @@ def main():
             out["fixed_work"] = res["fixed_work"]
         if "nondeterministic" in res:
             out["nondeterministic"] = res["nondeterministic"]
+        if "cost_evaluation" in res:
+            out["config"]["cost_evaluation"] = res["cost_evaluation"]
         if "sharded_protocol" in res:
             out["config"]["sharded_protocol"] = res["sharded_protocol"]
         if extra is not None:

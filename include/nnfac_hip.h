@@ -126,6 +126,19 @@ int nnf_xty_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx,
 int nnf_frob_resid_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
                        const float* V, int64_t ldv, int r, double* out_f64, void* stream);
 
+/* The same cost (nmf.py:452) from what a HALS iteration has on hand after its V update, without another pass over X:
+ *     ||X - U V||^2 = ||X||^2 - 2 <V, U^T X> + sum_j v_j^T (U^T U) v_j
+ * UtM = U^T X (r x n) and UtU (r x r) are the fp32 operands of the V update (nmf.py:432-433: they belong to the final U of
+ * the iteration), V (r x n) is its result, *normx2_f64 = ||X||^2 (device scalar: computed once per run, all-reduced once in
+ * a row-sharded run -- every other operand is replicated there, so this cost needs no collective).  The three inner
+ * products and the quadratic forms are taken in fp64; the fp32 rounding of UtM and UtU leaves an absolute error of
+ * ~1e-9 ||X||^2 (measured: tools/probes/gram_cost_probe.py), which is only acceptable while the
+ * residual is not that small.  The kernel estimates it and says so:
+ *   out_f64[0] = cost,  out_f64[1] = 0 if the estimate is below 5e-4 of the cost, else 1 (the caller then evaluates
+ *   nnf_frob_resid_f32 for this iterate),  out_f64[2] = the estimate (4 sigma). */
+int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg,
+                          int r, int64_t n, const double* normx2_f64, double* out_f64, void* stream);
+
 /* hals_nnls_acc (nnls.py:147-198) on device: V (r x ncols, in/out) is swept in place until
  *   eps >= delta*eps0 fails, or sweeps == max_sweeps                         (nnls.py:156)
  * max_sweeps is min(maxiter, floor(1+alpha*rho)) resolved by the host; the wall-clock rule of nnls.py:190-194 stays

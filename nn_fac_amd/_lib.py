@@ -9,7 +9,8 @@ import os
 from .utils.errors import EngineError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnnfac_hip.so")
+# NNF_LIBRARY: another build of the same library (tools/: timing-only ablation builds side by side with the product's)
+LIB_PATH = os.environ.get("NNF_LIBRARY") or os.path.join(_HERE, "libnnfac_hip.so")
 
 _i64, _i32, _u32 = C.c_int64, C.c_int, C.c_uint
 _p, _f32, _f64 = C.c_void_p, C.c_float, C.c_double
@@ -33,6 +34,7 @@ SIGNATURES = {
     "nnf_xht_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32, _i64, _p, _i64, _p]),
     "nnf_xty_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32, _i64, _p, _i64, _p]),
     "nnf_frob_resid_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _p]),
+    "nnf_nmf_gram_cost_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _p, _p, _p]),
     "nnf_hals_solve_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _f64, _f32, _u32, _p, _p]),
     "nnf_hals_solve_cross_f32": (_i32, [_p, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _f64, _f32, _u32, _p,
                                         _p]),

@@ -187,6 +187,18 @@ static int pick_rp(int r) {
     return -1;
 }
 
+// workgroups of 256 columns the register-resident lane kernel of padded rank RP keeps on the chip
+static int64_t lane_resident_blocks(nnf_ctx* ctx, int RP) {
+    hals_args q{};
+    q.ncols = -1;
+    int nb = 0, rc;
+    if (RP <= 48) rc = nnf_hals_fast_part0(ctx, RP, q, NNF_HALS_MAX_BLOCKS, &nb, nullptr);
+    else if (RP <= 64) rc = nnf_hals_fast_part1(ctx, RP, q, NNF_HALS_MAX_BLOCKS, &nb, nullptr);
+    else if (RP <= 104) rc = nnf_hals_fast_part2(ctx, RP, q, NNF_HALS_MAX_BLOCKS, &nb, nullptr);
+    else rc = nnf_hals_fast_part3(ctx, RP, q, NNF_HALS_MAX_BLOCKS, &nb, nullptr);
+    return rc == NNF_OK ? nb : 0;
+}
+
 template <int MODE>
 static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V, int64_t ldv,
                       int r, int64_t ncols, int nsweeps, double delta, float sparsity, unsigned flags, double* status,
@@ -207,13 +219,21 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     // few columns: four lanes per column (k_hals_quad.hip); many: one lane per column (k_hals_fast.hip)
     // NNF_HALS_FORCE=lane|quad pins the column layout (tests exercise both kernels on the same fixtures)
     const char* force = getenv("NNF_HALS_FORCE");
-    const bool force_lane = force && force[0] == 'l', force_quad = force && force[0] == 'q';
-    const bool quad = !generic && !force_lane && (ncols <= 32768 || force_quad) && (int64_t)(r + 16) * (ldv > ldm ? ldv : ldm) * 4 < (int64_t)0x7fff0000 &&
+    const bool force_lane = force && force[0] == 'l', force_quad = force && force[0] == 'q', force_wave = force && force[0] == 'w';
+    // fewer still (<= 4800, a persistent solve from its first sweep): one wave per column, push form (k_hals_wave.hip)
+    const bool wave = !generic && MODE == 0 && sweep0 == 0 && !force_lane && !force_quad && nsweeps <= NNF_HALS_MAX_SWEEPS &&
+                      nnf_hals_wave_fits(ctx, r, ncols, max_blocks);
+    (void)force_wave;
+    const bool quad = !wave && !generic && !force_lane && (ncols <= 32768 || force_quad) && (int64_t)(r + 16) * (ldv > ldm ? ldv : ldm) * 4 < (int64_t)0x7fff0000 &&
                       nnf_hals_quad_fits(ctx, r, ncols, max_blocks);
+    if (getenv("NNF_HALS_DEBUG"))
+        fprintf(stderr, "[nnf hals] r=%d ncols=%lld mode=%d sweeps=%d layout=%s\n", r, (long long)ncols, MODE, nsweeps,
+                wave ? "wave" : quad ? "quad" : generic ? "generic" : "lane");
     const size_t gs_off = (((size_t)RP * RS + 2 * RP + 1) + 15) & ~(size_t)15;   // scaled image, 64-byte aligned
     const bool want_gs = !generic && RP > 32 && RP <= 52;
     size_t gfloats = gs_off + (want_gs ? (size_t)RP * RS : 0);
     if (quad && nnf_hals_quad_gram_floats(r) > gfloats) gfloats = nnf_hals_quad_gram_floats(r);
+    if (wave && nnf_hals_wave_gram_floats(r) > gfloats) gfloats = nnf_hals_wave_gram_floats(r);
     float* Gp = (float*)cur.take(gfloats * 4);   // padded Gram, then the (1/diag, nz) pairs (quad: scaled Gram, 1/diag)
     float* dinv = Gp ? Gp + (size_t)RP * RS : nullptr;
     unsigned* counter = (unsigned*)cur.take(256);
@@ -226,7 +246,7 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     if (!Gp || !dinv || !counter || !slots || !sslots || (MODE == 1 && !sweep_partials))
         return NNF_ERR_WORKSPACE;
     if (Vsrc == nullptr || Vsrc == V) { Vsrc = V; ldvs = ldv; }
-    if (!quad && (UtU2 != nullptr || Vsrc != V)) {
+    if (!quad && !wave && (UtU2 != nullptr || Vsrc != V)) {
         // the Hadamard Gram and the separate start values are native to the few-column (quad) kernel -- the shape they were
         // made for (NTF factors); the other layouts get them from two small element-wise launches
         if (UtU2 != nullptr) {
@@ -238,7 +258,11 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
             ldg = r;
             UtU2 = nullptr;
         }
-        if (Vsrc != V) {
+        // separate start values: the resident lane kernel reads them itself (once); the generic and the streaming kernels
+        // work in place on a copy
+        const bool lane_resident = !generic && nsweeps > 0 && RP > 0 && nnf_cdiv(ncols, 256) <= lane_resident_blocks(ctx, RP) &&
+                                   (((int64_t)(r - 1) * ldvs + ncols) * 4) < (int64_t)0x7fff0000;
+        if (Vsrc != V && !lane_resident) {
             if (hipMemcpy2DAsync(V, (size_t)ldv * 4, Vsrc, (size_t)ldvs * 4, (size_t)ncols * 4, (size_t)r, hipMemcpyDeviceToDevice,
                                  st) != hipSuccess)
                 return NNF_ERR_LAUNCH;
@@ -246,7 +270,7 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
             ldvs = ldv;
         }
     }
-    if (!quad) {
+    if (!quad && !wave) {
         hipLaunchKernelGGL(nnf_hals_prep_kernel, dim3(RP), dim3(128), 0, st, UtU, ldg, r, RP, Gp, dinv,
                            want_gs ? Gp + gs_off : (float*)nullptr, counter,
                            (MODE == 0 && sweep0 == 0) ? status : (double*)nullptr);
@@ -260,7 +284,15 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     }
     hals_sync sy{counter, slots, sslots, ctx->hals_epoch};
     int nblocks = 0, rc = NNF_OK;
-    if (quad) {
+    if (wave) {
+        hals_args a{UtM, ldm, nullptr, nullptr, nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status, sweep_partials,
+                    snapshots, snap_stride, sweep0, Vsrc, ldvs};
+        float* snap = (float*)cur.take(nnf_hals_wave_snap_floats(r, ncols) * 4);
+        if (!snap) return NNF_ERR_WORKSPACE;
+        rc = nnf_hals_wave_run(ctx, UtU, UtU2, ldg, Gp, snap, counter, a, &nblocks, st);
+        if (rc != NNF_OK) return rc;
+        if (nsweeps == 0) return NNF_OK;
+    } else if (quad) {
         if ((((int64_t)(r - 1) * ldv + ncols) * 4) >= (int64_t)0x7fff0000 || (((int64_t)(r - 1) * ldm + ncols) * 4) >= (int64_t)0x7fff0000)
             return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
         hals_args a{UtM, ldm, nullptr, nullptr, nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status, sweep_partials,
@@ -289,7 +321,7 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
         if ((((int64_t)(r - 1) * ldv + ncols) * 4) >= (int64_t)0x7fff0000 || (((int64_t)(r - 1) * ldm + ncols) * 4) >= (int64_t)0x7fff0000)
             return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
         hals_args a{UtM, ldm, Gp, dinv, want_gs ? Gp + gs_off : nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status,
-                    sweep_partials, snapshots, snap_stride, sweep0, V, ldv};
+                    sweep_partials, snapshots, snap_stride, sweep0, Vsrc, ldvs};
         nnf_probe(ctx, NNF_PROBE_HALS, 0, st);
         if (RP <= 48) rc = nnf_hals_fast_part0(ctx, RP, a, max_blocks, &nblocks, st);
         else if (RP <= 64) rc = nnf_hals_fast_part1(ctx, RP, a, max_blocks, &nblocks, st);

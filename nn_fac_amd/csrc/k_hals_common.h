@@ -331,6 +331,13 @@ int nnf_hals_fast_part1(nnf_ctx*, int RP, const hals_args&, int max_blocks_cap, 
 int nnf_hals_fast_part2(nnf_ctx*, int RP, const hals_args&, int max_blocks_cap, int* nblocks_out, hipStream_t);
 int nnf_hals_fast_part3(nnf_ctx*, int RP, const hals_args&, int max_blocks_cap, int* nblocks_out, hipStream_t);
 
+// k_hals_wave.hip: one wave per column (lane = row), push form of the sweep; solve mode, <= 4800 columns
+bool nnf_hals_wave_fits(nnf_ctx*, int r, int64_t ncols, int max_blocks_cap);
+size_t nnf_hals_wave_gram_floats(int r);
+size_t nnf_hals_wave_snap_floats(int r, int64_t ncols);
+int nnf_hals_wave_run(nnf_ctx*, const float* UtU, const float* UtU2, int64_t ldg, float* Gw, float* snap, unsigned* counter,
+                      hals_args a, int* nblocks_out, hipStream_t);
+
 // k_hals_quad.hip: four lanes per column, for solves with few columns
 bool nnf_hals_quad_fits(nnf_ctx*, int r, int64_t ncols, int max_blocks_cap);
 size_t nnf_hals_quad_gram_floats(int r);

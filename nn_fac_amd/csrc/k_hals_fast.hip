@@ -240,6 +240,12 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
     const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.UtM), 0,
                                                         (int)(((int64_t)(a.r - 1) * a.ldm + a.ncols) * 4), 0x00020000);
     const int ldv4 = (int)(a.ldv * 4), ldm4 = (int)(a.ldm * 4);
+    // start values: a.Vsrc (resident kernel only: the column is read ONCE, before the first sweep, and V is written once, at
+    // the end -- so a solve that starts from another matrix, nmf.py:415 `hals_nnls_acc(..., U_in^T)`, needs no copy of it first;
+    // the streaming kernel re-reads V every sweep and gets Vsrc == V from the entry point)
+    const rsrc_t rvs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Vsrc), 0,
+                                                         (int)(((int64_t)(a.r - 1) * a.ldvs + a.ncols) * 4), 0x00020000);
+    const int ldvs4 = (int)(a.ldvs * 4);
     f32x2 v2[RP / 2];
     float b[KEEPB ? RP : 1];
     auto sweep = [&](int voff, const auto& mid) -> float {
@@ -252,7 +258,8 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
     auto load_col = [&](int voff) {
 #pragma unroll
         for (int k = 0; k < RP; ++k) {
-            v2[k / 2][k & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, k * ldv4, 0));
+            v2[k / 2][k & 1] = RES ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvs, voff, k * ldvs4, 0))
+                                   : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff, k * ldv4, 0));
             if constexpr (KEEPB) {   // the sparsity constant is folded in once (rows >= r: di = 0, value irrelevant)
                 b[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, voff, k * ldm4, 0)) - a.sp;
                 if constexpr (XY) b[k] *= a.dinv[2 * k];   // scaled operands (hals_sweep_column_xy)

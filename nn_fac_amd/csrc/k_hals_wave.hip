@@ -12,29 +12,47 @@
 // and a row update is      d = max(acc[k], -v[k]) ;  v[k] += d ;  acc[i] -= G'[i][k] * d  for all i      (G' = D^-1 UtU)
 // -- the reference's statement with the dot product read off the residual: v_max (all lanes, lane k's value is the step),
 // v_readlane (the step to an SGPR), v_fma (every lane pushes the step into its own residual), v_writelane (lane k keeps
-// its step): FOUR instructions per row, three of them dependent, whatever the rank.  Column k of G' comes from an LDS image
-// shared by the workgroup's waves, prefetched a block of eight rows ahead.  There are n waves instead of n/16: 2000 columns
-// = two waves on every SIMD of 250 CUs.
+// its step): FOUR vector instructions per row, three of them dependent, whatever the rank, and no scalar instruction at all
+// (the sweep is unrolled: the lane numbers are immediates).  Column k of G' comes from an LDS image shared by the
+// workgroup's waves.  There are n waves instead of n/16: 2000 columns = two waves on every SIMD of 250 CUs.
 //
-// Rounding: the residual is formed from scratch (b' - G'v) when the kernel starts and pushed forward from then on; each
-// push rounds once relative to the residual itself (which shrinks as the solve converges), not to the dot product, so the
-// carried residual is as accurate as a freshly evaluated fp32 one.  Results differ from the other layouts in
-// the last bits, like those differ from each other.
+// Rounding: the residual is formed from scratch (b' - G'v, summed in row order like the reference's dot product) when the
+// kernel starts and every 8 sweeps, and pushed forward in between; each push rounds once relative to the residual itself
+// (which shrinks as the solve converges), not to the dot product, so the carried residual is as accurate as a freshly
+// evaluated fp32 one.  Results differ from the other layouts in the last bits, like those differ from
+// each other.
 //
-// Stopping rule (nnls.py:156) on the device, no barrier anywhere in the sweep loop:
-//   * a wave's fp32 sum of squared steps (DPP) -> fp64 -> its slot of an LDS ring; the LAST wave of the workgroup to arrive
-//     for a sweep (LDS counter) adds the slots in wave order and publishes the block sum as two tagged granules (k_hals_common.h);
-//   * every wave collects the global sum of sweep s-2 after sweep s (its granule loads went out after sweep s-1, when the
-//     other workgroups had published): lag-TWO speculation -- a sweep is ~0.5 us here, shorter than an L2 round trip under
-//     load.  A snapshot of the column costs one VGPR, so the two sweeps run ahead are undone from registers.
-//   * rows with a zero Gram diagonal (nnls.py:160) and the padding rows hold residual 0 and "-v" = -inf: their step is 0.
+// Stopping rule (nnls.py:156) on the device.  A sweep takes ~0.5 us here -- a third of the round trip through the memory
+// side of the chip that a grid-wide exchange costs (the granules cross XCDs: ~1.6 us measured) -- so the compute waves never
+// wait for it:
+//   * a compute wave ends a sweep with its fp32 sum of squared steps (DPP) as a tagged fp64 in an LDS slot and a snapshot of
+//     its column in a global scratch ring (256 coalesced bytes; 16 sweeps deep), then goes on to the next sweep;
+//   * FOUR more waves per workgroup, the COMMUNICATION waves, do the exchange; wave u serves the sweeps c = u + 1 (mod 4):
+//     it adds the slots of sweep c in wave order once they are all there, publishes the block sum as two tagged granules
+//     (k_hals_common.h), then reads the granules of ALL blocks for sweep c - 4 (published a few sweeps ago: normally one
+//     round trip), adds them in block order -- the same double in every workgroup -- and leaves the total and the verdict
+//     `total >= delta * eps0` in an LDS ring.  Each of the four takes a round trip per sweep it serves; together they keep up
+//     with the sweeps.  (One wave with four requests in flight would do as well -- but in-flight registers across a loop
+//     with re-read branches are exactly what hipcc's wait-count insertion turns into "wait for everything".)
+//   * a compute wave reads the verdicts IN SWEEP ORDER, one LDS word per sweep, before it starts a sweep: it may run ahead of
+//     them by at most the depth of its snapshot ring, and at the first "stop" verdict -- sweep c -- it reloads the snapshot of
+//     sweep c and leaves.  Sweeps run ahead of a stop are discarded.
+// Nothing in a sweep depends on the exchange; every spin is bounded.  Control words travel through LDS as relaxed
+// workgroup-scope atomics (`volatile` makes hipcc drain every outstanding memory operation in front of each access).
+// Rows with a zero Gram diagonal (nnls.py:160) and the padding rows hold residual 0 and "-v" = -inf: their step is 0.
 #include "k_hals_common.h"
 
-typedef float f32x2w __attribute__((ext_vector_type(2)));
+constexpr int WAVE_COMM = 4;         // communication waves per workgroup
+constexpr int WAVE_MAX_NW = 16 - WAVE_COMM;   // compute waves (= columns) per workgroup (1024 threads in all)
+constexpr int WAVE_SNAP = 16;        // snapshot / slot / verdict rings (sweeps a compute wave may run ahead of the verdicts, + 1)
+constexpr int WAVE_NP = 6;           // granule pairs per lane of a communication wave: nblocks <= 384
+constexpr int WAVE_REFRESH = 8;      // the residual is re-formed from scratch (b' - G'v) every so many sweeps
+constexpr unsigned WAVE_ERR = 0xffffffffu;
 
-constexpr int WAVE_MAX_NW = 16;      // waves (= columns) per workgroup
-constexpr int WAVE_RING = 4;         // LDS ring of per-sweep wave partials (a wave is at most 3 sweeps ahead of another)
-constexpr int WAVE_PF = 8;           // granule pairs per lane a collect can hold: nblocks <= 512
+#ifndef WAVE_DBG
+#define WAVE_DBG 0      // timing-only ablations (tools/probes/vside_probe.py): 1 = verdicts without totals (run to the budget), 4 = no row updates
+#endif
+NNF_BUILD_FLAGS(k_hals_wave, "WAVE_DBG=" NNF_STR(WAVE_DBG))
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float wave_dpp_add_f32(float v) {
@@ -54,7 +72,8 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 
 // prep: image of G' by COLUMNS.  img[k][lane] (RL = 1) or img[k][lane] = {row lane, row lane + 64} (RL = 2):
 //   G'[i][k] = UtU[i][k] / UtU[i][i]   (0 where the diagonal is 0, outside r x r, in the padding rows k >= r)
-// read as UtU[k][i] (symmetric) so that a workgroup reads one contiguous Gram row.  Then 1/diag per row, counter, status.
+// UtU[i][k] as stored -- NOT UtU[k][i]: the reference reads rows of whatever it is handed (nnls.py:167) and its own tests pass
+// a random, non-symmetric "Gram" (tests/nnls_tests.py:44-45).  Then 1/diag per row, counter, status.
 __global__ void nnf_hals_prep_wave_kernel(const float* __restrict__ UtU, const float* __restrict__ UtU2, int64_t ldg, int r, int RL,
                                           float* __restrict__ img, float* __restrict__ dinv, unsigned* counter, double* status) {
     const int k = blockIdx.x;                   // image row = Gram column
@@ -68,7 +87,7 @@ __global__ void nnf_hals_prep_wave_kernel(const float* __restrict__ UtU, const f
         float val = 0.f;
         if (k < r && i < r) {
             const float d = gram(i, i);
-            if (d != 0.f) val = gram(k, i) * (float)(1.0 / (double)d);
+            if (d != 0.f) val = gram(i, k) * (float)(1.0 / (double)d);
         }
         img[(size_t)k * W + c] = val;
     }
@@ -90,275 +109,424 @@ __global__ void nnf_hals_prep_wave_kernel(const float* __restrict__ UtU, const f
     }
 }
 
-struct wave_prefetch {
-    unsigned long long g0[WAVE_PF], g1[WAVE_PF];
-    int s;
+// LDS control block behind the image.  Every word that crosses waves carries the sweep number it belongs to.
+struct wave_ctl {
+    unsigned long long slot[WAVE_SNAP][WAVE_MAX_NW][2];   // tagged halves {sweep, lo32} {sweep, hi32} of a compute wave's fp64 sum
+    unsigned long long tot[WAVE_SNAP][2];                 // the same for the global sum of a sweep
+    unsigned long long ver[WAVE_SNAP];                    // verdict {sweep : 32 | 1 = stop, 2 = time-out : 32}, written after tot
+    unsigned long long eps0[2];                           // tagged halves (tag 1) of the global sum of sweep 1
+    unsigned long long fin;                               // {1 : 32 | stopping sweep : 32} once a compute wave has found it
 };
-__device__ __forceinline__ void wave_collect_issue(const hals_sync& sy, int s, int nblocks, int lane, wave_prefetch& pf) {
-    const unsigned long long* base = reinterpret_cast<const unsigned long long*>(sy.sslots) + (size_t)s * nblocks * 2;
-    pf.s = s;
+
+// Words of the control block are exchanged between waves of the workgroup with RELAXED workgroup-scope atomics: plain LDS
+// reads / writes that the compiler neither caches in registers nor hoists out of a polling loop.  (`volatile` accesses made
+// hipcc drain EVERY outstanding memory operation first -- s_waitcnt vmcnt(0) in front of each poll, i.e. the round trip of the
+// snapshot store of the sweep before, 0.65 us per sweep.)
+__device__ __forceinline__ unsigned long long wave_ld(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void wave_st(unsigned long long* p, unsigned long long x) {
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void wave_st_tagged(unsigned long long* p2, unsigned tagv, double x) {
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, x), tag = (unsigned long long)tagv << 32;
+    wave_st(p2, tag | (bits & 0xffffffffull));
+    wave_st(p2 + 1, tag | (bits >> 32));
+}
+// false while either half does not carry `tagv` yet
+__device__ __forceinline__ bool wave_ld_tagged(const unsigned long long* p2, unsigned tagv, double& x) {
+    const unsigned long long h0 = wave_ld(p2), h1 = wave_ld(p2 + 1);
+    x = __builtin_bit_cast(double, (h1 << 32) | (h0 & 0xffffffffull));
+    return (unsigned)(h0 >> 32) == tagv && (unsigned)(h1 >> 32) == tagv;
+}
+
+// row update K (compile-time: every operand position is an immediate) of the CPW columns a wave holds -- the columns'
+// chains are independent, so a wave with two columns fills the latency of one chain with the other
+template <int RL, int CPW, int K>
+__device__ __forceinline__ void wave_row(const float* img, float (&acc)[CPW][RL], const float (&nvd)[CPW][RL], float (&dk)[CPW][RL]) {
+    constexpr int H = K >> 6, KL = K & 63, W = 64 * RL;
+    float g[RL];
 #pragma unroll
-    for (int i = 0; i < WAVE_PF; ++i) {
-        const int b = lane + 64 * i;
-        pf.g0[i] = pf.g1[i] = 0ull;
-        if (b < nblocks) {
-            pf.g0[i] = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pf.g1[i] = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    for (int h = 0; h < RL; ++h) g[h] = img[K * W + h];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        float d;   // max(acc, -v) in one instruction (fmaxf adds a canonicalising max); lane KL's value is the step of row K
+        asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(acc[c][H]), "v"(nvd[c][H]));
+        const float sd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), KL));
+#pragma unroll
+        for (int h = 0; h < RL; ++h) acc[c][h] = fmaf(g[h], -sd, acc[c][h]);
+        // lane KL keeps its step (v_writelane: SGPR data, immediate lane select; this clang has no builtin for it)
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(dk[c][H]) : "s"(sd), "n"(KL));
     }
 }
-// global sum of sweep s: granules strided over the lanes (prefetched copies first, bounded re-reads for late ones), added in
-// index order per lane, DPP wave sum -- the same double in every wave of every workgroup.  false = time-out (wave-uniform).
-__device__ __forceinline__ bool wave_collect(const hals_sync& sy, int s, int nblocks, int lane, double& total, const wave_prefetch& pf) {
+template <int RL, int CPW, int K, int RU>
+struct wave_rows {
+    static __device__ __forceinline__ void run(const float* img, float (&acc)[CPW][RL], const float (&nvd)[CPW][RL], float (&dk)[CPW][RL]) {
+        wave_row<RL, CPW, K>(img, acc, nvd, dk);
+        if constexpr (K + 1 < RU) wave_rows<RL, CPW, K + 1, RU>::run(img, acc, nvd, dk);
+    }
+};
+
+// fixed-order fp64 sum of lanes 0 .. 15 of `v` (other lanes must hold 0), wave-uniform
+__device__ __forceinline__ double wave_sum16_f64(double v) {
+    v = nnf_dpp_add_f64<0xB1, 0xf>(v);
+    v = nnf_dpp_add_f64<0x4E, 0xf>(v);
+    v = nnf_dpp_add_f64<0x141, 0xf>(v);
+    v = nnf_dpp_add_f64<0x140, 0xf>(v);
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 0);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 0);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+
+// global sum of sweep s: the granules of all blocks, strided over the lanes (late ones are re-read, bounded), added in block
+// order per lane, DPP wave sum -- the same double in every workgroup.  false = time-out or `fin` set (wave-uniform).
+__device__ __forceinline__ bool wave_total(const hals_sync& sy, const wave_ctl* ctl, int s, int nblocks, int lane, double& total) {
     const unsigned tag = sy.epoch * 1024u + (unsigned)s;
     const unsigned long long* base = reinterpret_cast<const unsigned long long*>(sy.sslots) + (size_t)s * nblocks * 2;
-    double v = 0.0;
-    bool late = false;
+    unsigned long long g0[WAVE_NP], g1[WAVE_NP];
+    // every request of the wave goes out before the first answer is looked at: no load under a branch (lanes past the last
+    // block re-read block 0 and ignore it) -- one round trip for the lot, not one per pair
 #pragma unroll
-    for (int i = 0; i < WAVE_PF; ++i) {
-        const int b = lane + 64 * i;
-        if (b < nblocks) {
-            unsigned long long g0 = (pf.s == s) ? pf.g0[i] : 0ull, g1 = (pf.s == s) ? pf.g1[i] : 0ull;
+    for (int i = 0; i < WAVE_NP; ++i) {
+        const int b = lane + 64 * i < nblocks ? lane + 64 * i : 0;
+        g0[i] = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g1[i] = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool fresh = true;
+#pragma unroll
+    for (int i = 0; i < WAVE_NP; ++i) fresh = fresh && (unsigned)(g0[i] >> 32) == tag && (unsigned)(g1[i] >> 32) == tag;
+    bool late = false;
+    if (__ballot(!fresh) != 0ull) {                       // somebody's granule is not there yet: re-read (rare, bounded)
+#pragma unroll 1
+        for (int i = 0; i < WAVE_NP; ++i) {
+            const int b = lane + 64 * i < nblocks ? lane + 64 * i : 0;
+            unsigned long long a0 = g0[0], a1 = g1[0];
+#pragma unroll
+            for (int u = 0; u < WAVE_NP; ++u)
+                if (u == i) { a0 = g0[u]; a1 = g1[u]; }
             unsigned spins = 0;
-            while (!((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag)) {
-                if (spins > 0) __builtin_amdgcn_s_sleep(1);
-                if (++spins > HALS_SPIN_LIMIT) { late = true; break; }
-                g0 = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                g1 = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (!((unsigned)(a0 >> 32) == tag && (unsigned)(a1 >> 32) == tag)) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > HALS_SPIN_LIMIT || ((spins & 63u) == 0u && wave_ld(&ctl->fin) != 0ull)) { late = true; break; }
+                a0 = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a1 = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            v += __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xffffffffull));
+#pragma unroll
+            for (int u = 0; u < WAVE_NP; ++u)
+                if (u == i) { g0[u] = a0; g1[u] = a1; }
         }
     }
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < WAVE_NP; ++i)
+        v += (lane + 64 * i < nblocks) ? __builtin_bit_cast(double, (g1[i] << 32) | (g0[i] & 0xffffffffull)) : 0.0;
     total = nnf_wave_sum_f64(v);
     return __ballot(late) == 0ull;
 }
 
-// eight row updates k = kb .. kb+7, all in the half H of the rows (H = 0: rows 0..63, lane = row; H = 1: rows 64..127)
-template <int RL, int H>
-__device__ __forceinline__ void wave_rows8(const float (&g)[8][RL], int kb, float (&acc)[RL], const float (&nvd)[RL], float (&dk)[RL]) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int kl = (kb + u) & 63;
-        float d;   // max(acc, -v) in one instruction (fmaxf adds a canonicalising max); lane kl's value is the step of row k
-        asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(acc[H]), "v"(nvd[H]));
-        const float sd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), kl));
-#pragma unroll
-        for (int h = 0; h < RL; ++h) acc[h] = fmaf(g[u][h], -sd, acc[h]);
-        dk[H] = __builtin_bit_cast(float, __builtin_amdgcn_writelane(__builtin_bit_cast(int, sd), kl, __builtin_bit_cast(int, dk[H])));
+// ---- a communication wave: serves the sweeps c = u + 1, u + 1 + WAVE_COMM, ... ---------------------------------------------
+// block sum of sweep c: waits (bounded) until every compute wave has left its tagged sum; false: time-out or the solve is over
+__device__ __forceinline__ bool wave_block_sum(wave_ctl* ctl, int c, int NW, int lane, double& bs) {
+    const int sl = c & (WAVE_SNAP - 1);
+    unsigned spins = 0;
+    double v = 0.0;
+    for (;;) {
+        double x = 0.0;
+        const bool have = lane >= NW || wave_ld_tagged(&ctl->slot[sl][lane < NW ? lane : 0][0], (unsigned)c, x);
+        if (__ballot(!have) == 0ull) {
+            v = lane < NW ? x : 0.0;
+            break;
+        }
+        if (wave_ld(&ctl->fin) != 0ull) return false;     // the compute waves have left: the slots of this sweep will never come
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > HALS_SPIN_LIMIT) return false;
+    }
+    bs = wave_sum16_f64(v);
+    return true;
+}
+__device__ __forceinline__ void wave_publish(const hals_sync& sy, int s, int nblocks, int lane, double mine) {
+    if (lane == 0) {
+        const unsigned long long bits = __builtin_bit_cast(unsigned long long, mine);
+        const unsigned long long tag = (unsigned long long)(sy.epoch * 1024u + (unsigned)s) << 32;
+        unsigned long long* g = reinterpret_cast<unsigned long long*>(sy.sslots) + ((size_t)s * nblocks + blockIdx.x) * 2;
+        __hip_atomic_store(g, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-
-template <int RL>
-__global__ __launch_bounds__(64 * WAVE_MAX_NW) void nnf_hals_wave_kernel(hals_args a, int RU) {
-    extern __shared__ __attribute__((aligned(16))) float wlds[];
-    // LDS: image RU x (64 RL) floats | ring of wave partials WAVE_RING x NW doubles | arrival counters WAVE_RING
-    const int W = 64 * RL;
-    const int NW = blockDim.x >> 6;
-    double* part = reinterpret_cast<double*>(wlds + (size_t)RU * W);
-    unsigned* arrive = reinterpret_cast<unsigned*>(part + WAVE_RING * WAVE_MAX_NW);
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nblocks = gridDim.x;
-    const int64_t col = (int64_t)blockIdx.x * NW + w;
-    const bool valid = col < a.ncols;
-    for (int e = threadIdx.x; e < RU * W / 4; e += blockDim.x)
-        reinterpret_cast<f32x4*>(wlds)[e] = reinterpret_cast<const f32x4*>(a.Gp)[e];
-    if (threadIdx.x < WAVE_RING) arrive[threadIdx.x] = 0u;
-
-    // this lane's rows: lane (and lane + 64); start values from a.Vsrc (== a.V for an in-place solve)
-    float v[RL], acc[RL], nvd[RL], dk[RL], v1[RL], v2[RL];
-    bool dead[RL];
-#pragma unroll
-    for (int h = 0; h < RL; ++h) {
-        const int row = lane + 64 * h;
-        const bool in = valid && row < a.r;
-        const float di = a.dinv[row];                     // 0: zero diagonal or padding row (128 entries are always there)
-        dead[h] = !(in && di != 0.f);
-        v[h] = in ? a.Vsrc[(int64_t)row * a.ldvs + col] : 0.f;
-        const float bm = in ? a.UtM[(int64_t)row * a.ldm + col] : 0.f;
-        acc[h] = dead[h] ? 0.f : (bm - a.sp) * di;
-        nvd[h] = dead[h] ? -__builtin_inff() : -v[h];
-        v1[h] = v2[h] = v[h];
-    }
-    __syncthreads();                                      // the only barrier: the image is in LDS
-    const float* img = wlds + (RL == 2 ? 2 * lane : lane);
-    // residual from scratch: acc = b' - G' v   (columns of G' one by one, v[j] through an SGPR)
-    for (int jb = 0; jb < RU; jb += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = jb + u;
-            const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (RL == 2 && j >= 64) ? v[RL - 1] : v[0]), j & 63));
-#pragma unroll
-            for (int h = 0; h < RL; ++h) acc[h] = fmaf(img[(size_t)j * W + h], -vj, acc[h]);
-        }
-    }
-
-    double eps0 = 0.0, eps = 1.0;
-    int done = 0;
-    bool ok = true, stopped = false;
-    wave_prefetch pf;
-    pf.s = 0;
-    // first block of image columns (the pipeline then runs across sweeps: the image is the same every sweep)
-    float g[2][8][RL];
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int h = 0; h < RL; ++h) g[0][u][h] = img[(size_t)u * W + h];
-
-    auto decide = [&](int c, double tot) {       // nnls.py:156 after sweep c; true = sweep c was the last one
-        if (c == 1) eps0 = tot;
-        eps = tot;
-        done = c;
-        return !(eps >= a.delta * eps0);
-    };
-
-    for (int s = 1; s <= a.max_sweeps; ++s) {
-#pragma unroll
-        for (int h = 0; h < RL; ++h) dk[h] = 0.f;
-        for (int kb = 0; kb < RU; kb += 16) {    // two blocks of eight rows per trip: the two register sets alternate statically
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int k0 = kb + 8 * half;
-                if (k0 < RU) {
-                    int kn = k0 + 8;             // the block after this one (wraps to the next sweep's first block)
-                    if (kn >= RU) kn = 0;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-#pragma unroll
-                        for (int h = 0; h < RL; ++h) g[half ^ 1][u][h] = img[(size_t)(kn + u) * W + h];
-                    if (RL == 2 && k0 >= 64) wave_rows8<RL, RL - 1>(g[half], k0, acc, nvd, dk);
-                    else wave_rows8<RL, 0>(g[half], k0, acc, nvd, dk);
-                } else {
-                    // RU is an odd number of blocks: this half-trip does not exist; keep the register sets in step
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-#pragma unroll
-                        for (int h = 0; h < RL; ++h) g[half ^ 1][u][h] = g[half][u][h];
+// total + verdict of sweep cd into the rings (nnls.py:156: the loop goes on while eps >= delta * eps0).  false: give up.
+__device__ __forceinline__ bool wave_judge(const hals_args& a, wave_ctl* ctl, int cd, int nblocks, int lane) {
+    double tot = 0.0;
+    unsigned flag = 0u;
+    if (!(WAVE_DBG & 1)) {
+        if (!wave_total(a.sy, ctl, cd, nblocks, lane, tot)) {
+            if (wave_ld(&ctl->fin) != 0ull) return false;
+            flag = 2u;                                    // time-out
+        } else {
+            double e0 = tot;
+            if (cd == 1) {
+                if (lane == 0) wave_st_tagged(&ctl->eps0[0], 1u, tot);
+            } else {                                      // eps0 comes from the wave that serves sweep 1 (bounded wait)
+                unsigned spins = 0;
+                while (!wave_ld_tagged(&ctl->eps0[0], 1u, e0)) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > HALS_SPIN_LIMIT || wave_ld(&ctl->fin) != 0ull) return false;
                 }
             }
+            flag = (tot >= a.delta * e0) ? 0u : 1u;
         }
-        // end of sweep s: apply the steps, this column's sum of squared steps
-        float f = 0.f;
-#pragma unroll
-        for (int h = 0; h < RL; ++h) {
-            v2[h] = v1[h];
-            v1[h] = v[h];                                 // v1 = V after sweep s-1, v2 = after s-2
-            v[h] += dk[h];
-            nvd[h] = dead[h] ? -__builtin_inff() : -v[h];
-            f = fmaf(dk[h], dk[h], f);
-        }
-        const double wsum = (double)wave_sum_f32(f);
-        // workgroup partial: slot, arrival count; the last wave to arrive adds the slots in wave order and publishes
-        const int slot = s & (WAVE_RING - 1);
-        if (lane == 0) {
-            part[slot * WAVE_MAX_NW + w] = wsum;
-            __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the slot is written before the arrival is counted
-            const unsigned prev = __hip_atomic_fetch_add(&arrive[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (prev == (unsigned)NW - 1u) {
-                double bs = 0.0;
-                for (int i = 0; i < NW; ++i) bs += part[slot * WAVE_MAX_NW + i];
-                arrive[slot] = 0u;
-                const unsigned long long bits = __builtin_bit_cast(unsigned long long, bs);
-                const unsigned long long tag = (unsigned long long)(a.sy.epoch * 1024u + (unsigned)s) << 32;
-                unsigned long long* gq = reinterpret_cast<unsigned long long*>(a.sy.sslots) + ((size_t)s * nblocks + blockIdx.x) * 2;
-                __hip_atomic_store(gq, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gq + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // lag two: the sum of sweep s-2 (granules requested after sweep s-1) is examined now
-        const int c = s - 2;
-        if (c >= 1) {
-            double tot;
-            ok = wave_collect(a.sy, c, nblocks, lane, tot, pf);
-            if (!ok) break;
-            if (decide(c, tot)) { stopped = true; break; }
-        }
-        if (s >= 2 && s < a.max_sweeps) wave_collect_issue(a.sy, s - 1, nblocks, lane, pf);
     }
-    // result: V after sweep `done` once the loop has decided; the budget ran out with one or two sweeps still undecided
-    int have = a.max_sweeps;                              // sweeps the registers hold (v), v1 = have-1, v2 = have-2
-    if (stopped) {
-        // decided at the end of sweep done + 2
-#pragma unroll
-        for (int h = 0; h < RL; ++h) v[h] = v2[h];
-    } else if (ok && a.max_sweeps >= 1) {
-        for (int c = (a.max_sweeps >= 2 ? a.max_sweeps - 1 : 1); c <= a.max_sweeps; ++c) {
-            double tot;
-            wave_prefetch none;
-            none.s = 0;
-            ok = wave_collect(a.sy, c, nblocks, lane, tot, none);
-            if (!ok) break;
-            if (decide(c, tot) && c < have) {             // sweep have-1 was the last one: drop the sweep run ahead
-#pragma unroll
-                for (int h = 0; h < RL; ++h) v[h] = v1[h];
-                break;
-            }
-        }
-    } else if (!ok) {
-        // time-out: report the last confirmed sweep's column (two sweeps back at most)
-#pragma unroll
-        for (int h = 0; h < RL; ++h) v[h] = v2[h];
+    if (lane == 0) {
+        const int sl = cd & (WAVE_SNAP - 1);
+        wave_st_tagged(&ctl->tot[sl][0], (unsigned)cd, tot);
+        wave_st(&ctl->ver[sl], ((unsigned long long)(unsigned)cd << 32) | (unsigned long long)flag);   // after tot: LDS keeps a wave's order
     }
-    if (a.max_sweeps >= 1) {
+    return flag == 0u;
+}
+__device__ __forceinline__ void wave_comm_loop(const hals_args& a, wave_ctl* ctl, int NW, int u, int lane, int nblocks) {
+    const int S = a.max_sweeps;
+    int c = u + 1;
+    for (; c <= S; c += WAVE_COMM) {
+        double bs;
+        if (!wave_block_sum(ctl, c, NW, lane, bs)) return;
+        wave_publish(a.sy, c, nblocks, lane, bs);
+        const int cd = c - WAVE_COMM;                     // published by everybody a few sweeps ago
+        if (cd >= 1 && !wave_judge(a, ctl, cd, nblocks, lane)) return;
+    }
+    // the last sweep this wave served has not been judged yet
+    const int cd = c - WAVE_COMM;
+    if (cd >= 1 && cd <= S) (void)wave_judge(a, ctl, cd, nblocks, lane);
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------------------------
+// a.Gp: image (prep kernel), a.dinv: 128 floats.  snap: global scratch [ncols][WAVE_SNAP][64 RL] floats.
+// CPW: columns per compute wave (2 when one column per wave would need more workgroups than the chip holds at once).
+template <int RL, int RU, int CPW>
+__global__ __launch_bounds__(1024) void nnf_hals_wave_kernel(hals_args a, float* __restrict__ snap) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    constexpr int W = 64 * RL;
+    wave_ctl* ctl = reinterpret_cast<wave_ctl*>(wlds + (size_t)RU * W);
+    const int NW = (blockDim.x >> 6) - WAVE_COMM;         // compute waves; waves NW .. NW+3 are the communication waves
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nblocks = gridDim.x;
+    for (int e = threadIdx.x; e < RU * W / 4; e += blockDim.x)
+        reinterpret_cast<f32x4*>(wlds)[e] = reinterpret_cast<const f32x4*>(a.Gp)[e];
+    for (int e = threadIdx.x; e < (int)(sizeof(wave_ctl) / 8); e += blockDim.x)
+        reinterpret_cast<unsigned long long*>(ctl)[e] = 0ull;
+    __syncthreads();                                      // the only barrier: image and control block are in LDS
+    if (w >= NW) {
+        wave_comm_loop(a, ctl, NW, w - NW, lane, nblocks);
+        return;
+    }
+    const int64_t col0 = ((int64_t)blockIdx.x * NW + w) * CPW;
+    // this lane's rows: lane (and lane + 64) of each column; start values from a.Vsrc (== a.V for an in-place solve)
+    float v[CPW][RL], acc[CPW][RL], nvd[CPW][RL], dk[CPW][RL], bs[CPW][RL];
+    bool dead[CPW][RL];
+    float* mysnap[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int64_t col = col0 + c;
+        const bool valid = col < a.ncols;
 #pragma unroll
         for (int h = 0; h < RL; ++h) {
             const int row = lane + 64 * h;
-            if (valid && row < a.r) a.V[(int64_t)row * a.ldv + col] = v[h];
+            const bool in = valid && row < a.r;
+            const float di = a.dinv[row];                 // 0: zero diagonal or padding row (128 entries are always there)
+            dead[c][h] = !(in && di != 0.f);
+            v[c][h] = in ? a.Vsrc[(int64_t)row * a.ldvs + col] : 0.f;
+            const float bm = in ? a.UtM[(int64_t)row * a.ldm + col] : 0.f;
+            bs[c][h] = dead[c][h] ? 0.f : (bm - a.sp) * di;
+            nvd[c][h] = dead[c][h] ? -__builtin_inff() : -v[c][h];
+            acc[c][h] = 0.f;
+        }
+        mysnap[c] = snap + ((size_t)(valid ? col : 0) * WAVE_SNAP) * W + (RL == 2 ? 2 * lane : lane);
+    }
+    const bool valid0 = col0 < a.ncols;                   // (a wave whose first column is past the end has nothing to sweep)
+    const float* img = wlds + (RL == 2 ? 2 * lane : lane);
+    // residual from scratch: acc = b' - G' v   (columns of G' one by one in row order -- the order of the reference's dot
+    // product --, v[j] through an SGPR).  At the start, and again every WAVE_REFRESH sweeps: the pushes in between carry it
+    // forward exactly up to one rounding each, and the refresh keeps those roundings from adding up over a long solve.
+    auto refresh = [&]() {
+#pragma unroll
+        for (int c = 0; c < CPW; ++c)
+#pragma unroll
+            for (int h = 0; h < RL; ++h) acc[c][h] = bs[c][h];
+#pragma unroll
+        for (int j = 0; j < RU; ++j) {
+            float g[RL];
+#pragma unroll
+            for (int h = 0; h < RL; ++h) g[h] = img[j * W + h];
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[c][j >> 6]), j & 63));
+#pragma unroll
+                for (int h = 0; h < RL; ++h) acc[c][h] = fmaf(g[h], -vj, acc[c][h]);
+            }
+        }
+    };
+    if (valid0) refresh();
+    const int S = a.max_sweeps;
+    int judged = 0;                                       // verdicts read so far: sweeps 1 .. judged go on
+    unsigned stop = 0u;                                   // the stopping sweep once its verdict has been read; WAVE_ERR
+    // Verdicts are read IN SWEEP ORDER.  The sweep loop looks at ONE ring word per sweep (verdicts arrive at the rate of the
+    // sweeps, a few sweeps late: that keeps pace) and only when it would otherwise overrun the ring does it wait.
+    auto take = [&](unsigned long long x) -> bool {       // x: the ring word of sweep judged + 1; true = it was that sweep's verdict
+        if ((int)(unsigned)(x >> 32) != judged + 1) return false;
+        ++judged;
+        const unsigned fl = (unsigned)x;
+        if (fl != 0u) stop = (fl == 1u) ? (unsigned)judged : WAVE_ERR;
+        return true;
+    };
+    auto wait_verdicts = [&](int need) {                  // rare path: until sweep `need` is judged (bounded)
+        unsigned spins = 0;
+        while (stop == 0u && judged < need) {
+            if (take(wave_ld(&ctl->ver[(judged + 1) & (WAVE_SNAP - 1)]))) { spins = 0; continue; }
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > HALS_SPIN_LIMIT) stop = WAVE_ERR;
+        }
+    };
+    int ran = 0;                                          // sweeps this wave has run
+    for (int s = 1; s <= S; ++s) {
+        // the slot / snapshot of sweep s reuses those of sweep s - WAVE_SNAP: that sweep must have been judged (and go on)
+        (void)take(wave_ld(&ctl->ver[(judged + 1) & (WAVE_SNAP - 1)]));
+        if (__builtin_expect(judged < s - WAVE_SNAP + 1, 0)) wait_verdicts(s - WAVE_SNAP + 1);
+        if (stop != 0u) break;
+#pragma unroll
+        for (int c = 0; c < CPW; ++c)
+#pragma unroll
+            for (int h = 0; h < RL; ++h) dk[c][h] = 0.f;
+        if (valid0 && s > 1 && ((s - 1) & (WAVE_REFRESH - 1)) == 0) refresh();
+        if (valid0 && !(WAVE_DBG & 4)) wave_rows<RL, CPW, 0, RU>::run(img, acc, nvd, dk);
+        float f = 0.f;
+        const int sl = s & (WAVE_SNAP - 1);
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+#pragma unroll
+            for (int h = 0; h < RL; ++h) {
+                v[c][h] += dk[c][h];
+                nvd[c][h] = dead[c][h] ? -__builtin_inff() : -v[c][h];
+                f = fmaf(dk[c][h], dk[c][h], f);
+            }
+            if (col0 + c < a.ncols) {                     // V after sweep s: coalesced, fire and forget (read back by this wave only)
+#pragma unroll
+                for (int h = 0; h < RL; ++h) mysnap[c][(size_t)sl * W + h] = v[c][h];
+            }
+        }
+        const double wsum = (double)wave_sum_f32(f);
+        if (lane == 0) wave_st_tagged(&ctl->slot[sl][w][0], (unsigned)s, wsum);
+        ran = s;
+    }
+    if (stop == 0u && S >= 1) wait_verdicts(S);           // the budget ran out: every sweep must be judged
+    const unsigned last = stop != 0u ? stop : (unsigned)S;    // the sweep whose column is the result
+    if (w == 0 && lane == 0) wave_st(&ctl->fin, (1ull << 32) | (unsigned long long)last);     // (communication waves may leave)
+    if (S >= 1) {
+        if (last != WAVE_ERR && (int)last != ran) __builtin_amdgcn_s_waitcnt(0);   // (own snapshot stores have landed before they are read back)
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int64_t col = col0 + c;
+            if (col < a.ncols) {
+                if (last != WAVE_ERR && (int)last != ran) {   // sweeps run ahead of the stop are dropped
+                    const int sl = (int)last & (WAVE_SNAP - 1);
+#pragma unroll
+                    for (int h = 0; h < RL; ++h) v[c][h] = __builtin_nontemporal_load(&mysnap[c][(size_t)sl * W + h]);
+                }
+#pragma unroll
+                for (int h = 0; h < RL; ++h) {
+                    const int row = lane + 64 * h;
+                    if (row < a.r) a.V[(int64_t)row * a.ldv + col] = v[c][h];
+                }
+            }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (a.max_sweeps >= 1) {
+    if (blockIdx.x == 0 && w == 0 && lane == 0) {
+        if (S >= 1 && last != WAVE_ERR) {
+            double eps = 1.0, eps0 = 0.0;
+            (void)wave_ld_tagged(&ctl->tot[(int)last & (WAVE_SNAP - 1)][0], last, eps);
+            (void)wave_ld_tagged(&ctl->eps0[0], 1u, eps0);
+            if (last == 1u) eps0 = eps;
+            if (WAVE_DBG & 1) { eps = 1.0; eps0 = 0.0; }
             a.status[NNF_HALS_ST_EPS] = eps;
-            a.status[NNF_HALS_ST_CNT] = (double)(done + 1);
+            a.status[NNF_HALS_ST_CNT] = (double)(last + 1u);
             a.status[NNF_HALS_ST_EPS0] = eps0;
         }
-        if (!ok) a.status[NNF_HALS_ST_ERR] = 1.0;
+        if (last == WAVE_ERR) a.status[NNF_HALS_ST_ERR] = 1.0;
     }
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
 static int wave_ru(int r) { return (r + 7) & ~7; }
 static int wave_rl(int r) { return r <= 64 ? 1 : 2; }
-static size_t wave_lds(int r) {
-    return (size_t)wave_ru(r) * 64 * wave_rl(r) * 4 + (size_t)WAVE_RING * WAVE_MAX_NW * 8 + WAVE_RING * 4 + 16;
-}
-static int wave_nw(int64_t ncols) {      // waves per workgroup: ~one workgroup per CU, 2 .. 16 columns each
-    int nw = 2;
-    while (nw < WAVE_MAX_NW && ncols > (int64_t)256 * nw) nw *= 2;
+static size_t wave_lds(int r) { return (size_t)wave_ru(r) * 64 * wave_rl(r) * 4 + sizeof(wave_ctl) + 16; }
+static int wave_nw(int64_t ncols) {      // compute waves per workgroup: about one workgroup per CU
+    int nw = (int)nnf_cdiv(ncols, 256);
+    if (nw < 1) nw = 1;
+    if (nw > WAVE_MAX_NW) nw = WAVE_MAX_NW;
     return nw;
 }
 
 size_t nnf_hals_wave_gram_floats(int r) { return (size_t)wave_ru(r) * 64 * wave_rl(r) + 128; }
+size_t nnf_hals_wave_snap_floats(int r, int64_t ncols) { return (size_t)ncols * WAVE_SNAP * 64 * wave_rl(r); }
 
-// all workgroups of the persistent kernel must be co-resident
-bool nnf_hals_wave_fits(nnf_ctx* ctx, int r, int64_t ncols, int max_blocks_cap) {
-    if (r < 1 || r > 128 || ncols < 1 || ncols > 8192) return false;
-    const int nw = wave_nw(ncols);
-    const int64_t need = nnf_cdiv(ncols, nw);
-    if (need > 64 * WAVE_PF || need > max_blocks_cap) return false;
-    static int cached[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};     // [RL-1][log2 nw]
-    int lg = 0;
-    while ((1 << lg) < nw) ++lg;
-    const int rl = wave_rl(r);
-    // (occupancy depends on the LDS size, i.e. on r: query with this r's size, cache the worst case per (RL, nw) conservatively)
-    int nb = 0;
-    const size_t lds = wave_lds(r);
-    hipError_t e;
-    if (rl == 1) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_wave_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_wave_kernel<1>, 64 * nw, lds);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_wave_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_wave_kernel<2>, 64 * nw, lds);
+template <int RL, int RU, int CPW>
+static int wave_launch(const hals_args& a, float* snap, int nblocks, int nw, size_t lds, hipStream_t st, int* occupancy) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_wave_kernel<RL, RU, CPW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr = true;
     }
-    (void)cached;
-    if (e != hipSuccess || nb < 1) return false;
-    const int b = nb >= 3 ? nb - 1 : nb;                  // margin: the occupancy API can over-report by one block per CU
-    return need <= (int64_t)b * ctx->num_cus;
+    if (occupancy) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_wave_kernel<RL, RU, CPW>, 64 * (nw + WAVE_COMM), lds) != hipSuccess)
+            nb = 0;
+        *occupancy = nb;
+        return NNF_OK;
+    }
+    hipLaunchKernelGGL((nnf_hals_wave_kernel<RL, RU, CPW>), dim3(nblocks), dim3(64 * (nw + WAVE_COMM)), lds, st, a, snap);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+static int wave_dispatch(int r, int cpw, const hals_args& a, float* snap, int nblocks, int nw, hipStream_t st, int* occupancy) {
+    const size_t lds = wave_lds(r);
+    switch (wave_ru(r)) {
+#define WAVE_CASE(N)                                                                                               \
+    case N:                                                                                                        \
+        return cpw == 1 ? wave_launch<(N <= 64 ? 1 : 2), N, 1>(a, snap, nblocks, nw, lds, st, occupancy)           \
+                        : wave_launch<(N <= 64 ? 1 : 2), N, 2>(a, snap, nblocks, nw, lds, st, occupancy);
+        WAVE_CASE(8) WAVE_CASE(16) WAVE_CASE(24) WAVE_CASE(32) WAVE_CASE(40) WAVE_CASE(48) WAVE_CASE(56) WAVE_CASE(64)
+        WAVE_CASE(72) WAVE_CASE(80) WAVE_CASE(88) WAVE_CASE(96) WAVE_CASE(104) WAVE_CASE(112) WAVE_CASE(120) WAVE_CASE(128)
+#undef WAVE_CASE
+        default: return NNF_ERR_UNSUPPORTED;
+    }
 }
 
-// Gw: workspace of nnf_hals_wave_gram_floats(r) floats.  Solve mode only (a.mode == 0, a.sweep0 == 0).
-int nnf_hals_wave_run(nnf_ctx* ctx, const float* UtU, const float* UtU2, int64_t ldg, float* Gw, unsigned* counter, hals_args a,
-                      int* nblocks_out, hipStream_t st) {
+// Columns per compute wave with which every workgroup of the persistent kernel is co-resident (1, or 2 when one column per
+// wave would take more workgroups than the chip holds at once: 4000 columns at rank 100); 0: this layout does not fit.
+static int wave_plan(nnf_ctx* ctx, int r, int64_t ncols, int max_blocks_cap) {
+    if (r < 1 || r > 128 || ncols < 1) return 0;
+    const int nw = wave_nw(ncols);
+    const char* pin = getenv("NNF_WAVE_CPW");             // measurement knob (tools/probes/vside_probe.py): start at 2 columns per wave
+    for (int cpw = (pin && pin[0] == '2') ? 2 : 1; cpw <= 2; ++cpw) {
+        const int64_t need = nnf_cdiv(ncols, (int64_t)nw * cpw);
+        if (need > 64 * WAVE_NP || need > max_blocks_cap) continue;
+        int nb = 0;
+        hals_args dummy{};
+        const int rc = wave_dispatch(r, cpw, dummy, nullptr, 0, nw, nullptr, &nb);
+        if (getenv("NNF_HALS_DEBUG"))
+            fprintf(stderr, "[nnf hals wave] r=%d ncols=%lld nw=%d cpw=%d need=%lld occupancy=%d rc=%d lds=%zu\n", r, (long long)ncols,
+                    nw, cpw, (long long)need, nb, rc, wave_lds(r));
+        if (rc != NNF_OK || nb < 1) return 0;
+        const int b = nb >= 3 ? nb - 1 : nb;              // margin: the occupancy API can over-report by one block per CU
+        if (need <= (int64_t)b * ctx->num_cus) return cpw;
+    }
+    return 0;
+}
+bool nnf_hals_wave_fits(nnf_ctx* ctx, int r, int64_t ncols, int max_blocks_cap) { return wave_plan(ctx, r, ncols, max_blocks_cap) > 0; }
+
+// Gw: workspace of nnf_hals_wave_gram_floats(r) floats, snap: nnf_hals_wave_snap_floats(r, ncols) floats.
+// Solve mode only (a.mode == 0, a.sweep0 == 0).
+int nnf_hals_wave_run(nnf_ctx* ctx, const float* UtU, const float* UtU2, int64_t ldg, float* Gw, float* snap, unsigned* counter,
+                      hals_args a, int* nblocks_out, hipStream_t st) {
     const int ru = wave_ru(a.r), rl = wave_rl(a.r);
     float* dinv = Gw + (size_t)ru * 64 * rl;
     hipLaunchKernelGGL(nnf_hals_prep_wave_kernel, dim3(ru), dim3(64), 0, st, UtU, UtU2, ldg, a.r, rl, Gw, dinv, counter, a.status);
@@ -371,13 +539,13 @@ int nnf_hals_wave_run(nnf_ctx* ctx, const float* UtU, const float* UtU2, int64_t
     }
     a.Gp = Gw;
     a.dinv = dinv;
+    const int cpw = wave_plan(ctx, a.r, a.ncols, NNF_HALS_MAX_BLOCKS);
+    if (cpw < 1) return NNF_ERR_UNSUPPORTED;
     const int nw = wave_nw(a.ncols);
-    const int nblocks = (int)nnf_cdiv(a.ncols, nw);
+    const int nblocks = (int)nnf_cdiv(a.ncols, (int64_t)nw * cpw);
     *nblocks_out = nblocks;
     nnf_probe(ctx, NNF_PROBE_HALS, 0, st);
-    if (rl == 1) hipLaunchKernelGGL((nnf_hals_wave_kernel<1>), dim3(nblocks), dim3(64 * nw), wave_lds(a.r), st, a, ru);
-    else hipLaunchKernelGGL((nnf_hals_wave_kernel<2>), dim3(nblocks), dim3(64 * nw), wave_lds(a.r), st, a, ru);
-    NNF_CHECK_LAUNCH();
+    const int rc = wave_dispatch(a.r, cpw, a, snap, nblocks, nw, st, nullptr);
     nnf_probe(ctx, NNF_PROBE_HALS, 1, st);
-    return NNF_OK;
+    return rc;
 }

@@ -177,3 +177,91 @@ extern "C" int nnf_hadamard_f32(nnf_ctx* ctx, const float* A, const float* B, fl
     NNF_CHECK_LAUNCH();
     return NNF_OK;
 }
+
+// ---- Frobenius cost of an NMF iterate through the Gram identity (include/nnfac_hip.h) ------------------------------------
+// 16 threads per column j: thread t takes the rows a = t, t + 16, ...:  t_a = sum_b UtU[a][b] v_b, then its shares of
+//   A = sum v_a UtM[a][j],  A2 = sum (v_a UtM[a][j])^2,  B = sum v_a t_a,  V2 = sum v_a^2      (all fp64)
+// block sums in a fixed order -> partial[wg][4]; the finishing workgroup adds them in index order.
+__global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restrict__ V, int64_t ldv, const float* __restrict__ UtM,
+                                                            int64_t ldm, const float* __restrict__ G, int64_t ldg, int r, int64_t n,
+                                                            double* __restrict__ partial) {
+    extern __shared__ float gc_sh[];
+    float* g = gc_sh;                    // r x r
+    float* vc = gc_sh + (size_t)r * r;   // 16 columns x r
+    __shared__ double red[4];
+    for (int e = threadIdx.x; e < r * r; e += 256) g[e] = G[(int64_t)(e / r) * ldg + (e % r)];
+    const int tc = threadIdx.x >> 4, t = threadIdx.x & 15;
+    const int64_t j = (int64_t)blockIdx.x * 16 + tc;
+    for (int a = t; a < r; a += 16) vc[tc * r + a] = (j < n) ? V[(int64_t)a * ldv + j] : 0.f;
+    __syncthreads();
+    double pA = 0.0, pA2 = 0.0, pB = 0.0, pV2 = 0.0;
+    if (j < n) {
+        const float* vj = vc + tc * r;
+        for (int a = t; a < r; a += 16) {
+            const float* ga = g + (size_t)a * r;
+            double ta = 0.0;
+            for (int b = 0; b < r; ++b) ta = __builtin_fma((double)ga[b], (double)vj[b], ta);
+            const double va = (double)vj[a], p = va * (double)UtM[(int64_t)a * ldm + j];
+            pA += p;
+            pA2 = __builtin_fma(p, p, pA2);
+            pB = __builtin_fma(va, ta, pB);
+            pV2 = __builtin_fma(va, va, pV2);
+        }
+    }
+    const double sA = nnf_block_sum_f64(pA, red), sA2 = nnf_block_sum_f64(pA2, red), sB = nnf_block_sum_f64(pB, red),
+                 sV2 = nnf_block_sum_f64(pV2, red);
+    if (threadIdx.x == 0) {
+        double* o = partial + (size_t)blockIdx.x * 4;
+        o[0] = sA; o[1] = sA2; o[2] = sB; o[3] = sV2;
+    }
+}
+__global__ __launch_bounds__(256) void nnf_gram_cost_finish_kernel(const double* __restrict__ partial, int nwg, const float* __restrict__ G,
+                                                                   int64_t ldg, int r, const double* __restrict__ normx2,
+                                                                   double* __restrict__ out) {
+    __shared__ double red[4];
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int e = threadIdx.x; e < nwg; e += 256)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] += partial[(size_t)e * 4 + i];
+    double tot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tot[i] = nnf_block_sum_f64(s[i], red);
+    float gm = 0.f;
+    for (int e = threadIdx.x; e < r * r; e += 256) gm = fmaxf(gm, fabsf(G[(int64_t)(e / r) * ldg + (e % r)]));
+    __shared__ float gmax[256];
+    gmax[threadIdx.x] = gm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 256; ++i) gm = fmaxf(gm, gmax[i]);
+        const double cost = normx2[0] - 2.0 * tot[0] + tot[2];
+        // fp32 storage of UtM (relative rms 2^-24/sqrt(3) = 3.4e-8, measured 5.5e-8 with the accumulation) and of UtU:
+        //   sigma_A = 2 * 6e-8 * || V .* UtM ||_F,   sigma_B <= 4e-8 * max|UtU| * ||V||_F^2  (= trace of V V^T >= ||V V^T||_F / 1)
+        const double sa = 2.0 * 6e-8 * sqrt(tot[1]), sb = 4e-8 * (double)gm * tot[3];
+        const double est = 4.0 * sqrt(sa * sa + sb * sb);
+        out[0] = cost;
+        out[1] = (est <= 5e-4 * cost) ? 0.0 : 1.0;      // (a NaN or a non-positive cost lands on 1)
+        out[2] = est;
+    }
+}
+extern "C" int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
+                                     int64_t ldg, int r, int64_t n, const double* normx2_f64, double* out_f64, void* stream) {
+    if (!ctx || !V || !UtM || !UtU || !normx2_f64 || !out_f64 || r < 1 || n < 1 || ldv < n || ldm < n || ldg < r) return NNF_ERR_ARG;
+    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nwg = nnf_cdiv(n, 16);
+    if (nwg > (int64_t)1 << 24) return NNF_ERR_UNSUPPORTED;
+    nnf_ws_cursor cur(ctx);
+    double* partial = (double*)cur.take((size_t)nwg * 4 * 8);
+    if (!partial) return NNF_ERR_WORKSPACE;
+    const size_t shm = ((size_t)r * r + (size_t)16 * r) * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_gram_cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(nnf_gram_cost_kernel, dim3((int)nwg), dim3(256), shm, st, V, ldv, UtM, ldm, UtU, ldg, r, n, partial);
+    NNF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nnf_gram_cost_finish_kernel, dim3(1), dim3(256), 0, st, partial, (int)nwg, UtU, ldg, r, normx2_f64, out_f64);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}

@@ -69,6 +69,15 @@ def allreduce_cost_(block, group):
     return block
 
 
+def allreduce_errs_(block, group):
+    """The error words alone (HALS cost through the Gram identity: every operand of the cost is replicated, nothing else of
+    the block has to cross ranks)."""
+    if is_sharded(group):
+        block[17:19].copy_(block[3:12:8])
+        dist.all_reduce(block[17:19], op=dist.ReduceOp.SUM, group=group)
+    return block
+
+
 def agreed_code(host, i, nranks):
     """Error code of solve i from the summed copies made by allreduce_cost_: 0 if no rank reported anything; the common code
     when every rank reported the same one (3 / 4: the device-side stopping decision missed -- a function of all-reduced sums;

@@ -16,6 +16,7 @@ Inputs may be NumPy arrays or torch tensors; results come back in kind.  Arithme
 ``nn_fac_amd.dist`` (same step, RCCL all-reduce of the Gram / cross terms).
 """
 import math
+import os
 import time
 import warnings
 
@@ -177,6 +178,8 @@ class _StepBuffers:
         self.last_step_async = False
         self.async_hits = self.async_misses = 0
         self.safe_solve = False           # set by run_steps after a persistent solve timed out (chunked launches from then on)
+        self.direct_cost = False          # set by run_steps when the Gram-identity cost said it cannot carry the residual
+        self.normx2 = None                # ||X||^2 (float64 device scalar; row-sharded: summed over the ranks), on first use
         # the r x r Gram of an update is independent of its cross product (nmf.py:407-408, :432-433): it runs on a side
         # stream, with its own context (a context's workspace serves one stream at a time), under the streaming kernel
         self.side_eng, self.side_stream = _engine.get_side_engine(X.device) if X.is_cuda else (None, None)
@@ -185,25 +188,23 @@ class _StepBuffers:
 
 
 
-def _gram_on_side(ws, eng, A, out, start_from=None):
-    """eng.gram(A, out=out) overlapped with whatever the caller launches next on the current stream.  With `start_from` the
-    copy the following solve works on (nmf.py:415/440: the solve starts from a copy of the current factor) is made on the
-    side stream as well, instead of between the streaming kernel and the solve (a 20 MB copy + two dispatch gaps on the
-    critical path at config B).  Returns (event the current stream has to wait on before `out` / the copy are used -- None:
-    everything ran inline (CPU test doubles, buffers without a side stream) --, the copy or None)."""
+def _gram_on_side(ws, eng, A, out):
+    """eng.gram(A, out=out) overlapped with whatever the caller launches next on the current stream (the r x r Gram of an
+    update is independent of its cross product, nmf.py:407-408 / :432-433).  Returns the event the current stream has to wait
+    on before `out` is used -- None: it ran inline (CPU test doubles, buffers without a side stream).  Only the SHORT factor's
+    Gram (V V^T: r x n) goes to the side stream: the Gram of the long one (U^T U, 20 MB at config B) took 82 us there next to
+    W^T X instead of 5.4 us alone and cost that kernel 5 % (profiles/r02_B_kernel_stats.txt) -- it is launched in line, in
+    front of W^T X (`inline=True`)."""
     side = getattr(ws, "side_stream", None)
     if side is None or not isinstance(eng, _engine.Engine):
         eng.gram(A, out=out)
-        return None, (start_from.clone() if start_from is not None else None)
+        return None
     main = torch.cuda.current_stream(A.device)
-    copy = torch.empty_like(start_from) if start_from is not None else None    # allocated in the main stream's pool
     ready = main.record_event()
     with torch.cuda.stream(side):
         side.wait_event(ready)
-        if copy is not None:
-            copy.copy_(start_from)
         ws.side_eng.gram(A, out=out)
-        return side.record_event(), copy
+        return side.record_event()
 
 
 def _sync(dev):
@@ -213,6 +214,12 @@ def _sync(dev):
 
 class _SolveTimedOut(Exception):
     """A persistent HALS solve gave up waiting for its other workgroups (status word 1)."""
+
+
+class _IdentityUnreliable(Exception):
+    """HALS cost through the Gram identity (nnf_nmf_gram_cost_f32): the kernel's own error estimate is above 5e-4 of the
+    cost -- the residual is too small next to ||X||^2 for fp32 cross terms (an almost exact fit).  The iteration is redone
+    with the streaming cost kernel, and so is the rest of the run."""
 
 
 class _GuessMissed(Exception):
@@ -263,7 +270,19 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
     tensors, so the speculative iterations in flight are simply dropped.  Paths that synchronise inside a step anyway
     (wall-clock rule, row-sharded solve) run through the same code."""
     cuda = X.is_cuda
-    overlap = (cuda and update_rule == "hals" and 1 not in fixed_modes and isinstance(eng, _engine.Engine)
+    # HALS cost (nmf.py:452) WITHOUT a pass over X: ||X||^2 - 2 <V, U^T X> + sum_j v_j^T (U^T U) v_j from the operands of the V
+    # update (they belong to the iteration's final U) and its result, inner products in fp64 (Engine.gram_cost).  Measured
+    # against the fp64 residual on config B's own iterates: 7e-8 ... 1.2e-5 relative (the streaming kernel: 1e-9), absolute
+    # error ~1e-9 ||X||^2 -- tools/probes/gram_cost_probe.py.  The kernel estimates its error from the operands and flags
+    # an iterate it cannot carry to 5e-4 (an almost exact fit): run_steps then redoes that iteration, and runs the rest, with
+    # the streaming kernel.  Row-sharded: every operand is replicated (||X||^2 summed once), so the cost needs no collective.
+    # NNF_COST=direct in the environment forces the streaming kernel.
+    ident = (cuda and update_rule == "hals" and 1 not in fixed_modes and isinstance(eng, _engine.Engine)
+             and not ws.direct_cost and os.environ.get("NNF_COST") != "direct")
+    if ident and ws.normx2 is None:
+        ws.normx2 = eng.dot(X, X)
+        _dist.allreduce_(ws.normx2, group)
+    overlap = (cuda and update_rule == "hals" and 1 not in fixed_modes and isinstance(eng, _engine.Engine) and not ident
                and ws.cost_stream is not None
                and (not _dist.is_sharded(group) or _dist.opt_in("NNF_SHARDED_OVERLAP", group)))
     if ws.async_sharded is None:
@@ -306,6 +325,8 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
         host = ws.host[step["slot"]]
         _raise_on_status(host, step["nstat"], timeout_ok=not getattr(ws, "safe_solve", False),
                          nranks=_dist.world(group) if _dist.is_sharded(group) else 0)
+        if step.get("ident") and float(host[20]) != 0.0:
+            raise _IdentityUnreliable()
         pending.pop(0)                     # (a step that timed out stays at the head: run_steps resumes from it)
         result = (step["Ut"], step["V"])
         if group is not None and update_rule == "hals" and step["nstat"] >= 1 and 0 not in fixed_modes:
@@ -315,7 +336,7 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
         if step.get("async_u"):            # row-sharded, device-side protocol: centre the next blind chunk on this count
             ws.async_hits += 1
             ws.guess_u.value = max(8, min(int(host[_engine.ST_CNT]) - 1 + 4, ws.guess_u.max_chunk))
-        stop = bool(retired(step["it"], float(host[16]),
+        stop = bool(retired(step["it"], float(host[19 if step.get("ident") else 16]),
                             [int(host[8 * i + _engine.ST_CNT]) - 1 for i in range(step["nstat"])]))
 
     def drain():
@@ -353,10 +374,17 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
             hooks["before_u_solve"] = lambda ev=costed["ev"]: main.wait_event(ev)
         Ut, V, nstat = _one_nmf_step_dev(eng, ws, X, rank, Ut, V, update_rule, beta, sparsity_coefficients,
                                          fixed_modes, normalize, deterministic, group=group,
-                                         skip_cost=overlap or fused_mu, **hooks)
-        step = dict(it=iteration, slot=ws.slot, Ut=Ut, V=V, nstat=nstat, ev=None, async_u=ws.last_step_async)
+                                         skip_cost=overlap or fused_mu or ident, **hooks)
+        step = dict(it=iteration, slot=ws.slot, Ut=Ut, V=V, nstat=nstat, ev=None, async_u=ws.last_step_async, ident=ident)
         ws.sync_next = False
-        if fused_mu:
+        if ident:
+            # words 19..21 of the block: {cost, 1 = not reliable, error estimate}; the V update's operands are still in place
+            eng.gram_cost(V, ws.UtM, ws.G2, ws.normx2, ws.block[19:22])
+            _add_sparsity_terms(Ut, V, sparsity_coefficients, ws.block[19:20], group)
+            _dist.allreduce_errs_(ws.block, group)
+            ws.host[ws.slot].copy_(ws.block, non_blocking=True)
+            step["ev"] = main.record_event()
+        elif fused_mu:
             if owed is not None:          # its cost has just been enqueued with this step's left update
                 _dist.allreduce_cost_(ws.blocks[owed["slot"]], group)
                 ws.host[owed["slot"]].copy_(ws.blocks[owed["slot"]], non_blocking=True)
@@ -386,6 +414,18 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
             failed = pending[0]["it"]             # the step being retired is still at the head of the list
             fall_back()
             Ut, V = result                        # factors of the last iteration that retired cleanly
+            iteration = failed
+        except _IdentityUnreliable:
+            failed = pending[0]["it"]
+            drain()
+            pending.clear()
+            ws.direct_cost = True                 # this iteration again, and every later one, with the streaming cost kernel
+            ident = False
+            overlap = (ws.cost_stream is not None
+                       and (not _dist.is_sharded(group) or _dist.opt_in("NNF_SHARDED_OVERLAP", group)))
+            depth = PIPELINE_DEPTH + (1 if overlap else 0)
+            owed = costed = None
+            Ut, V = result
             iteration = failed
         except _GuessMissed:
             failed = pending[0]["it"]
@@ -423,8 +463,11 @@ def _timed_budget(eng, cross, gram, F, sparsity, normalize, timer, group=None):
     return _dist.agree_int(budget, group, F.device)
 
 
-def _hals_call(eng, cross, gram, F, sparsity, normalize, deterministic, timer, status, safe=None, group=None, guess=None):
-    """hals_nnls_acc(..., maxiter=100, atime=timer, alpha=inf|0.5, delta=0.01) of nmf.py:415-419,440-444, in place.
+def _hals_call(eng, cross, gram, F_in, sparsity, normalize, deterministic, timer, status, safe=None, group=None, guess=None):
+    """hals_nnls_acc(..., maxiter=100, atime=timer, alpha=inf|0.5, delta=0.01) of nmf.py:415-419,440-444.  Returns the updated
+    factor, a NEW tensor: the solve reads its start values from F_in and writes its result elsewhere (the V_in / V_out form of
+    nnf_hals_solve_cross_f32 -- the reference works on `in_V.copy()`, nnls.py:147; the 20 MB copy of U^T that used to run on
+    the side stream next to X H^T is gone).
     `safe` (a dist.SweepGuess): the solve runs as chunked fixed-count launches whose workgroups never wait for each other
     (run_steps' fall-back after a persistent solve timed out); row normalisation needs the persistent kernel and cannot.
     `guess` (a dist.SweepGuess): the same chunked form is ALSO the fast one for a factor with more columns than the resident
@@ -434,17 +477,25 @@ def _hals_call(eng, cross, gram, F, sparsity, normalize, deterministic, timer, s
     budget = HALS_INNER["maxiter"]
     if safe is None and guess is not None and deterministic and not normalize:
         cap = getattr(eng, "hals_resident_columns", None)
-        if cap is not None and F.shape[1] > cap(F.shape[0]):
+        if cap is not None and F_in.shape[1] > cap(F_in.shape[0]):
             safe = guess
     if safe is not None and deterministic and not normalize:
+        F = F_in.clone()
         eps, cnt, eps0 = _dist.sharded_hals_solve(eng, cross, gram, F, None, safe, budget=budget, delta=HALS_INNER["delta"],
                                                   sparsity=sparsity)
         status[:4] = torch.tensor([eps, cnt, eps0, 0.0], dtype=torch.float64)
-        return status
+        return F
     if not deterministic:
-        budget = _timed_budget(eng, cross, gram, F, sparsity, normalize, timer, group)
-    return eng.hals_solve(cross, gram, F, budget, delta=HALS_INNER["delta"], sparsity=sparsity, normalize=normalize, nonzero=False,
-                          status=status)
+        budget = _timed_budget(eng, cross, gram, F_in, sparsity, normalize, timer, group)
+    if hasattr(eng, "hals_solve_cross"):
+        F = torch.empty_like(F_in)
+        eng.hals_solve_cross(cross, gram, None, F_in, F, budget, delta=HALS_INNER["delta"], sparsity=sparsity, normalize=normalize,
+                             status=status)
+        return F
+    F = F_in.clone()                       # (CPU test doubles: in place on a copy)
+    eng.hals_solve(cross, gram, F, budget, delta=HALS_INNER["delta"], sparsity=sparsity, normalize=normalize, nonzero=False,
+                   status=status)
+    return F
 
 
 def _step_cost_local(eng, X, Ut, V, update_rule, beta, out):
@@ -462,11 +513,17 @@ def _step_cost_finish(Ut, V, update_rule, sparsity_coefficients, block, group=No
     out = block[16:17]
     if sharded:
         _dist.allreduce_cost_(block, group)
+    if update_rule == "hals":
+        _add_sparsity_terms(Ut, V, sparsity_coefficients, out, group)
+
+
+def _add_sparsity_terms(Ut, V, sparsity_coefficients, out, group=None):
+    """out += 2 (sp0 ||U||_1 + sp1 ||V||_1) with the MATRIX 1-norm (max column abs-sum, np.linalg.norm(., ord=1)) -- not the
+    entry-wise l1 the reference's docstring states (nmf.py:452)."""
     sp = [0 if s is None else s for s in sparsity_coefficients]
-    if update_rule == "hals" and (sp[0] or sp[1]):
-        # matrix 1-norm (max column abs-sum, np.linalg.norm(., ord=1)) -- NOT the entry-wise l1 (nmf.py:452)
+    if sp[0] or sp[1]:
         cs = Ut.abs().sum(dim=1).double()         # columns of U are rows of Ut
-        if sharded:
+        if _dist.is_sharded(group):
             _dist.allreduce_(cs, group)
         nU = cs.max()
         nV = V.abs().sum(dim=0).max().double()
@@ -508,7 +565,7 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             if not deterministic:
                 _sync(dev)
                 t0 = time.time()
-            done, Ut = _gram_on_side(ws, eng, V, ws.G, start_from=Ut_in)   # VVt (nmf.py:407); solve starts from U_in^T (:415)
+            done = _gram_on_side(ws, eng, V, ws.G)      # VVt (nmf.py:407)
             eng.xht(X, V, out=ws.VMt)                   # VMt  (nmf.py:408)
             if done is not None:
                 torch.cuda.current_stream(dev).wait_event(done)
@@ -521,6 +578,8 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             budget_u = HALS_INNER["maxiter"]
             if sharded and not deterministic:    # wall-clock rule (nnls.py:190-194): rank 0's budget on every rank
                 budget_u = _timed_budget(eng, ws.VMt, ws.G, Ut, sparsity_coefficients[0], False, timer, group)
+            if sharded:
+                Ut = Ut_in.clone()                  # the chunked sharded protocols work in place (nmf.py:415: from U_in^T)
             if sharded and deterministic and hasattr(eng, "hals_stop_restore") and not ws.sync_next and ws.async_sharded \
                     and ws.async_ready:
                 # no host round trip: blind chunk + all-reduce + device-side replay of the stopping rule; a missed guess
@@ -535,9 +594,9 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                                                           sparsity=sparsity_coefficients[0])
                 ws.block[8 * nstat:8 * nstat + 4] = torch.tensor([eps, cnt, eps0, 0.0], dtype=torch.float64)
             else:
-                _hals_call(eng, ws.VMt, ws.G, Ut, sparsity_coefficients[0], normalize[0], deterministic, timer,
-                           ws.block[8 * nstat:8 * nstat + 8], safe=ws.guess_u if getattr(ws, "safe_solve", False) else None,
-                           guess=ws.guess_u)
+                Ut = _hals_call(eng, ws.VMt, ws.G, Ut_in, sparsity_coefficients[0], normalize[0], deterministic, timer,
+                                ws.block[8 * nstat:8 * nstat + 8],
+                                safe=ws.guess_u if getattr(ws, "safe_solve", False) else None, guess=ws.guess_u)
             nstat += 1
         else:
             if mu_cost_out is not None:                 # + beta_divergence(X, U_in V_in, 1): the previous iteration's cost
@@ -551,10 +610,8 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             if not deterministic:
                 _sync(dev)
                 t0 = time.time()
-            done, V = _gram_on_side(ws, eng, Ut, ws.G2, start_from=V_in)   # UtU (nmf.py:432); solve starts from V_in (:440)
+            eng.gram(Ut, out=ws.G2)                     # UtU  (nmf.py:432) -- in line: see _gram_on_side
             eng.xty(X, Ut, out=ws.UtM)                  # UtM  (nmf.py:433)
-            if done is not None:
-                torch.cuda.current_stream(dev).wait_event(done)
             if sharded:                                 # sum over the row blocks: r x n and r x r over xGMI, one collective
                 if getattr(ws, "v_terms", None) is not None:
                     _dist.allreduce_(ws.v_terms, group)
@@ -566,9 +623,9 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                 timer = time.time() - t0
             if before_v_solve is not None:
                 before_v_solve()
-            _hals_call(eng, ws.UtM, ws.G2, V, sparsity_coefficients[1], normalize[1], deterministic, timer,
-                       ws.block[8 * nstat:8 * nstat + 8], safe=ws.guess_v if getattr(ws, "safe_solve", False) else None,
-                       group=group if sharded else None, guess=ws.guess_v)
+            V = _hals_call(eng, ws.UtM, ws.G2, V_in, sparsity_coefficients[1], normalize[1], deterministic, timer,
+                           ws.block[8 * nstat:8 * nstat + 8], safe=ws.guess_v if getattr(ws, "safe_solve", False) else None,
+                           group=group if sharded else None, guess=ws.guess_v)
             nstat += 1
         else:
             if sharded:

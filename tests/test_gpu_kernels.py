@@ -137,9 +137,12 @@ def _kw(vec):
 
 
 LAYOUTS = ["lane", "quad"]      # one lane per column (k_hals_fast.hip) / four lanes per column (k_hals_quad.hip)
+# persistent solves also have the one-wave-per-column push form (k_hals_wave.hip; the default up to 8192 columns -- "wave"
+# forces nothing, it names the default; fixed-count / snapshot launches keep the two layouts above)
+LAYOUTS_SOLVE = LAYOUTS + ["wave"]
 
 
-@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("layout", LAYOUTS_SOLVE)
 def test_hals_against_reference_fixtures(golden, layout, monkeypatch):
     """hals_nnls_acc through the drop-in signature vs the reference outputs stored in g1 (57 cases), both kernels."""
     from nn_fac_amd.update_rules.nnls import hals_nnls_acc
@@ -160,7 +163,7 @@ def test_hals_against_reference_fixtures(golden, layout, monkeypatch):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("layout", LAYOUTS_SOLVE)
 def test_hals_coupling_against_reference_fixtures(golden, layout, monkeypatch):
     """hals_coupling_nnls_acc (nnls.py:204-352, PARAFAC2's caller of the sweep) vs the real reference's outputs (g8):
     sweep counts equal, factors within the fp32 single-call tolerance, both kernel layouts."""
@@ -209,7 +212,7 @@ def test_hals_zero_column_raises():
 
 
 @pytest.mark.parametrize("r", [12, 50, 64, 100])
-@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("layout", LAYOUTS_SOLVE)
 def test_hals_zero_diagonal_row_is_left_alone(eng, layout, r, monkeypatch):
     """nnls.py:160: a row whose Gram diagonal is 0 is skipped whatever it holds (negative entries included), and the
     other rows keep seeing its values through the off-diagonal Gram entries."""
@@ -241,10 +244,12 @@ def test_hals_does_not_modify_inputs(eng):
 
 @pytest.mark.parametrize("r,ncols,layout", [(50, 100000, "lane"), (100, 20000, "lane"), (30, 500, "lane"), (50, 300000, "lane"),
                                             (30, 500, "quad"), (50, 2000, "quad"), (96, 8000, "quad"), (70, 16000, "quad"), (100, 4000, "quad"), (128, 3000, "quad"),
+                                            (30, 500, "wave"), (50, 2000, "wave"), (100, 4000, "wave"), (128, 3000, "wave"), (64, 8000, "wave"),
+                                            (65, 700, "wave"), (3, 50, "wave"), (1, 9, "wave"), (57, 8192, "wave"),
                                             (100, 20000, "auto"), (120, 9000, "lane"), (64, 70000, "lane"), (56, 40000, "lane"), (34, 40000, "lane")])
 def test_hals_large_vs_oracle(eng, r, ncols, layout, monkeypatch):
     """Resident and strided (ncols > resident threads) persistent solves vs the fp64 oracle; sweep counts equal."""
-    if layout != "auto":
+    if layout not in ("auto", "wave"):
         monkeypatch.setenv("NNF_HALS_FORCE", layout)
     rng = np.random.RandomState(r + ncols)
     A = rng.rand(4 * r, r)
@@ -264,7 +269,7 @@ def test_hals_large_vs_oracle(eng, r, ncols, layout, monkeypatch):
     got = Vd.cpu().numpy()
     assert rel(got[:, :cols], Vo) < 2e-4
     assert np.array_equal(got[:, :cols], got[:, -cols:])      # identical columns -> identical results
-    assert abs(float(st[0]) - reps * epso) <= 5e-3 * reps * epso
+    assert abs(float(st[0]) - reps * epso) <= 5e-3 * reps * epso + 1e-10 * reps * log[0]   # (+ fp32 noise of an exact fit: rank 1)
 
 
 @pytest.mark.parametrize("layout", LAYOUTS)
@@ -438,6 +443,9 @@ def test_hals_resident_columns_and_blocked_chunks(eng, monkeypatch):
     and the counts of the persistent solve bit for bit, in both forms of the stopping decision; the real capacity is what the
     occupancy of the kernels says (two 256-column workgroups per CU at ranks 50 and 100 on this device)."""
     from nn_fac_amd import dist as nd
+    # (the subject is the one-lane-per-column kernel whose resident capacity the blocks exist for; 5000 columns alone would
+    # take the few-column layouts, which agree with it to rounding, not bit for bit)
+    monkeypatch.setenv("NNF_HALS_FORCE", "lane")
     for r in (50, 100):
         cap = eng.hals_resident_columns(r)
         assert cap % 256 == 0 and 65536 <= cap <= 2048 * 256

@@ -160,6 +160,9 @@ __device__ __forceinline__ bool hals_collect(const hals_sync& sy, int s, int nbl
 // instruction, no branch, no exec mask in the middle of the hand-scheduled scalar loads (a C++ version there made hipcc
 // shuffle in-flight scalar destinations: tools/check_sweep_spills.py).  Threads without a granule of their own read
 // granule 0 and ignore it.  The consumer waits with vmcnt(0) (hals_mid_wait) before it looks at the registers.
+#ifndef HALS_DBG
+#define HALS_DBG 0             // timing-only ablations of the exchange (tools/probes/exchange_cost_probe.py): 1 granules taken as they
+#endif                         // come (no tag wait), 2 no collect at all, 4 no publish either; decisions are ignored then
 #ifndef HALS_LATE_ISSUE
 #define HALS_LATE_ISSUE 1      // 0: the exchange prefetch goes out before the sweep (A/B builds)
 #endif
@@ -260,39 +263,59 @@ __device__ __forceinline__ bool hals_collect_wave(const hals_sync& sy, int s, in
 // block sum of this sweep's partial AND collect of an earlier sweep's global sum behind ONE barrier: both are "every wave
 // leaves a double in LDS, everybody adds the four up", so the two values of a wave travel together (red_p: two slot arrays
 // of the current sweep parity).  Returns the block sum in `bs` (every thread), the global sum of sweep c in `total`.
+// For workgroups of exactly NT = 256 threads (the resident lane kernel): the thread count is a compile-time constant --
+// `blockDim.x` is a load from the implicit kernel arguments, i.e. a memory round trip per sweep in the middle of the
+// exchange (s_load + global_load_ushort + s_waitcnt in the ISA of round 2's kernel) -- and the two granule pairs of a thread
+// are handled by straight-line code; only a granule that has not arrived takes the re-read loop.
+template <int NT>
 __device__ __forceinline__ bool hals_sum_collect1(const hals_sync& sy, double nd, double& bs, int c, int nblocks, double& total,
                                                   double* red_bs, double* red_tot, unsigned* lds_flag,
                                                   const hals_prefetch& pf) {
+    static_assert(NT == 256 && HALS_PF == 2, "two granule pairs per thread cover nblocks <= 512");
     const unsigned tag = sy.epoch * 1024u + (unsigned)c;
     const unsigned long long* base = reinterpret_cast<const unsigned long long*>(sy.sslots) + (size_t)c * nblocks * 2;
     double v = 0.0;
-    int i = 0;
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x, ++i) {
-        unsigned long long g0 = 0ull, g1 = 0ull;
-        if (pf.s == c) {
 #pragma unroll
-            for (int u = 0; u < HALS_PF; ++u)
-                if (u == i) { g0 = pf.g0[u]; g1 = pf.g1[u]; }
+    for (int i = 0; i < HALS_PF; ++i) {
+        const int b = (int)threadIdx.x + NT * i;
+        if (b < nblocks) {
+            unsigned long long g0 = (pf.s == c) ? pf.g0[i] : 0ull, g1 = (pf.s == c) ? pf.g1[i] : 0ull;
+            if (!(HALS_DBG & 1) && !((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag)) {   // not there yet: re-read (bounded)
+                unsigned spins = 0;
+                do {
+                    if (spins > 0) __builtin_amdgcn_s_sleep(1);
+                    if (++spins > HALS_SPIN_LIMIT) { *lds_flag = 0u; break; }
+                    g0 = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g1 = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while (!((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag));
+            }
+            v += __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xffffffffull));
         }
-        unsigned spins = 0;
-        while (!((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag)) {
-            if (spins > 0) __builtin_amdgcn_s_sleep(1);
-            if (++spins > HALS_SPIN_LIMIT) { *lds_flag = 0u; break; }
-            g0 = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            g1 = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        v += __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xffffffffull));
     }
     v = nnf_wave_sum_f64(v);
     nd = nnf_wave_sum_f64(nd);
-    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    constexpr int nw = NT / 64;
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red_bs[w] = nd; red_tot[w] = v; }
     __syncthreads();
     double t = red_tot[0], b2 = red_bs[0];
+#pragma unroll
     for (int k = 1; k < nw; ++k) { t += red_tot[k]; b2 += red_bs[k]; }
     total = t;
     bs = b2;
     return *lds_flag != 0u;
+}
+template <int NT>
+__device__ __forceinline__ double hals_block_sum1(double v, double* red_p) {
+    v = nnf_wave_sum_f64(v);
+    constexpr int nw = NT / 64;
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red_p[w] = v;
+    __syncthreads();
+    double t = red_p[0];
+#pragma unroll
+    for (int k = 1; k < nw; ++k) t += red_p[k];
+    return t;   // every thread
 }
 
 struct hals_args {

@@ -7,7 +7,7 @@
 #error "compile with -DHALS_PART=0..3"
 #endif
 
-NNF_BUILD_FLAGS(NNF_CAT(k_hals_fast, HALS_PART), "HALS_LATE_ISSUE=" NNF_STR(HALS_LATE_ISSUE) " HALS_MID_AT(R)=" NNF_STR(HALS_MID_AT(R)))
+NNF_BUILD_FLAGS(NNF_CAT(k_hals_fast, HALS_PART), "HALS_LATE_ISSUE=" NNF_STR(HALS_LATE_ISSUE) " HALS_MID_AT(R)=" NNF_STR(HALS_MID_AT(R)) " HALS_DBG=" NNF_STR(HALS_DBG))
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -334,13 +334,13 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
         bool merged = false;    // SPEC: this sweep's block sum and the collect of sweep s-1 share one barrier
         double tot_m = 0.0;
         if constexpr (RES && SPEC) {
-            if (a.mode == 0 && s >= 2) {
-                ok = hals_sum_collect1(a.sy, nd, bs, s - 1, nblocks, tot_m, red2[s & 1][0], red2[s & 1][1], &lds_flag, pf);
+            if (a.mode == 0 && s >= 2 && !(HALS_DBG & 6)) {
+                ok = hals_sum_collect1<256>(a.sy, nd, bs, s - 1, nblocks, tot_m, red2[s & 1][0], red2[s & 1][1], &lds_flag, pf);
                 merged = true;
             }
         }
         if (!merged) {
-            if constexpr (RES) bs = hals_block_sum1(nd, red2[s & 1][0]);   // valid in every thread; one barrier
+            if constexpr (RES) bs = hals_block_sum1<256>(nd, red2[s & 1][0]);   // valid in every thread; one barrier
             else bs = nnf_block_sum_f64(nd, red);
         }
         if (a.mode == 1) {
@@ -356,9 +356,9 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
             done = s;
             continue;
         }
-        hals_publish(a.sy, s, nblocks, bs);
+        if (!(HALS_DBG & 4)) hals_publish(a.sy, s, nblocks, bs);
         const int c = SPEC ? s - 1 : s;         // sweep whose global sum is examined now
-        if (c >= 1) {
+        if (c >= 1 && !(HALS_DBG & 6)) {
             double tot;
             if (merged) tot = tot_m;
             else if constexpr (RES) ok = hals_collect1(a.sy, c, nblocks, tot, red2[s & 1][1], &lds_flag, pf);
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
             if (c == 1 && a.sweep0 == 0) eps0 = tot;
             eps = tot;
             done = c;
-            if (!(eps >= a.delta * eps0)) { stopped = true; break; }   // nnls.py:156: sweep c was the last one
+            if (!(eps >= a.delta * eps0) && !HALS_DBG) { stopped = true; break; }   // nnls.py:156: sweep c was the last one
         }
     }
     if constexpr (RES) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
     }
     if (a.mode == 1) {
         if constexpr (RES) store_col(voff0);
-    } else if (SPEC && ok && !stopped && a.max_sweeps >= 1) {
+    } else if (SPEC && ok && !stopped && a.max_sweeps >= 1 && !HALS_DBG) {
         double tot;                             // ran to the sweep budget: the last sweep's sum is still due
         ok = hals_collect(a.sy, a.max_sweeps, nblocks, tot, red, &lds_flag);
         if (ok) {

@@ -661,7 +661,10 @@ static int launch_gram(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, 
     }
     // one split per CU (the slab reduction spreads every output element over up to 16 threads, so its cost grows slowly
     // with the split count): 64 splits left a 50 x 100000 Gram at 22 us and a 100 x 125000 one at 127 us
-    int64_t nsplit = ctx->num_cus > 8 ? ctx->num_cus : 8;
+    // (a workgroup walks its split in 64-wide LDS-staged chunks, one memory round trip each: with one split per CU the Gram of a
+    // 50 x 100000 factor was 7 dependent round trips = 15.7 us in front of W^T X; two resident workgroups per CU halve the
+    // chain and overlap each other's waits)
+    int64_t nsplit = ctx->num_cus > 8 ? 2 * (int64_t)ctx->num_cus : 8;
     const int64_t max_split = nnf_cdiv(K, 64);
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;

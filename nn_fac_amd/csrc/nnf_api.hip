@@ -61,16 +61,20 @@ extern "C" int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_by
     c->probe_id = NNF_PROBE_XTY;
     c->ring = nullptr;
     c->ring_n = c->ring_pos = 0;
+    c->gc_ticket = nullptr;
     c->xch = nullptr;
     c->xch_bytes = (size_t)(NNF_HALS_MAX_SWEEPS + 2) * NNF_HALS_MAX_BLOCKS * 16;
     hipError_t e = hipMalloc((void**)&c->ws, c->ws_bytes);
     if (e == hipSuccess) e = hipMemset(c->ws, 0, c->ws_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&c->xch, c->xch_bytes);
     if (e == hipSuccess) e = hipMemset(c->xch, 0, c->xch_bytes);   // exchange words must not start as look-alike tags
+    if (e == hipSuccess) e = hipMalloc((void**)&c->gc_ticket, 256);
+    if (e == hipSuccess) e = hipMemset(c->gc_ticket, 0, 256);
     (void)hipSetDevice(prev);
     if (e != hipSuccess) {
         if (c->ws) (void)hipFree(c->ws);
         if (c->xch) (void)hipFree(c->xch);
+        if (c->gc_ticket) (void)hipFree(c->gc_ticket);
         delete c;
         return NNF_ERR_WORKSPACE;
     }
@@ -82,6 +86,7 @@ extern "C" int nnf_ctx_destroy(nnf_ctx* ctx) {
     if (!ctx) return NNF_ERR_ARG;
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->xch) (void)hipFree(ctx->xch);
+    if (ctx->gc_ticket) (void)hipFree(ctx->gc_ticket);
     delete[] ctx->ring;
     delete ctx;
     return NNF_OK;
@@ -181,14 +186,17 @@ extern "C" int nnf_hadamard_f32(nnf_ctx* ctx, const float* A, const float* B, fl
 // ---- Frobenius cost of an NMF iterate through the Gram identity (include/nnfac_hip.h) ------------------------------------
 // 16 threads per column j: thread t takes the rows a = t, t + 16, ...:  t_a = sum_b UtU[a][b] v_b, then its shares of
 //   A = sum v_a UtM[a][j],  A2 = sum (v_a UtM[a][j])^2,  B = sum v_a t_a,  V2 = sum v_a^2      (all fp64)
-// block sums in a fixed order -> partial[wg][4]; the finishing workgroup adds them in index order.
+// block sums in a fixed order -> partial[wg][4]; the LAST workgroup to finish (a ticket) adds the partials in index order
+// -- the same bits whichever workgroup that is -- and writes {cost, flag, estimate}.  One launch.
 __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restrict__ V, int64_t ldv, const float* __restrict__ UtM,
                                                             int64_t ldm, const float* __restrict__ G, int64_t ldg, int r, int64_t n,
-                                                            double* __restrict__ partial) {
+                                                            double* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                            const double* __restrict__ normx2, double* __restrict__ out) {
     extern __shared__ float gc_sh[];
     float* g = gc_sh;                    // r x r
     float* vc = gc_sh + (size_t)r * r;   // 16 columns x r
     __shared__ double red[4];
+    __shared__ unsigned last;
     for (int e = threadIdx.x; e < r * r; e += 256) g[e] = G[(int64_t)(e / r) * ldg + (e % r)];
     const int tc = threadIdx.x >> 4, t = threadIdx.x & 15;
     const int64_t j = (int64_t)blockIdx.x * 16 + tc;
@@ -211,36 +219,49 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
     const double sA = nnf_block_sum_f64(pA, red), sA2 = nnf_block_sum_f64(pA2, red), sB = nnf_block_sum_f64(pB, red),
                  sV2 = nnf_block_sum_f64(pV2, red);
     if (threadIdx.x == 0) {
-        double* o = partial + (size_t)blockIdx.x * 4;
-        o[0] = sA; o[1] = sA2; o[2] = sB; o[3] = sV2;
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(partial) + (size_t)blockIdx.x * 4;
+        const double vals[4] = {sA, sA2, sB, sV2};
+        for (int i = 0; i < 4; ++i)
+            __hip_atomic_store(o + i, __builtin_bit_cast(unsigned long long, vals[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // release: the partials are visible to whoever sees this workgroup's ticket
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = (tk == gridDim.x - 1u) ? 1u : 0u;
     }
-}
-__global__ __launch_bounds__(256) void nnf_gram_cost_finish_kernel(const double* __restrict__ partial, int nwg, const float* __restrict__ G,
-                                                                   int64_t ldg, int r, const double* __restrict__ normx2,
-                                                                   double* __restrict__ out) {
-    __shared__ double red[4];
+    __syncthreads();
+    if (last == 0u) return;
+    // ---- the last workgroup: everything is published ----
+    const int nwg = (int)gridDim.x;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const unsigned long long* pp = reinterpret_cast<const unsigned long long*>(partial);
     for (int e = threadIdx.x; e < nwg; e += 256)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s[i] += partial[(size_t)e * 4 + i];
+        for (int i = 0; i < 4; ++i)
+            s[i] += __builtin_bit_cast(double, __hip_atomic_load(pp + (size_t)e * 4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     double tot[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) tot[i] = nnf_block_sum_f64(s[i], red);
     float gm = 0.f;
-    for (int e = threadIdx.x; e < r * r; e += 256) gm = fmaxf(gm, fabsf(G[(int64_t)(e / r) * ldg + (e % r)]));
-    __shared__ float gmax[256];
-    gmax[threadIdx.x] = gm;
+    for (int e = threadIdx.x; e < r * r; e += 256) gm = fmaxf(gm, fabsf(g[e]));
+    gm = fmaxf(gm, __shfl_xor(gm, 1, 64));
+    gm = fmaxf(gm, __shfl_xor(gm, 2, 64));
+    gm = fmaxf(gm, __shfl_xor(gm, 4, 64));
+    gm = fmaxf(gm, __shfl_xor(gm, 8, 64));
+    gm = fmaxf(gm, __shfl_xor(gm, 16, 64));
+    gm = fmaxf(gm, __shfl_xor(gm, 32, 64));
+    __shared__ float gmax[4];
+    if ((threadIdx.x & 63) == 0) gmax[threadIdx.x >> 6] = gm;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < 256; ++i) gm = fmaxf(gm, gmax[i]);
+        gm = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
         const double cost = normx2[0] - 2.0 * tot[0] + tot[2];
         // fp32 storage of UtM (relative rms 2^-24/sqrt(3) = 3.4e-8, measured 5.5e-8 with the accumulation) and of UtU:
-        //   sigma_A = 2 * 6e-8 * || V .* UtM ||_F,   sigma_B <= 4e-8 * max|UtU| * ||V||_F^2  (= trace of V V^T >= ||V V^T||_F / 1)
+        //   sigma_A = 2 * 6e-8 * || V .* UtM ||_F,   sigma_B <= 4e-8 * max|UtU| * ||V||_F^2  (= trace of V V^T >= ||V V^T||_F)
         const double sa = 2.0 * 6e-8 * sqrt(tot[1]), sb = 4e-8 * (double)gm * tot[3];
         const double est = 4.0 * sqrt(sa * sa + sb * sb);
         out[0] = cost;
         out[1] = (est <= 5e-4 * cost) ? 0.0 : 1.0;      // (a NaN or a non-positive cost lands on 1)
         out[2] = est;
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call (stream-ordered)
     }
 }
 extern "C" int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
@@ -253,15 +274,17 @@ extern "C" int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, 
     nnf_ws_cursor cur(ctx);
     double* partial = (double*)cur.take((size_t)nwg * 4 * 8);
     if (!partial) return NNF_ERR_WORKSPACE;
+    // the ticket: 256 bytes of the context's own, zero at creation, returned to zero by the kernel itself (stream-ordered)
+    unsigned* ticket = ctx->gc_ticket;
+    if (!ticket) return NNF_ERR_WORKSPACE;
     const size_t shm = ((size_t)r * r + (size_t)16 * r) * 4;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_gram_cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL(nnf_gram_cost_kernel, dim3((int)nwg), dim3(256), shm, st, V, ldv, UtM, ldm, UtU, ldg, r, n, partial);
-    NNF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nnf_gram_cost_finish_kernel, dim3(1), dim3(256), 0, st, partial, (int)nwg, UtU, ldg, r, normx2_f64, out_f64);
+    hipLaunchKernelGGL(nnf_gram_cost_kernel, dim3((int)nwg), dim3(256), shm, st, V, ldv, UtM, ldm, UtU, ldg, r, n, partial, ticket,
+                       normx2_f64, out_f64);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
 }

@@ -16,6 +16,7 @@ struct nnf_ctx {
                            // and whenever the epoch wraps
     hipEvent_t probe[2];   // optional caller-owned events recorded around ONE main kernel (nnf_ctx_set_probe[_kernel])
     int probe_id;          // which kernel the probe brackets (NNF_PROBE_*, include/nnfac_hip.h); default: W^T X
+    unsigned* gc_ticket;   // nnf_nmf_gram_cost_f32: finishing ticket (256 zeroed bytes of its own; the kernel returns it to zero)
     hipEvent_t* ring;      // nnf_ctx_set_probe_ring: ring_n (begin, end) pairs, the next launch records pair ring_pos
     int ring_n, ring_pos;
 };

@@ -43,10 +43,10 @@ def test_built_library_carries_the_default_build_switches(built_lib):
     n = lib.nnf_build_flags(buf, 8192)
     assert 0 < n < 8192
     got = dict(u.split(": ", 1) for u in buf.value.decode().split("; "))
-    hals = "HALS_LATE_ISSUE=1 HALS_MID_AT(R)=((R) - 1)"
+    hals = "HALS_LATE_ISSUE=1 HALS_MID_AT(R)=((R) - 1) HALS_DBG=0"
     quad = "QUAD_MID_SEL=1 HALS_LATE_ISSUE=1"
     mu = "MU_WG_PER_CU=2 MU_STEP_FENCE()=__builtin_amdgcn_sched_barrier(0)"
-    want = {"k_stream": "XHT_ABL=0", "k_mttkrp": "SEG_ABL=0 MTTKRP_ABL=0",
+    want = {"k_stream": "XHT_ABL=0", "k_mttkrp": "SEG_ABL=0 MTTKRP_ABL=0", "k_hals_wave": "WAVE_DBG=0",
             **{f"k_hals_fast{i}": hals for i in range(4)}, **{f"k_hals_quad{i}": quad for i in range(4)},
             **{f"k_mu{i}": mu for i in range(3)}}
     for unit, flags in want.items():

@@ -16,9 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 configs = sys.argv[2:] or ["B", "C", "D"]
-MAIN = {"B": ["nnf_xty_kernel", "nnf_xht_kernel", "nnf_cost_kernel", "nnf_hals_kernel", "nnf_hals_quad_kernel"],
+MAIN = {"B": ["nnf_xty_kernel", "nnf_xht_kernel", "nnf_cost_kernel", "nnf_hals_kernel", "nnf_hals_wave_kernel", "nnf_gram_cost_kernel",
+              "nnf_gram_kernel"],
         "C": ["nnf_mu_left_kernel", "nnf_mu_right_kernel", "nnf_cost_kernel"],
-        "D": ["nnf_mu_left_kernel", "nnf_mttkrp_rows_kernel", "nnf_xht_kernel", "nnf_hals_quad_kernel"]}
+        "D": ["nnf_mu_left_kernel", "nnf_mttkrp_rows_kernel", "nnf_xht_kernel", "nnf_hals_wave_kernel"]}
 for cfg in configs:
     O = os.path.join(G, f"prof_{cfg}")
     if not os.path.isdir(O):

@@ -232,7 +232,7 @@ int nnf_mu_ratio_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t
 /* Deep KL-NMF (deep_nmf.py:84-113, update_rules/deep_mu.py:8-14), the three device pieces of deep_KL_mu:
  *   nnf_mu_left_num_f32   num[k,i] = sum_j (X[i,j]/(UV)[i,j]) V[k,j]  -- the raw KL numerator of the left update (the fused
  *                         kernel of nnf_mu_left_f32 without its division by rowsum(V)); b = U .* num  (deep_mu.py:10); r <= 64;
- *   nnf_small_gemm_f32    out[p x cols] = A[p x q] B[q x cols], p * q <= 16384 (A staged whole in LDS) -- (W_{l+1} H_{l+1})^T = H_{l+1}^T W_{l+1}^T
+ *   nnf_small_gemm_f32    out[p x cols] = A[p x q] B[q x cols], q <= 2048 (eight rows of A at a time in LDS) -- (W_{l+1} H_{l+1})^T = H_{l+1}^T W_{l+1}^T
  *                         (deep_nmf.py:93,109), also the rank-sized links of the NTD contraction chains (ntd.py:539-557);
  *   nnf_deep_kl_apply_f32 out[k,i] = max(1e-12, (b/lambda) / (W0(b exp(a/lambda)/lambda) + 1e-12)),  b = F .* num,
  *                         a[k,i] = hsum_f64[k] - lambda log(WHnext[k,i])   (deep_mu.py:9-12; hsum = row sums of H_l, i.e.

@@ -299,20 +299,40 @@ __device__ __forceinline__ void wave_comm_loop(const hals_args& a, wave_ctl* ctl
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------------
-// a.Gp: image (prep kernel), a.dinv: 128 floats.  snap: global scratch [ncols][WAVE_SNAP][64 RL] floats.
+// a.Gp = UtU (r x r, row stride ldg), a.Gs = the second Gram of a Hadamard pair or NULL: every workgroup builds its own LDS
+// image of G' by columns from them (a few Gram entries per thread; a preparation launch of its own was 5-6 us in front of a
+// 17 us solve at the NTF shapes).  snap: global scratch [ncols][WAVE_SNAP][64 RL] floats.
 // CPW: columns per compute wave (2 when one column per wave would need more workgroups than the chip holds at once).
 template <int RL, int RU, int CPW>
-__global__ __launch_bounds__(1024) void nnf_hals_wave_kernel(hals_args a, float* __restrict__ snap) {
+__global__ __launch_bounds__(1024) void nnf_hals_wave_kernel(hals_args a, int64_t ldg, float* __restrict__ snap) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     constexpr int W = 64 * RL;
     wave_ctl* ctl = reinterpret_cast<wave_ctl*>(wlds + (size_t)RU * W);
     const int NW = (blockDim.x >> 6) - WAVE_COMM;         // compute waves; waves NW .. NW+3 are the communication waves
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nblocks = gridDim.x;
-    for (int e = threadIdx.x; e < RU * W / 4; e += blockDim.x)
-        reinterpret_cast<f32x4*>(wlds)[e] = reinterpret_cast<const f32x4*>(a.Gp)[e];
+    auto gram = [&](int i, int k) -> float {              // UtU[i][k] as stored (rows: see the preparation kernel's note)
+        const float g = a.Gp[(int64_t)i * ldg + k];
+        return a.Gs ? g * a.Gs[(int64_t)i * ldg + k] : g;
+    };
+    for (int e = threadIdx.x; e < RU * W; e += blockDim.x) {
+        const int k = e / W, c = e - k * W;
+        const int i = (RL == 2) ? ((c >> 1) + 64 * (c & 1)) : c;
+        float val = 0.f;
+        if (k < a.r && i < a.r) {
+            const float d = gram(i, i);
+            if (d != 0.f) val = gram(i, k) * (float)(1.0 / (double)d);
+        }
+        wlds[e] = val;
+    }
     for (int e = threadIdx.x; e < (int)(sizeof(wave_ctl) / 8); e += blockDim.x)
         reinterpret_cast<unsigned long long*>(ctl)[e] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {            // (rewritten by this same thread at the end)
+        a.status[NNF_HALS_ST_EPS] = 1.0;
+        a.status[NNF_HALS_ST_CNT] = 1.0;
+        a.status[NNF_HALS_ST_EPS0] = 0.0;
+        a.status[NNF_HALS_ST_ERR] = 0.0;
+    }
     __syncthreads();                                      // the only barrier: image and control block are in LDS
     if (w >= NW) {
         wave_comm_loop(a, ctl, NW, w - NW, lane, nblocks);
@@ -331,7 +351,11 @@ __global__ __launch_bounds__(1024) void nnf_hals_wave_kernel(hals_args a, float*
         for (int h = 0; h < RL; ++h) {
             const int row = lane + 64 * h;
             const bool in = valid && row < a.r;
-            const float di = a.dinv[row];                 // 0: zero diagonal or padding row (128 entries are always there)
+            float di = 0.f;                               // 0: zero diagonal or padding row
+            if (row < a.r) {
+                const float d = gram(row, row);
+                di = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;
+            }
             dead[c][h] = !(in && di != 0.f);
             v[c][h] = in ? a.Vsrc[(int64_t)row * a.ldvs + col] : 0.f;
             const float bm = in ? a.UtM[(int64_t)row * a.ldm + col] : 0.f;
@@ -468,7 +492,7 @@ size_t nnf_hals_wave_gram_floats(int r) { return (size_t)wave_ru(r) * 64 * wave_
 size_t nnf_hals_wave_snap_floats(int r, int64_t ncols) { return (size_t)ncols * WAVE_SNAP * 64 * wave_rl(r); }
 
 template <int RL, int RU, int CPW>
-static int wave_launch(const hals_args& a, float* snap, int nblocks, int nw, size_t lds, hipStream_t st, int* occupancy) {
+static int wave_launch(const hals_args& a, int64_t ldg, float* snap, int nblocks, int nw, size_t lds, hipStream_t st, int* occupancy) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_wave_kernel<RL, RU, CPW>),
@@ -482,17 +506,17 @@ static int wave_launch(const hals_args& a, float* snap, int nblocks, int nw, siz
         *occupancy = nb;
         return NNF_OK;
     }
-    hipLaunchKernelGGL((nnf_hals_wave_kernel<RL, RU, CPW>), dim3(nblocks), dim3(64 * (nw + WAVE_COMM)), lds, st, a, snap);
+    hipLaunchKernelGGL((nnf_hals_wave_kernel<RL, RU, CPW>), dim3(nblocks), dim3(64 * (nw + WAVE_COMM)), lds, st, a, ldg, snap);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
 }
-static int wave_dispatch(int r, int cpw, const hals_args& a, float* snap, int nblocks, int nw, hipStream_t st, int* occupancy) {
+static int wave_dispatch(int r, int cpw, const hals_args& a, int64_t ldg, float* snap, int nblocks, int nw, hipStream_t st, int* occupancy) {
     const size_t lds = wave_lds(r);
     switch (wave_ru(r)) {
 #define WAVE_CASE(N)                                                                                               \
     case N:                                                                                                        \
-        return cpw == 1 ? wave_launch<(N <= 64 ? 1 : 2), N, 1>(a, snap, nblocks, nw, lds, st, occupancy)           \
-                        : wave_launch<(N <= 64 ? 1 : 2), N, 2>(a, snap, nblocks, nw, lds, st, occupancy);
+        return cpw == 1 ? wave_launch<(N <= 64 ? 1 : 2), N, 1>(a, ldg, snap, nblocks, nw, lds, st, occupancy)      \
+                        : wave_launch<(N <= 64 ? 1 : 2), N, 2>(a, ldg, snap, nblocks, nw, lds, st, occupancy);
         WAVE_CASE(8) WAVE_CASE(16) WAVE_CASE(24) WAVE_CASE(32) WAVE_CASE(40) WAVE_CASE(48) WAVE_CASE(56) WAVE_CASE(64)
         WAVE_CASE(72) WAVE_CASE(80) WAVE_CASE(88) WAVE_CASE(96) WAVE_CASE(104) WAVE_CASE(112) WAVE_CASE(120) WAVE_CASE(128)
 #undef WAVE_CASE
@@ -511,7 +535,7 @@ static int wave_plan(nnf_ctx* ctx, int r, int64_t ncols, int max_blocks_cap) {
         if (need > 64 * WAVE_NP || need > max_blocks_cap) continue;
         int nb = 0;
         hals_args dummy{};
-        const int rc = wave_dispatch(r, cpw, dummy, nullptr, 0, nw, nullptr, &nb);
+        const int rc = wave_dispatch(r, cpw, dummy, 0, nullptr, 0, nw, nullptr, &nb);
         if (getenv("NNF_HALS_DEBUG"))
             fprintf(stderr, "[nnf hals wave] r=%d ncols=%lld nw=%d cpw=%d need=%lld occupancy=%d rc=%d lds=%zu\n", r, (long long)ncols,
                     nw, cpw, (long long)need, nb, rc, wave_lds(r));
@@ -527,25 +551,27 @@ bool nnf_hals_wave_fits(nnf_ctx* ctx, int r, int64_t ncols, int max_blocks_cap) 
 // Solve mode only (a.mode == 0, a.sweep0 == 0).
 int nnf_hals_wave_run(nnf_ctx* ctx, const float* UtU, const float* UtU2, int64_t ldg, float* Gw, float* snap, unsigned* counter,
                       hals_args a, int* nblocks_out, hipStream_t st) {
-    const int ru = wave_ru(a.r), rl = wave_rl(a.r);
-    float* dinv = Gw + (size_t)ru * 64 * rl;
-    hipLaunchKernelGGL(nnf_hals_prep_wave_kernel, dim3(ru), dim3(64), 0, st, UtU, UtU2, ldg, a.r, rl, Gw, dinv, counter, a.status);
-    NNF_CHECK_LAUNCH();
     if (a.max_sweeps == 0) {
+        // nothing to sweep: only the status defaults (the preparation kernel writes them) and V_out := V_in
+        const int ru = wave_ru(a.r), rl = wave_rl(a.r);
+        hipLaunchKernelGGL(nnf_hals_prep_wave_kernel, dim3(ru), dim3(64), 0, st, UtU, UtU2, ldg, a.r, rl, Gw, Gw + (size_t)ru * 64 * rl,
+                           counter, a.status);
+        NNF_CHECK_LAUNCH();
         if (a.Vsrc != a.V && hipMemcpy2DAsync(a.V, (size_t)a.ldv * 4, a.Vsrc, (size_t)a.ldvs * 4, (size_t)a.ncols * 4, (size_t)a.r,
                                                hipMemcpyDeviceToDevice, st) != hipSuccess)
             return NNF_ERR_LAUNCH;
         return NNF_OK;
     }
-    a.Gp = Gw;
-    a.dinv = dinv;
+    a.Gp = UtU;              // the kernel builds its image from the Gram(s) itself
+    a.Gs = UtU2;
+    a.dinv = nullptr;
     const int cpw = wave_plan(ctx, a.r, a.ncols, NNF_HALS_MAX_BLOCKS);
     if (cpw < 1) return NNF_ERR_UNSUPPORTED;
     const int nw = wave_nw(a.ncols);
     const int nblocks = (int)nnf_cdiv(a.ncols, (int64_t)nw * cpw);
     *nblocks_out = nblocks;
     nnf_probe(ctx, NNF_PROBE_HALS, 0, st);
-    const int rc = wave_dispatch(a.r, cpw, a, snap, nblocks, nw, st, nullptr);
+    const int rc = wave_dispatch(a.r, cpw, a, ldg, snap, nblocks, nw, st, nullptr);
     nnf_probe(ctx, NNF_PROBE_HALS, 1, st);
     return rc;
 }

@@ -463,8 +463,7 @@ int nnf_small_gemm_launch(const float* A, int64_t lda, int p, int q, const float
 extern "C" int nnf_small_gemm_f32(nnf_ctx* ctx, const float* A, int64_t lda, int p, int q, const float* B, int64_t ldb,
                                   int64_t cols, float* out, int64_t ldo, void* stream) {
     if (!ctx || !A || !B || !out || p < 1 || q < 1 || cols < 1 || lda < q || ldb < cols || ldo < cols) return NNF_ERR_ARG;
-    if ((int64_t)p * q > 16384) return NNF_ERR_UNSUPPORTED;
-    return nnf_small_gemm_launch(A, lda, p, q, B, ldb, cols, out, ldo, 1, 0, 0, (hipStream_t)stream);
+    return nnf_small_gemm_launch(A, lda, p, q, B, ldb, cols, out, ldo, 1, 0, 0, (hipStream_t)stream);   // (q <= 2048: 8 rows of A in LDS)
 }
 
 // deep_KL_mu (deep_mu.py:8-14), element-wise tail:  a = hsum[k] - lambda*log(WHnext[k,i]),  b = F[k,i]*num[k,i],

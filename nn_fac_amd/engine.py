@@ -374,7 +374,7 @@ class Engine:
         return O
 
     def small_gemm(self, A, B, out=None):
-        """A (p x q, p * q <= 16384) @ B (q x cols) -> p x cols."""
+        """A (p x q, q <= 2048) @ B (q x cols) -> p x cols: a rank-sized left operand against a wide matrix."""
         _chk2d(A, "small_gemm A"), _chk2d(B, "small_gemm B")
         p, q = A.shape
         if B.shape[0] != q:

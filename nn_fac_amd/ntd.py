@@ -125,13 +125,23 @@ def _normalize_core(core, mode_core_norm):
     return torch.movedim(unf * scale.view(shape), 0, mode_core_norm).contiguous()
 
 
-def _core_mode_dots(core, mats, skip=None):
-    """tl.tenalg.multi_mode_dot(core, mats, skip) for a core-sized tensor (mats[i]: new_dim x old_dim)."""
+def _mode_mul(eng, X, A, axis):
+    """X x_axis A for a rank-sized operand A (p x q, q = X.shape[axis]) -- tl.tenalg.mode_dot(X, A, axis): the contraction is
+    nnf_small_gemm_f32 on the matrix view with `axis` first (out = A @ unfold(X, axis)); moving the axis there and back is a
+    copy, not arithmetic."""
+    Xm = torch.movedim(X, axis, 0).contiguous()
+    out = eng.small_gemm(A.contiguous(), Xm.view(Xm.shape[0], -1))
+    return torch.movedim(out.view([A.shape[0]] + list(Xm.shape[1:])), 0, axis).contiguous()
+
+
+def _core_mode_dots(eng, core, mats, skip=None):
+    """tl.tenalg.multi_mode_dot(core, mats, skip) (ntd.py:539, :672) -- a chain of rank-sized mode products (mats[i]: new_dim x old_dim),
+    every link a nnf_small_gemm_f32 launch."""
     out = core
     for i, M in enumerate(mats):
         if i == skip:
             continue
-        out = torch.movedim(torch.tensordot(M, out, dims=([1], [i])), 0, i)
+        out = _mode_mul(eng, out, M, i)
     return out
 
 
@@ -190,8 +200,11 @@ def _one_ntd_step_dev(st, core_in, Ft_in, sparsity_coefficients, fixed_modes, no
             if i != mode:
                 grams[i] = eng.gram(Ft[i])                                    # elemprod (ntd.py:534-537)
         others = [i for i in range(N) if i != mode]
-        tmp = _core_mode_dots(core, [grams[i] if i != mode else None for i in range(N)], skip=mode)
-        UtU = torch.tensordot(tmp, core, dims=(others, others)).contiguous()  # r_n x r_n (ntd.py:544)
+        tmp = _core_mode_dots(eng, core, [grams[i] if i != mode else None for i in range(N)], skip=mode)
+        # UtU = <tmp, core> over the other modes (ntd.py:544) = unfold(tmp, mode) unfold(core, mode)^T: the X H^T kernel on the two
+        # r_n x prod(other ranks) unfoldings
+        unf = lambda t: torch.movedim(t, mode, 0).reshape(t.shape[mode], -1).contiguous()   # noqa: E731
+        UtU = eng.xht(unf(core), unf(tmp))                                                  # r_n x r_n
         # temp = T x_{i != mode} F_i^T (ntd.py:550).  The pass over T contracts its first axis (W^T X kernel; shared by all
         # modes but the first) or, for mode 0, its last one (X H^T kernel); what follows works on a tensor I/r times smaller:
         # the modes above `mode` are last when their turn comes (taken in decreasing order, each result moves to the front),
@@ -264,7 +277,7 @@ def _one_ntd_step_dev(st, core_in, Ft_in, sparsity_coefficients, fixed_modes, no
     # itself for a near-exact fit (tools/stress_tensor.py: 1e-2 ... 2e-1 relative error on normalised costs of 1e-6).  One
     # streaming pass over T against the mode-0 matrix form (the cost kernel, product never materialised) is exact to ~1e-6
     # relative and costs ~1 % of the iteration.
-    eng.frob_resid(st.t0, Ft[0], _core_expand_mode0(core, Ft), out=cost)
+    eng.frob_resid(st.t0, Ft[0], _core_expand_mode0(eng, core, Ft), out=cost)
     sparsity_error = None
     for index, sp in enumerate(sparsity_coefficients):
         if sp:
@@ -281,13 +294,22 @@ def _one_ntd_step_dev(st, core_in, Ft_in, sparsity_coefficients, fixed_modes, no
     return core, Ft, nstat
 
 
-def _core_expand_mode0(core, Ft):
-    """unfold(core x_1 F_1 x_2 F_2 ..., 0): the r_0 x prod(I_1..) right operand of the mode-0 matrix problem (core-width
-    GEMMs; the result is r_0 / I_0 of the tensor's size)."""
+def _core_expand_mode0(eng, core, Ft, st=None):
+    """unfold(core x_1 F_1 x_2 F_2 ..., 0): the r_0 x prod(I_1..) right operand of the mode-0 matrix problem (ntd.py:635-639,
+    :672): rank-sized mode products, nnf_small_gemm_f32 each; the result is r_0 / I_0 of the tensor's size.  With `st` the result
+    is remembered together with the operands it was made from: the cost at the end of an MU iteration and the mode-0 update
+    that opens the next one expand the SAME core with the SAME factors."""
+    if st is not None:
+        hit = getattr(st, "_expand0", None)
+        if hit is not None and hit[0] is core and len(hit[1]) == len(Ft) - 1 and all(a is b for a, b in zip(hit[1], Ft[1:])):
+            return hit[2]
     w = core
     for i in range(core.dim() - 1, 0, -1):
-        w = torch.movedim(torch.tensordot(w, Ft[i], dims=([i], [0])), -1, i)
-    return w.reshape(w.shape[0], -1).contiguous()
+        w = _mode_mul(eng, w, Ft[i].t(), i)
+    w = w.reshape(w.shape[0], -1).contiguous()
+    if st is not None:
+        st._expand0 = (core, tuple(Ft[1:]), w)
+    return w
 
 
 def _mu_tensorial_dev(st, core, Ft, beta):
@@ -297,7 +319,7 @@ def _mu_tensorial_dev(st, core, Ft, beta):
     N = st.nway
     if beta < 0:
         raise err.InvalidArgumentValue("Invalid value for beta: negative one.") from None
-    V0 = _core_expand_mode0(core, Ft)
+    V0 = _core_expand_mode0(eng, core, Ft)
     num, den, dvec = eng.mu_right_accum(st.t0, Ft[0], V0, beta)
     dims = [int(d) for d in st.T.shape[1:]]
 
@@ -335,16 +357,19 @@ def _one_ntd_step_mu_dev(st, core_in, Ft_in, beta, fixed_modes, normalize, mode_
     Ft = list(Ft_in)
     for mode in [m for m in range(N) if m not in fixed_modes]:
         # V = unfold(core x_{i != mode} F_i, mode): r_mode x prod(other dims), core-width GEMMs
-        mats = [Ft[i].t() if i != mode else None for i in range(N)]
-        V = torch.movedim(_core_mode_dots(core, mats, skip=mode), mode, 0)
-        V = V.reshape(V.shape[0], -1).contiguous()
+        if mode == 0:
+            V = _core_expand_mode0(eng, core, Ft, st)      # (what the previous iteration's cost expanded, if nothing changed)
+        else:
+            mats = [Ft[i].t() if i != mode else None for i in range(N)]
+            V = torch.movedim(_core_mode_dots(eng, core, mats, skip=mode), mode, 0)
+            V = V.reshape(V.shape[0], -1).contiguous()
         # mu_betadivmin(F, V, unfold(T, mode)) (ntd.py:672) on the TRANSPOSED problem unfold^T ~ V^T F^T: the unfolding is
         # short and fat (I_mode rows), its transpose gives the streaming kernel prod(other dims) rows to split over
         Ft[mode] = eng.mu_right(st.unfolded_t(mode), V, Ft[mode], beta)
     core = _mu_tensorial_dev(st, core, Ft, beta)
     if normalize[-1]:
         core = _normalize_core(core, mode_core_norm)
-    eng.betadiv(st.t0, Ft[0], _core_expand_mode0(core, Ft), beta, out=st.block[st.cost_at:st.cost_at + 1])
+    eng.betadiv(st.t0, Ft[0], _core_expand_mode0(eng, core, Ft, st), beta, out=st.block[st.cost_at:st.cost_at + 1])
     return core, Ft
 
 

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("tool,seed,cases", [("stress_kernels.py", 0, 60), ("stress_tensor.py", 1, 60),
-                                             ("stress_parity.py", 2, 60), ("stress_parity.py", 81, 60)])
+                                             ("stress_parity.py", 2, 60), ("stress_parity.py", 81, 60), ("stress_parity.py", 5, 60),
+                                             ("stress_hals.py", 0, 150), ("stress_hals.py", 3, 150)])
 def test_randomised_sweep(built_lib, tool, seed, cases):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(seed), str(cases)], capture_output=True,
                          text=True, timeout=600)

@@ -17,7 +17,13 @@ numbers, never from the device's:
   shapes the 5e-4 was calibrated on sit at 1e2 ... 1e4), the fp32 rounding of the Gram / cross terms (~1e-7 relative) is
   amplified into the factors by that number: factors are compared with LOOSE, the cost -- which stays well determined --
   keeps its bound.  Typical: rank = the smaller dimension (seed 0 case 55), rank 128 of a 256 x 257 matrix of exactly that
-  rank (seed 81 case 37: kappa 3e6, relV 1.4e-3 at equal sweep counts, cost 8.5e-6).
+  rank (seed 81 case 37: kappa 3e6, relV 1.4e-3 at equal sweep counts, cost 8.5e-6).  Beyond 1e7 the bound is 5e-3 (seeds 5 /
+  6: kappa 1.3e8 / 1.8e8 give relV 2.1e-3 / 2.2e-3 with the wave-per-column V-side solve and 1.8e-3 / 1.7e-3 with the
+  four-lanes-per-column one, at equal sweep counts, costs to 5e-5).
+* exact fits -- when the oracle's first-sweep sum of squared steps of a solve is exactly 0 (a 1 x 1 problem after its first
+  iteration: seed 5 case 59) the reference runs to maxiter (`eps >= delta * 0`), while fp32 leaves rounding noise in eps0 and
+  the rule stops after two sweeps: counts are not compared from that solve on; costs are compared with an absolute floor of
+  1e-9 ||X||^2 (a cost that IS rounding noise has no relative accuracy).
 """
 import os, sys
 import numpy as np
@@ -69,13 +75,17 @@ for c in range(cases):
     except Exception as e:   # noqa: BLE001
         print("CASE", c, (m, n, r, rule, beta, sp, nz), "raised", type(e).__name__, e); bad += 1; continue
     eu, ev = rel(U, Uo), rel(V, Vo)
-    ec = max(abs(a - b) / max(abs(b), 1e-30) for a, b in zip(costs, co))
+    ec = max(abs(a - b) / max(abs(b), 1e-9 * float(np.sum(X.astype(np.float64) ** 2))) for a, b in zip(costs, co))
     tol_f, tol_c, why = (TOL_HALS if rule == "hals" else TOL_MU), TOL_COST, ""
     counts_ok = True
     if rule == "hals":
         kap = max(kappa(Uo.T @ Uo), kappa(Vo @ Vo.T))
         if kap > KAPPA:
-            tol_f, why = LOOSE, f"ill-conditioned: kappa {kap:.1e}"
+            tol_f, why = (LOOSE if kap <= 1e7 else 5e-3), f"ill-conditioned: kappa {kap:.1e}"
+        exact = next((i for i, lg in enumerate(solve_logs) if lg and lg[0] == 0.0), None)
+        if exact is not None and sw[:exact] == swo[:exact]:
+            sw, swo = sw[:exact], swo[:exact]
+            why = (why + "; " if why else "") + f"exact fit from solve {exact} on (eps0 = 0 in fp64): counts not compared"
         if sw != swo:
             j = next(i for i, (a, b) in enumerate(zip(sw, swo)) if a != b)
             log, s = solve_logs[j], min(sw[j], swo[j])          # the oracle's sums of that solve; s = the earlier stop

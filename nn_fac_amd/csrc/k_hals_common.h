@@ -274,24 +274,38 @@ __device__ __forceinline__ bool hals_sum_collect1(const hals_sync& sy, double nd
     static_assert(NT == 256 && HALS_PF == 2, "two granule pairs per thread cover nblocks <= 512");
     const unsigned tag = sy.epoch * 1024u + (unsigned)c;
     const unsigned long long* base = reinterpret_cast<const unsigned long long*>(sy.sslots) + (size_t)c * nblocks * 2;
-    double v = 0.0;
+    // fast path: both pairs arrived with the prefetch -- two compares per pair, ONE wave-uniform test, no exec-mask branches;
+    // a granule that is not there yet sends the whole wave through the re-read loop (rare; bounded)
+    unsigned long long g0[HALS_PF], g1[HALS_PF];
+    bool want[HALS_PF], need = false;
 #pragma unroll
     for (int i = 0; i < HALS_PF; ++i) {
-        const int b = (int)threadIdx.x + NT * i;
-        if (b < nblocks) {
-            unsigned long long g0 = (pf.s == c) ? pf.g0[i] : 0ull, g1 = (pf.s == c) ? pf.g1[i] : 0ull;
-            if (!(HALS_DBG & 1) && !((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag)) {   // not there yet: re-read (bounded)
+        want[i] = (int)threadIdx.x + NT * i < nblocks;
+        g0[i] = (pf.s == c) ? pf.g0[i] : 0ull;
+        g1[i] = (pf.s == c) ? pf.g1[i] : 0ull;
+        need = need || (want[i] && !((unsigned)(g0[i] >> 32) == tag && (unsigned)(g1[i] >> 32) == tag));
+    }
+    if (!(HALS_DBG & 1) && __builtin_expect(__ballot(need) != 0ull, 0)) {
+#pragma unroll 1
+        for (int i = 0; i < HALS_PF; ++i) {
+            const int b = (int)threadIdx.x + NT * i;
+            unsigned long long a0 = i == 0 ? g0[0] : g0[HALS_PF - 1], a1 = i == 0 ? g1[0] : g1[HALS_PF - 1];
+            if (b < nblocks) {
                 unsigned spins = 0;
-                do {
+                while (!((unsigned)(a0 >> 32) == tag && (unsigned)(a1 >> 32) == tag)) {
                     if (spins > 0) __builtin_amdgcn_s_sleep(1);
                     if (++spins > HALS_SPIN_LIMIT) { *lds_flag = 0u; break; }
-                    g0 = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    g1 = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } while (!((unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag));
+                    a0 = __hip_atomic_load(base + 2 * (size_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a1 = __hip_atomic_load(base + 2 * (size_t)b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
-            v += __builtin_bit_cast(double, (g1 << 32) | (g0 & 0xffffffffull));
+            if (i == 0) { g0[0] = a0; g1[0] = a1; } else { g0[HALS_PF - 1] = a0; g1[HALS_PF - 1] = a1; }
         }
     }
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < HALS_PF; ++i)
+        v += want[i] ? __builtin_bit_cast(double, (g1[i] << 32) | (g0[i] & 0xffffffffull)) : 0.0;
     v = nnf_wave_sum_f64(v);
     nd = nnf_wave_sum_f64(nd);
     constexpr int nw = NT / 64;

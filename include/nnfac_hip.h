@@ -173,6 +173,17 @@ int nnf_hals_sweeps_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float
                         int r, int64_t ncols, int nsweeps, float sparsity, unsigned flags, double* nodelta_f64,
                         float* snapshots, int64_t snap_stride, void* stream);
 
+/* Row-sharded solves that normalise the SHARDED factor (nmf(normalize=[True, .]) over several ranks): the row
+ * norm of nnls.py:179-185 runs over the columns of all ranks, once per row update, so the host walks the rows:
+ *   nnf_hals_row_update_f32  row k of V (r x ncols: this rank's columns) gets the update of nnls.py:162-170;
+ *                            out2_f64 = {sum of squared steps, sum of squares of the updated row} over the local columns
+ *   (the caller all-reduces the two doubles)
+ *   nnf_hals_row_scale_f32   row k /= sqrt(*normsq_f64), or := 1/sqrt(ncols_total) when the norm is 0 (nnls.py:181-185) */
+int nnf_hals_row_update_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V, int64_t ldv, int r,
+                            int64_t ncols, int k, float sparsity, unsigned flags, double* out2_f64, void* stream);
+int nnf_hals_row_scale_f32(nnf_ctx* ctx, float* V, int64_t ldv, int64_t ncols, int k, const double* normsq_f64, int64_t ncols_total,
+                           void* stream);
+
 /* Columns the register-resident sweep kernel of rank r keeps on this device (one lane per column, all workgroups co-resident).
  * More columns than that: nnf_hals_solve_f32 / nnf_hals_sweeps_f32 stream the factor through HBM once per sweep and
  * nnf_hals_sweeps_f32 refuses `snapshots`; a caller that runs blind chunks of sweeps (the row-sharded protocol of nnls.py:156, or

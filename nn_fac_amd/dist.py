@@ -208,6 +208,36 @@ def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01
     return eps, done + 1, eps0
 
 
+def sharded_hals_solve_rownorm(eng, cross, gram, F, group, budget=100, delta=0.01, sparsity=None):
+    """hals_nnls_acc(..., normalize=True) on the local columns F (r x m_local) of a factor whose columns are spread over the
+    ranks: the row norm of nnls.py:179-185 runs over ALL columns, once per row update, so the rows are walked from the host --
+    row update on the local columns (Engine.hals_row_update), ONE all-reduce of {sum of squared steps, sum of squares of the
+    row}, scaling (Engine.hals_row_scale) -- and the stopping rule of nnls.py:156 is applied once per sweep.  r collectives
+    per sweep: correct and slow; the option is not on any BASELINE configuration.  Returns (eps, cnt, eps0) like
+    sharded_hals_solve."""
+    r = int(F.shape[0])
+    ncols_total = torch.tensor([int(F.shape[1])], dtype=torch.int64, device=F.device)
+    if group is not None and dist.get_world_size(group) > 1:
+        dist.all_reduce(ncols_total, op=dist.ReduceOp.SUM, group=group)
+    ncols_total = int(ncols_total.item())
+    eps0, eps, done = 0.0, 1.0, 0
+    acc = torch.zeros(1, dtype=torch.float64, device=F.device)
+    while done < budget:
+        acc.zero_()
+        for k in range(r):
+            st = eng.hals_row_update(cross, gram, F, k, sparsity=sparsity)
+            allreduce_(st, group)
+            eng.hals_row_scale(F, k, st[1:2], ncols_total)
+            acc.add_(st[0:1])
+        eps = float(acc.item())                    # one host round trip per sweep (nnls.py:187-196)
+        if done == 0:
+            eps0 = eps
+        done += 1
+        if not (eps >= delta * eps0):
+            break
+    return eps, done + 1, eps0
+
+
 ERR_BEFORE_WINDOW, ERR_NOT_STOPPED = 3, 4      # status codes of nnf_hals_stop_restore_f32
 
 

@@ -244,6 +244,24 @@ class Engine:
                                                 self._stream()), "nnf_hals_sweeps_f32")
         return nd[:int(nsweeps)]
 
+    def hals_row_update(self, UtM, UtU, V, k, sparsity=None, out=None):
+        """Row k of V (this rank's columns) gets the update of nnls.py:162-170, in place; returns a 2-element float64 device
+        tensor {sum of squared steps, sum of squares of the updated row} (row-sharded solves with normalize, dist.py)."""
+        _chk2d(UtM, "hals UtM"), _chk2d(UtU, "hals UtU"), _chk2d(V, "hals V")
+        r, ncols = V.shape
+        o = out if out is not None else torch.empty(2, dtype=torch.float64, device=V.device)
+        _lib.check(self.lib.nnf_hals_row_update_f32(self.ctx, _ptr(UtM), _ld(UtM), _ptr(UtU), _ld(UtU), _ptr(V), _ld(V), r, ncols,
+                                                    int(k), float(sparsity or 0.0), self._hals_flags(sparsity, False, False), _ptr(o),
+                                                    self._stream()), "nnf_hals_row_update_f32")
+        return o
+
+    def hals_row_scale(self, V, k, normsq, ncols_total):
+        """Row k of V /= sqrt(normsq[0]) (a float64 device scalar), or := 1 / sqrt(ncols_total) when it is 0 (nnls.py:181-185)."""
+        _chk2d(V, "hals V")
+        _lib.check(self.lib.nnf_hals_row_scale_f32(self.ctx, _ptr(V), _ld(V), V.shape[1], int(k), _ptr(normsq), int(ncols_total),
+                                                   self._stream()), "nnf_hals_row_scale_f32")
+        return V
+
     def hals_resident_columns(self, r):
         """Columns the register-resident sweep kernel of rank r holds on this device (blind chunks with snapshots, and fast
         sweeps at all, need column blocks of at most this size: dist.sharded_hals_solve)."""

@@ -544,10 +544,6 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
     run_steps' hooks: `before_u_solve` / `before_v_solve` are called right before the U-side / V-side HALS solve is
     launched; with `skip_cost` the cost line is left to the caller (who overlaps it with the next V-side solve)."""
     sharded = _dist.is_sharded(group)
-    if sharded:
-        if update_rule == "hals" and normalize[0]:
-            raise NotImplementedError("row-sharded HALS runs cannot normalise the sharded factor (a grid-wide reduction per "
-                                      "row update across ranks)")
     if update_rule not in ["hals", "mu"]:
         raise err.InvalidArgumentValue(f"Invalid update rule: {update_rule}") from None
     if update_rule == "hals" and beta != 2:
@@ -580,7 +576,12 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                 budget_u = _timed_budget(eng, ws.VMt, ws.G, Ut, sparsity_coefficients[0], False, timer, group)
             if sharded:
                 Ut = Ut_in.clone()                  # the chunked sharded protocols work in place (nmf.py:415: from U_in^T)
-            if sharded and deterministic and hasattr(eng, "hals_stop_restore") and not ws.sync_next and ws.async_sharded \
+            if sharded and normalize[0]:
+                # the row norm runs over the columns of all ranks, once per row update: rows walked from the host (dist.py)
+                eps, cnt, eps0 = _dist.sharded_hals_solve_rownorm(eng, ws.VMt, ws.G, Ut, group, budget=budget_u,
+                                                                  delta=HALS_INNER["delta"], sparsity=sparsity_coefficients[0])
+                ws.block[8 * nstat:8 * nstat + 4] = torch.tensor([eps, cnt, eps0, 0.0], dtype=torch.float64)
+            elif sharded and deterministic and hasattr(eng, "hals_stop_restore") and not ws.sync_next and ws.async_sharded \
                     and ws.async_ready:
                 # no host round trip: blind chunk + all-reduce + device-side replay of the stopping rule; a missed guess
                 # shows in the status block and run_steps redoes the iteration through the branch below

@@ -115,6 +115,25 @@ class OracleEngine:
         Y.copy_(torch.from_numpy(np.einsum('ijk,kr->rij', T.numpy(), F[2])))
         return Y
 
+    def hals_row_update(self, UtM, UtU, V, k, sparsity=None, out=None):
+        sp = 0.0 if sparsity is None else sparsity
+        d = float(UtU[k, k])
+        nd = 0.0
+        if d != 0:
+            step = torch.maximum((UtM[k] - UtU[k] @ V - sp) / d, -V[k])
+            V[k] += step
+            nd = float(step @ step)
+        o = torch.tensor([nd, float(V[k] @ V[k])], dtype=torch.float64)
+        return o if out is None else out.copy_(o)
+
+    def hals_row_scale(self, V, k, normsq, ncols_total):
+        nsq = float(normsq[0])
+        if nsq != 0:
+            V[k] /= math.sqrt(nsq)
+        else:
+            V[k] = 1.0 / math.sqrt(ncols_total)
+        return V
+
     def hals_stop_restore(self, sums, head, budget, delta, V, snapshots, status):
         s = sums.tolist()
         stop = next((j for j, v in enumerate(s) if not (v >= delta * s[0]) or j + 1 >= budget), None)

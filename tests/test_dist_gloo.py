@@ -21,7 +21,8 @@ import nnfac_oracle as orc
 from engine_double import OracleEngine  # noqa: E402
 
 
-def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2, guess=(3, 5, 2), deterministic=True):
+def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2, guess=(3, 5, 2), deterministic=True,
+            normalize=(False, False)):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=nranks)
     try:
@@ -45,7 +46,7 @@ def _worker(rank, nranks, port, m, n, r, iters, sparsity, q, rule="hals", beta=2
             sweeps.extend(sw)
             return False
 
-        Ut, V = nmf_mod.run_steps(eng, ws, Xl, r, Ut, V, iters, rule, beta, sparsity, [], [False, False], deterministic, retired,
+        Ut, V = nmf_mod.run_steps(eng, ws, Xl, r, Ut, V, iters, rule, beta, sparsity, [], list(normalize), deterministic, retired,
                                   group=dist.group.WORLD)
         q.put((rank, lo, hi, Ut.numpy().T.copy(), V.numpy().copy(), costs, sweeps, (ws.async_hits, ws.async_misses)))
     finally:
@@ -92,6 +93,35 @@ def test_row_sharded_step_equals_unsharded_oracle(sparsity, guess):
         else:
             assert hits == 0 or max(sw[0::2]) <= 4        # a 5-sweep chunk cannot contain a longer solve's stop
     assert np.array_equal(res[0][4], res[1][4])           # replicated V bitwise identical across ranks
+
+
+@pytest.mark.parametrize("sparsity", [[None, None], [0.03, None]])
+def test_row_sharded_step_with_a_normalised_sharded_factor(sparsity):
+    """nmf(normalize=[True, .]) over two ranks: the norm of a row of U^T (nnls.py:179-185) runs over the columns of BOTH ranks,
+    once per row update -- dist.sharded_hals_solve_rownorm walks the rows with one all-reduce each.  Factors, costs and sweep
+    counts of the unsharded oracle (round 2 raised NotImplementedError here)."""
+    m, n, r, iters, nranks = 151, 30, 5, 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(k, nranks, port, m, n, r, iters, sparsity, q, "hals", 2, (3, 5, 2), True, (True, False)))
+             for k in range(nranks)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(nranks))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    X, U0, V0 = orc.synth_nmf(m, n, r, seed=1, dtype=np.float64)
+    sw = []
+    U, V, costs, _ = orc.compute_nmf(X, r, U0, V0, n_iter_max=iters, tol=0, update_rule="hals", sparsity_coefficients=list(sparsity),
+                                     normalize=[True, False], return_costs=True, deterministic=True, sweeps=sw)
+    np.testing.assert_allclose(np.concatenate([x[3] for x in res], axis=0), U, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.linalg.norm(U, axis=0), 1.0, rtol=1e-12)       # (the columns of U are what got normalised)
+    for rank, lo, hi, Ul, Vl, cl, sl, _ in res:
+        np.testing.assert_allclose(Vl, V, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(cl, costs, rtol=1e-9)
+        assert sl == sw
 
 
 @pytest.mark.parametrize("beta", [1, 2, 0.5, 3])

@@ -488,15 +488,16 @@ def test_mu_right_accumulate_then_apply(eng, beta):
     assert rel(got.cpu().numpy(), want.cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 1), ("mu", 2)])
-def test_row_sharded_two_ranks_on_one_gpu(built_lib, rule, beta):
-    """Two gloo ranks sharing the GPU run the real sharded step (tools/dist_gpu_check.py) against the single-process run."""
+@pytest.mark.parametrize("rule,beta,extra", [("hals", 2, []), ("mu", 1, []), ("mu", 2, []), ("hals", 2, ["normalize"])])
+def test_row_sharded_two_ranks_on_one_gpu(built_lib, rule, beta, extra):
+    """Two gloo ranks sharing the GPU run the real sharded step (tools/dist_gpu_check.py) against the single-process run;
+    "normalize": the sharded factor is normalised (row norms across both ranks, nnf_hals_row_update_f32 / _scale_f32)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", "29533", os.path.join(root, "tools", "dist_gpu_check.py"), rule,
-                          str(beta)], capture_output=True, text=True, timeout=300, env=env)
+                          str(beta)] + extra, capture_output=True, text=True, timeout=300, env=env)
     assert "DIST_GPU_CHECK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 

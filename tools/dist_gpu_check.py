@@ -14,6 +14,7 @@ eng = get_engine("cuda:0")
 RULE = sys.argv[1] if len(sys.argv) > 1 else "hals"
 BETA = float(sys.argv[2]) if len(sys.argv) > 2 else 2
 BETA = int(BETA) if BETA == int(BETA) else BETA
+NORM = [len(sys.argv) > 3 and sys.argv[3] == "normalize", False]      # normalise the SHARDED factor (rows of U^T across both ranks)
 m, n, r, iters = 6001, 300, 20, 6
 X, U0, V0 = orc.synth_nmf(m, n, r, seed=4, dtype=np.float32)
 lo, hi = nd.shard_rows(m, rank, world)
@@ -33,17 +34,18 @@ def recorder(cs, sw):
 
 
 # the product's own outer loop (status ring, cost under the next V-side solve, fused all-reduce of the V-side terms)
-Ut, V = nm.run_steps(eng, ws, Xl, r, Ut, V, iters, RULE, BETA, [None, None], [], [False, False], True,
+Ut, V = nm.run_steps(eng, ws, Xl, r, Ut, V, iters, RULE, BETA, [None, None], [], NORM, True,
                      recorder(costs, sweeps), group=dist.group.WORLD)
 # single-process reference run of the same engine on rank 0
 if rank == 0:
     Xd, Ud, Vd = torch.from_numpy(X).cuda(), torch.from_numpy(U0.T.copy()).cuda(), torch.from_numpy(V0).cuda()
     ws1 = nm._StepBuffers(Xd, r); c1, s1 = [], []
-    Ud, Vd = nm.run_steps(eng, ws1, Xd, r, Ud, Vd, iters, RULE, BETA, [None, None], [], [False, False], True,
+    Ud, Vd = nm.run_steps(eng, ws1, Xd, r, Ud, Vd, iters, RULE, BETA, [None, None], [], NORM, True,
                           recorder(c1, s1))
     relV = float((V - Vd).norm() / Vd.norm()); relU = float((Ut - Ud[:, lo:hi]).norm() / Ud[:, lo:hi].norm())
     print("sharded sweeps", sweeps); print("single  sweeps", s1)
     print("relV %.2e relU %.2e cost rel %.2e" % (relV, relU, max(abs(a - b) / b for a, b in zip(costs, c1))))
-    assert sweeps == s1 and relV < 1e-4 and relU < 1e-4 and len(costs) == len(c1) == iters and all(abs(a - b) <= 1e-4 * b for a, b in zip(costs, c1))
+    tol = 5e-4 if NORM[0] else 1e-4      # (normalised: six iterations of 100-sweep solves, the row norms summed in another order)
+    assert sweeps == s1 and relV < tol and relU < tol and len(costs) == len(c1) == iters and all(abs(a - b) <= tol * b for a, b in zip(costs, c1))
     print("DIST_GPU_CHECK_OK")
 dist.barrier(); dist.destroy_process_group()

@@ -117,6 +117,47 @@ def test_smoke_entry(built_lib):
 MU_FRO, MU_COST = 2e-5, 1e-5
 
 
+@pytest.mark.parametrize("noise,expect_direct", [(0.3, False), (0.0, True)])
+def test_hals_cost_through_the_gram_identity_and_its_guard(built_lib, noise, expect_direct, monkeypatch):
+    """The HALS loop takes its cost from the Gram identity (nnf_nmf_gram_cost_f32: no pass over X).  On data with a real
+    residual the identity is what runs and agrees with the fp64 oracle far inside the stated 1e-3 (and with the streaming
+    kernel, NNF_COST=direct, to 1e-4); on an almost exact fit -- where ||X||^2 - 2<V,U^T X> + <U^T U, V V^T> cancels to
+    rounding noise of the fp32 cross terms -- the kernel's own error estimate flags the iterate, run_steps redoes it with the
+    streaming kernel and keeps that for the rest of the run: same costs, same factors, nothing lost."""
+    from nn_fac_amd import nmf as nmf_mod
+    from nn_fac_amd.engine import get_engine
+    rng = np.random.RandomState(7)
+    m, n, r, iters = 3000, 400, 12, 8
+    W, H = rng.rand(m, r), rng.rand(r, n)
+    X = (W @ H + noise * rng.rand(m, n)).astype(np.float32)
+    if noise:
+        U0, V0 = rng.rand(m, r).astype(np.float32), rng.rand(r, n).astype(np.float32)
+    else:           # exact low-rank data, start 1e-3 away from the factors that made it: cost / ||X||^2 ~ 1e-7 from the first iteration
+        U0, V0 = (W * (1 + 1e-3 * rng.rand(m, r))).astype(np.float32), (H * (1 + 1e-3 * rng.rand(r, n))).astype(np.float32)
+    Uo, Vo, co, _ = orc.compute_nmf(X.astype(np.float64), r, U0.astype(np.float64), V0.astype(np.float64), n_iter_max=iters,
+                                    tol=0, update_rule="hals", return_costs=True, deterministic=True)
+
+    def run():
+        dev = torch.device("cuda:0")
+        Xd = torch.from_numpy(X).to(dev)
+        ws = nmf_mod._StepBuffers(Xd, r)
+        costs = []
+        Ut, V = nmf_mod.run_steps(get_engine(dev), ws, Xd, r, torch.from_numpy(U0.T.copy()).to(dev), torch.from_numpy(V0).to(dev),
+                                  iters, "hals", 2, [None, None], [], [False, False], True,
+                                  lambda it, c, sw: costs.append((it, c)) and False)
+        return Ut.cpu().numpy().T, V.cpu().numpy(), costs, ws.direct_cost
+    U, V, costs, direct = run()
+    assert direct == expect_direct
+    assert [i for i, _ in costs] == list(range(iters))                    # every iteration retired once, in order
+    np.testing.assert_allclose([c for _, c in costs], co, rtol=HALS_COST, atol=1e-9 * float(np.sum(X.astype(np.float64) ** 2)))
+    assert rel(U, Uo) < HALS_FRO and rel(V, Vo) < HALS_FRO
+    monkeypatch.setenv("NNF_COST", "direct")
+    U2, V2, costs2, _ = run()
+    assert np.array_equal(U, U2) and np.array_equal(V, V2)                # the cost evaluation never touches the factors
+    if not expect_direct:
+        np.testing.assert_allclose([c for _, c in costs], [c for _, c in costs2], rtol=1e-4)
+
+
 @pytest.mark.parametrize("rule_beta_seed", [("mu", 2, 82), ("mu", 1, 82), ("mu", 0, 82)])
 def test_reference_known_answers_mu(golden, built_lib, rule_beta_seed):
     """tests/NMF_tests.py:83-135 of the reference."""

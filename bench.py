@@ -579,13 +579,16 @@ def bench_ntf(cx, args, cfg, steps, warmup, with_cpu, with_kernels):
     out = {"value": cx.world * steps / dt, "ms_per_step": 1e3 * dt / steps, "final_cost": cost,
            "inner_sweeps_per_step_last": sweeps[-1] if sweeps else None,
            "inner_sweeps_mean": (sum(sum(x) for x in sweeps) / len(sweeps)) if sweeps else None,
-           "rows_per_rank": I, "rule": "hals", "beta": 2}
+           "rows_per_rank": I, "rule": "hals", "beta": 2,
+           "cost_evaluation": ("pass over T (nnf_cp3_partial_cost_f32)" if (st.direct_cost or os.environ.get("NNF_COST") == "direct")
+                               else "the reference's expression ||T||^2 - 2<F,rhs> + sum f^T cross f on the last mode's operands "
+                                    "(nnf_nmf_gram_cost_f32), fp64 inner products, guarded by its own error estimate")}
     if with_kernels and cx.cuda and cx.rank == 0:
         eng = cx.eng
         tb = I * I * I * 4.0 + 3 * I * R * 4.0
         fl = 2.0 * I * I * I * R
         rl = []
-        # the two passes over T of an iteration of the loop timed above (dimension tree):
+        # the two passes over T of an iteration of the loop timed above (dimension tree + identity cost):
         ms = eng.time_kernel("mttkrp", lambda: eng.mttkrp3(T, Ft, 2))
         rl.append(roof("nnf_mttkrp_rows_kernel (mode-2 MTTKRP, Khatri-Rao operand generated on the fly; slab reduction not "
                        "included)", "hbm", tb, ms, HBM_PEAK_GBS, "GB/s", algorithmic_bytes=tb, algorithmic_flops=fl,
@@ -593,25 +596,31 @@ def bench_ntf(cx, args, cfg, steps, warmup, with_cpu, with_kernels):
         with_inloop(rl[-1], il_m.times()[-steps:], tb, HBM_PEAK_GBS, "GB/s",
                     f"HIP events around this kernel's {len(il_m.times()[-steps:])} launches inside the timed region")
         rl[-1]["tflops"] = fl / rl[-1]["launch_ms"] / 1e9
-        with InLoop(cx, eng, "mu_left", steps + 2) as il_f:
+        # the partial product Y = T x_2 F2^T the mode-0 / mode-1 right-hand sides are contracted from: the X H^T kernel on the
+        # (I J) x K unfolding -- a view of T.  (The cost comes from the last mode's operands: nnf_gram_cost_kernel, ~10 us.)
+        yb = tb - 2 * I * R * 4.0 + R * I * I * 4.0
+        with InLoop(cx, eng, "xht", steps + 2) as il_y:
             run(steps)
             torch.cuda.synchronize()
-        c = torch.zeros(1, dtype=torch.float64, device=T.device)
         Y = torch.empty((R, I, I), dtype=torch.float32, device=T.device)
-        ms = eng.time_kernel("mu_left", lambda: eng.cp3_partial_cost(T, Ft, Y, c))
-        rl.append(roof("nnf_mu_left_kernel<FROB> (one pass: ||T - model||^2 AND the partial product Y = T x_2 F2^T that the next "
-                       "iteration's mode-0 / mode-1 right-hand sides are contracted from)", "mfma", 2 * fl, ms,
-                       MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=2 * fl, algorithmic_bytes=tb + R * I * I * 4.0,
-                       hbm_gbs=(tb + R * I * I * 4.0) / ms / 1e6))
-        with_inloop(rl[-1], il_f.times()[-steps:], 2 * fl, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
+        ms = eng.time_kernel("xht", lambda: eng.ttm3(T, Ft[2], 2, out=Y))
+        rl.append(roof("nnf_xht_kernel as T x_2 F2^T (the partial product Y, R x I x J, of the dimension tree)", "hbm", yb, ms,
+                       HBM_PEAK_GBS, "GB/s", algorithmic_bytes=yb, algorithmic_flops=fl, tflops=fl / ms / 1e9))
+        with_inloop(rl[-1], il_y.times()[-steps:], yb, HBM_PEAK_GBS, "GB/s",
                     f"HIP events around this kernel's launches in {steps} further iterations of the same loop")
+        c = torch.zeros(3, dtype=torch.float64, device=T.device)
+        ms = eng.time_kernel("mu_left", lambda: eng.cp3_partial_cost(T, Ft, Y, c[0:1]))
+        rl.append(roof("nnf_mu_left_kernel<FROB> (one pass: ||T - model||^2 AND the partial product; what the loop runs instead "
+                       "once the Gram-identity cost is flagged unreliable or the stopping test is near -- not in the timed loop)",
+                       "mfma", 2 * fl, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=2 * fl,
+                       algorithmic_bytes=tb + R * I * I * 4.0, hbm_gbs=(tb + R * I * I * 4.0) / ms / 1e6))
         # the kernels the fused pass replaces / the first iteration and one_ntf_step use
         for mode in range(2):
             ms = eng.time_kernel("mttkrp", lambda: eng.mttkrp3(T, Ft, mode))
             rl.append(roof(f"nnf_mttkrp_seg_kernel, mode {mode} (direct MTTKRP; not in the timed loop since the dimension tree)",
                            "hbm", tb, ms, HBM_PEAK_GBS, "GB/s", algorithmic_bytes=tb, algorithmic_flops=fl,
                            tflops=fl / ms / 1e9))
-        ms = eng.time_kernel("cost", lambda: eng.cp3_betadiv(T, Ft, 2, out=c))
+        ms = eng.time_kernel("cost", lambda: eng.cp3_betadiv(T, Ft, 2, out=c[0:1]))
         rl.append(roof("nnf_cost_kernel<FROB> on the CP model (stand-alone cost; one_ntf_step)", "hbm", tb, ms, HBM_PEAK_GBS,
                        "GB/s", algorithmic_bytes=tb, algorithmic_flops=fl, tflops=fl / ms / 1e9))
         out["rooflines"] = rl

@@ -135,9 +135,11 @@ int nnf_frob_resid_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
  * ~1e-9 ||X||^2 (measured: tools/probes/gram_cost_probe.py), which is only acceptable while the
  * residual is not that small.  The kernel estimates it and says so:
  *   out_f64[0] = cost,  out_f64[1] = 0 if the estimate is below 5e-4 of the cost, else 1 (the caller then evaluates
- *   nnf_frob_resid_f32 for this iterate),  out_f64[2] = the estimate (4 sigma). */
-int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg,
-                          int r, int64_t n, const double* normx2_f64, double* out_f64, void* stream);
+ *   nnf_frob_resid_f32 for this iterate),  out_f64[2] = the estimate (4 sigma).
+ * UtU_b (may be NULL): the Gram is the Hadamard product UtU .* UtU_b -- the `cross` of one_ntf_step (ntf.py:442-445), whose
+ * own cost line IS this identity (ntf.py:462-470): V = the last updated factor (transposed), UtM = its MTTKRP right-hand side. */
+int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU, const float* UtU_b,
+                          int64_t ldg, int r, int64_t n, const double* normx2_f64, double* out_f64, void* stream);
 
 /* hals_nnls_acc (nnls.py:147-198) on device: V (r x ncols, in/out) is swept in place until
  *   eps >= delta*eps0 fails, or sweeps == max_sweeps                         (nnls.py:156)

@@ -189,7 +189,8 @@ extern "C" int nnf_hadamard_f32(nnf_ctx* ctx, const float* A, const float* B, fl
 // block sums in a fixed order -> partial[wg][4]; the LAST workgroup to finish (a ticket) adds the partials in index order
 // -- the same bits whichever workgroup that is -- and writes {cost, flag, estimate}.  One launch.
 __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restrict__ V, int64_t ldv, const float* __restrict__ UtM,
-                                                            int64_t ldm, const float* __restrict__ G, int64_t ldg, int r, int64_t n,
+                                                            int64_t ldm, const float* __restrict__ G, const float* __restrict__ G2,
+                                                            int64_t ldg, int r, int64_t n,
                                                             double* __restrict__ partial, unsigned* __restrict__ ticket,
                                                             const double* __restrict__ normx2, double* __restrict__ out) {
     extern __shared__ float gc_sh[];
@@ -197,7 +198,10 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
     float* vc = gc_sh + (size_t)r * r;   // 16 columns x r
     __shared__ double red[4];
     __shared__ unsigned last;
-    for (int e = threadIdx.x; e < r * r; e += 256) g[e] = G[(int64_t)(e / r) * ldg + (e % r)];
+    for (int e = threadIdx.x; e < r * r; e += 256) {      // G2: the Gram is a Hadamard product (NTF: ntf.py:442-445)
+        const int64_t o = (int64_t)(e / r) * ldg + (e % r);
+        g[e] = G2 ? G[o] * G2[o] : G[o];
+    }
     const int tc = threadIdx.x >> 4, t = threadIdx.x & 15;
     const int64_t j = (int64_t)blockIdx.x * 16 + tc;
     for (int a = t; a < r; a += 16) vc[tc * r + a] = (j < n) ? V[(int64_t)a * ldv + j] : 0.f;
@@ -265,7 +269,8 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
     }
 }
 extern "C" int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
-                                     int64_t ldg, int r, int64_t n, const double* normx2_f64, double* out_f64, void* stream) {
+                                     const float* UtU_b, int64_t ldg, int r, int64_t n, const double* normx2_f64, double* out_f64,
+                                     void* stream) {
     if (!ctx || !V || !UtM || !UtU || !normx2_f64 || !out_f64 || r < 1 || n < 1 || ldv < n || ldm < n || ldg < r) return NNF_ERR_ARG;
     if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -283,8 +288,8 @@ extern "C" int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_gram_cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL(nnf_gram_cost_kernel, dim3((int)nwg), dim3(256), shm, st, V, ldv, UtM, ldm, UtU, ldg, r, n, partial, ticket,
-                       normx2_f64, out_f64);
+    hipLaunchKernelGGL(nnf_gram_cost_kernel, dim3((int)nwg), dim3(256), shm, st, V, ldv, UtM, ldm, UtU, UtU_b, ldg, r, n, partial,
+                       ticket, normx2_f64, out_f64);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
 }

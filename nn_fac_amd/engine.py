@@ -134,7 +134,7 @@ class Engine:
                                                _ld(V), r, _ptr(o), self._stream()), "nnf_frob_resid_f32")
         return o
 
-    def gram_cost(self, V, UtM, UtU, normx2, out):
+    def gram_cost(self, V, UtM, UtU, normx2, out, UtU_b=None):
         """||X - U V||^2 through the Gram identity (nnf_nmf_gram_cost_f32): `normx2` a 1-element float64 device tensor holding
         ||X||^2, `out` >= 3 float64 on the device: {cost, 1 if the fp32 operands do not carry it to 5e-4, error estimate}."""
         _chk2d(V, "gram_cost V"), _chk2d(UtM, "gram_cost UtM"), _chk2d(UtU, "gram_cost UtU")
@@ -142,7 +142,10 @@ class Engine:
         if UtM.shape != (r, n) or UtU.shape[0] < r or UtU.shape[1] < r or normx2.dtype != torch.float64 or out.dtype != torch.float64 \
                 or out.numel() < 3:
             raise EngineError("gram_cost: shape / dtype mismatch")
-        _lib.check(self.lib.nnf_nmf_gram_cost_f32(self.ctx, _ptr(V), _ld(V), _ptr(UtM), _ld(UtM), _ptr(UtU), _ld(UtU), r, n,
+        if UtU_b is not None and (UtU_b.shape != UtU.shape or _ld(UtU_b) != _ld(UtU)):
+            raise EngineError("gram_cost: the two Grams of a Hadamard pair must share shape and leading dimension")
+        _lib.check(self.lib.nnf_nmf_gram_cost_f32(self.ctx, _ptr(V), _ld(V), _ptr(UtM), _ld(UtM), _ptr(UtU),
+                                                  _ptr(UtU_b) if UtU_b is not None else None, _ld(UtU), r, n,
                                                   _ptr(normx2), _ptr(out), self._stream()), "nnf_nmf_gram_cost_f32")
         return out
 

@@ -108,8 +108,12 @@ def compute_nmf(data, rank, U_in, V_in, n_iter_max=100, tol=1e-8,
             return True
         return False
 
+    def revise_last(cost):
+        cost_fct_vals[-1] = cost
+    retired.revise_last = revise_last
+
     Ut, V = run_steps(eng, ws, X, rank, Ut, V, n_iter_max, update_rule, beta, sparsity_coefficients, fixed_modes,
-                      normalize, deterministic, retired, group=group)
+                      normalize, deterministic, retired, group=group, tol=tol)
 
     U_out, V_out = like_input(Ut.t(), U_in), like_input(V, V_in)
     if return_costs:
@@ -222,6 +226,10 @@ class _IdentityUnreliable(Exception):
     with the streaming cost kernel, and so is the rest of the run."""
 
 
+class _IdentityNearStop(_IdentityUnreliable):
+    """Two consecutive identity costs differ by the caller's `tol` give or take their error estimates."""
+
+
 class _GuessMissed(Exception):
     """Row-sharded run: the blind chunk of the device-side protocol did not contain the stopping sweep in its snapshot window
     (status words 3 / 4 of nnf_hals_stop_restore_f32): the iteration is redone with the host-synchronous protocol."""
@@ -245,7 +253,7 @@ def _raise_on_status(host, nstat, timeout_ok=False, nranks=0):
 
 
 def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
-              deterministic, retired, group=None):
+              deterministic, retired, group=None, tol=None):
     """The `for iteration` loop of compute_nmf (nmf.py:298-324) with the device running ahead of the host.
 
     * Iteration i+1 is enqueued BEFORE the host reads the cost of iteration i (its 24-double block arrives through an
@@ -277,6 +285,9 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
     # an iterate it cannot carry to 5e-4 (an almost exact fit): run_steps then redoes that iteration, and runs the rest, with
     # the streaming kernel.  Row-sharded: every operand is replicated (||X||^2 summed once), so the cost needs no collective.
     # NNF_COST=direct in the environment forces the streaming kernel.
+    # `tol` given (the caller stops on |cost[i-1] - cost[i]| < tol, nmf.py:320): an iterate whose difference to its predecessor
+    # is within the two error estimates of `tol` is treated the same way, and the predecessor's cost is re-evaluated by the
+    # streaming kernel too and handed to `retired.revise_last` -- the stopping test never compares costs it cannot tell apart.
     ident = (cuda and update_rule == "hals" and 1 not in fixed_modes and isinstance(eng, _engine.Engine)
              and not ws.direct_cost and os.environ.get("NNF_COST") != "direct")
     if ident and ws.normx2 is None:
@@ -317,16 +328,23 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
             ws.host[step["slot"]].copy_(block, non_blocking=True)
             step["ev"] = stream.record_event()
 
+    last = None           # (cost, error estimate) of the last retired iterate while both came from the identity
+
     def retire():
-        nonlocal result, stop
+        nonlocal result, stop, last
         step = pending[0]
         if step["ev"] is not None:
             step["ev"].synchronize()
         host = ws.host[step["slot"]]
         _raise_on_status(host, step["nstat"], timeout_ok=not getattr(ws, "safe_solve", False),
                          nranks=_dist.world(group) if _dist.is_sharded(group) else 0)
-        if step.get("ident") and float(host[20]) != 0.0:
-            raise _IdentityUnreliable()
+        if step.get("ident"):
+            if float(host[20]) != 0.0:
+                raise _IdentityUnreliable()
+            c, e = float(host[19]), float(host[21])
+            if tol is not None and tol > 0 and last is not None and abs(last[0] - c) < tol + e + last[1]:
+                raise _IdentityNearStop()
+            last = (c, e)
         pending.pop(0)                     # (a step that timed out stays at the head: run_steps resumes from it)
         result = (step["Ut"], step["V"])
         if group is not None and update_rule == "hals" and step["nstat"] >= 1 and 0 not in fixed_modes:
@@ -415,10 +433,15 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
             fall_back()
             Ut, V = result                        # factors of the last iteration that retired cleanly
             iteration = failed
-        except _IdentityUnreliable:
+        except _IdentityUnreliable as why:
             failed = pending[0]["it"]
             drain()
             pending.clear()
+            if isinstance(why, _IdentityNearStop) and hasattr(retired, "revise_last"):
+                scratch = torch.zeros_like(ws.block)
+                _step_cost(eng, X, result[0], result[1], update_rule, beta, sparsity_coefficients, scratch, group)
+                retired.revise_last(float(scratch[16]))
+            last = None
             ws.direct_cost = True                 # this iteration again, and every later one, with the streaming cost kernel
             ident = False
             overlap = (ws.cost_stream is not None

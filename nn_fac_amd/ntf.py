@@ -8,9 +8,11 @@ Per updated mode the reference statements map to the C ABI as follows (factors k
                                                      neither the unfoldings nor the Khatri-Rao matrix are materialised)
     hals_nnls_acc(rhs^T, cross, F[mode]^T)         (ntf.py:454-456) -> nnf_hals_solve_f32
     mu_betadivmin(F[mode], krao^T, unfolded[mode]) (ntf.py:459-460) -> nnf_mu_right_f32 on the transposed unfolding (MU path only)
-    cost                                           (ntf.py:462-475) -> nnf_cp3_betadiv_f32: the reference's
-        ||T||^2 - 2<F,rhs> + ||F krao^T||^2 equals ||T - model||^2 exactly; it is evaluated directly (one more pass
-        over the tensor) because the difference form cancels catastrophically in fp32.
+    cost                                           (ntf.py:462-475) -> HALS loops: the reference's own form
+        ||T||^2 - 2<F,rhs> + sum_k f_k^T cross f_k on the last updated mode's operands, inner products in fp64, with the
+        kernel's error estimate as a guard (nnf_nmf_gram_cost_f32: no pass over T); wherever that form cannot carry the
+        cost -- an almost exact fit (the difference cancels), an iterate within the estimate of the stopping threshold,
+        a single step, MU -- ||T - model||^2 / the beta-divergence directly: nnf_cp3_betadiv_f32, one pass over the tensor.
 
 Differences kept on purpose: ``one_ntf_step`` exposes ``alpha`` like the reference (default 0.5 = wall-clock dependent,
 ntf.py:349); ``compute_ntf`` adds ``alpha`` / ``delta`` keywords (default: the reference's) so that deterministic runs
@@ -19,6 +21,7 @@ tensor that group adjacent modes, against the Khatri-Rao product of each group's
 tree and the fused cost pass are 3-way only.
 """
 import math
+import os
 import time
 
 import numpy as np
@@ -87,9 +90,10 @@ class _NtfState:
         self.last_cnt0 = None
         self.async_hits = self.async_misses = 0
         self._unf = {}
+        self.direct_cost = False           # set for the rest of a run once the Gram-identity cost was found unreliable
         self._Y, self._Y_of, self._grams = None, None, {}
-        # per-iteration status: one HALS status block per mode, then the cost at [8 * nway]; a ring with pinned host
-        # mirrors (run_ntf_steps)
+        # per-iteration status: one HALS status block per mode, then {cost, 1 = identity cost not reliable, its error
+        # estimate} at [8 * nway ...]; a ring with pinned host mirrors (run_ntf_steps)
         self.cost_at = 8 * self.nway
         self.blocks = torch.zeros((3, self.cost_at + 8), dtype=torch.float64, device=T.device)
         self.host = torch.zeros((3, self.cost_at + 8), dtype=torch.float64)
@@ -174,21 +178,30 @@ def _krao_t(Ft, skip):
     return res.contiguous()
 
 
-def _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, cost, fuse_next=False, host_norm=False):
-    """The cost lines of one_ntf_step (ntf.py:462-475) into the 1-element float64 device tensor `cost`, current stream.
-    `fuse_next` (HALS, another iteration follows): the same pass over T leaves the next iteration's partial product."""
+def _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, cost, fuse_next=False, host_norm=False, ident=None):
+    """The cost lines of one_ntf_step (ntf.py:462-475) into the float64 device words `cost` ([0] = the cost), current stream.
+    `fuse_next` (HALS, another iteration follows): the same pass over T leaves the next iteration's partial product.
+    `ident` = (mode, rhs, Ga, Gb) of the last updated mode: the reference's own expression (ntf.py:462-470)
+        ||T||^2 - 2 <F_mode, rhs> + sum_k f_k^T (Ga .* Gb) f_k        (f_k: the rows of the I_mode x R factor)
+    with the three inner products in fp64 (Engine.gram_cost) instead of a pass over T; cost[1], cost[2] = the kernel's
+    verdict on its own accuracy and its error estimate.  Leading-mode-sharded: every operand is replicated (rhs and the
+    mode-0 Gram are all-reduced for the solve, ||T||^2 once per run) -- no collective."""
     sharded = _dist.is_sharded(st.group)
-    if update_rule == "hals" and fuse_next and hasattr(eng, "cp3_partial_cost") \
+    if ident is not None:
+        mode, rhs_t, Ga, Gb = ident
+        eng.gram_cost(Ft[mode], rhs_t, Ga, st.norm2, cost[0:3], UtU_b=Gb)
+    elif update_rule == "hals" and fuse_next and hasattr(eng, "cp3_partial_cost") \
             and Ft[0].shape[0] <= getattr(eng, "CP3_FUSED_MAX_RANK", 0):
-        st.cost_and_partial(Ft, cost)                # ||T - model||^2
+        st.cost_and_partial(Ft, cost[0:1])           # ||T - model||^2
     elif update_rule == "hals":
         T3, F3, _ = st.view3(0, Ft)
-        eng.cp3_betadiv(T3, F3, 2, out=cost)
-        cost.mul_(2.0)                               # ||T - model||^2
+        eng.cp3_betadiv(T3, F3, 2, out=cost[0:1])
+        cost[0:1].mul_(2.0)                          # ||T - model||^2
     else:
         T3, F3, _ = st.view3(0, Ft)
-        eng.cp3_betadiv(T3, F3, beta, out=cost)
-    if sharded:
+        eng.cp3_betadiv(T3, F3, beta, out=cost[0:1])
+    cost = cost[0:1]
+    if sharded and ident is None:
         _dist.allreduce_(cost, st.group)             # additive over the blocks of the leading mode
     sparsity_error = None
     for index, sparse in enumerate(sparsity_coefficients):
@@ -206,7 +219,7 @@ def _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, cost, fuse_
 
 
 def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients, fixed_modes, normalize, alpha, delta,
-                      skip_cost=False, fuse_next=False, host_norm=False):
+                      skip_cost=False, fuse_next=False, host_norm=False, ident=False):
     eng = st.eng
     if update_rule not in ["hals", "mu"]:
         raise err.InvalidArgumentValue(f"Invalid update rule: {update_rule}") from None
@@ -237,6 +250,7 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
         T3, F3, m3 = st.view3(mode, Ft)
         return eng.mttkrp3(T3, F3, m3, out=out)
 
+    last = None            # (mode, rhs, Ga, Gb) of the last updated mode: what the reference's cost line is made of (ntf.py:462-470)
     for mode in [m for m in range(N) if m not in fixed_modes]:
         if update_rule == "hals":
             deterministic = math.isinf(alpha)
@@ -271,8 +285,10 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
                                      normalize=normalize[mode], status=st.block[8 * nstat:8 * nstat + 8])
                 nstat += 1
                 Ft[mode] = new
+                last = (mode, rhs_t, Ga, Gb)
                 continue
             cross = Ga if Gb is None else eng.hadamard(Ga, Gb)
+            last = (mode, rhs_t, cross, None)
             new = Ft[mode].clone()
             if sharded and mode == 0:
                 if st.async_sharded and st.async_ready and not st.sync_next and hasattr(eng, "hals_stop_restore"):
@@ -306,25 +322,43 @@ def _one_ntf_step_dev(st, rank, Ft_in, update_rule, beta, sparsity_coefficients,
             Ft[mode] = eng.mu_right(st.unfolded_t(mode), _krao_t(Ft, mode), Ft[mode], beta)
 
     if not skip_cost:
-        _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, st.block[st.cost_at:st.cost_at + 1],
-                  fuse_next=fuse_next and Y is not None, host_norm=host_norm)
+        _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, st.block[st.cost_at:st.cost_at + 3],
+                  fuse_next=fuse_next and Y is not None, host_norm=host_norm, ident=last if ident else None)
     return Ft, nstat
 
 
+def _identity_cost_applies(st, update_rule, fixed_modes):
+    """HALS loops on the device take their cost from the last updated mode's operands (_ntf_cost) -- unless that mode is the
+    sharded one (its factor and right-hand side are blocks, not replicas), an earlier iterate of this run showed the form
+    cannot carry the cost (st.direct_cost), or NNF_COST=direct in the environment asks for the pass over T."""
+    updated = [m for m in range(st.nway) if m not in fixed_modes]
+    return (st.T.is_cuda and update_rule == "hals" and isinstance(st.eng, _engine.Engine) and bool(updated)
+            and not (_dist.is_sharded(st.group) and updated[-1] == 0)
+            and not st.direct_cost and os.environ.get("NNF_COST") != "direct")
+
+
 def run_ntf_steps(st, rank, Ft, n_iter, update_rule, beta, sparsity_coefficients, fixed_modes, normalize, alpha, delta,
-                  retired):
+                  retired, tol=None):
     """The `for iteration` loop of compute_ntf (ntf.py:313-340) with the device one iteration ahead of the host, like
     nmf.run_steps: the status block of iteration i reaches the host through an asynchronous copy + event and is looked at
     after iteration i+1 has been enqueued (0.91 -> 0.76 ms per iteration at 500^3, rank 30).  `retired(iteration, cost,
     sweeps)` is called in order and returns True to stop; the factors of the stopping iteration are returned, the
     speculative one behind it is dropped.  (Running the cost on a second stream next to the following iteration's MTTKRP
-    kernels was tried: 0.78 ms, both want HBM.)"""
+    kernels was tried: 0.78 ms, both want HBM.)
+
+    HALS costs come from the Gram identity (_ntf_cost) while the kernel's own error estimate stays below 5e-4 of the cost
+    and -- `tol` given: the caller stops on |cost[i-1] - cost[i]| < tol (ntf.py:337) -- while that difference is further
+    from `tol` than the two estimates together.  The first iterate that fails either test is evaluated again by the pass
+    over T, and so is every later one; in the second case the previous iterate's cost is re-evaluated as well and handed to
+    `retired.revise_last`, so that the stopping test only ever compares two costs of the same kind."""
     cuda = st.T.is_cuda
     main = torch.cuda.current_stream(st.T.device) if cuda else None
     pending, result, stop = [], Ft, False
+    ident = _identity_cost_applies(st, update_rule, fixed_modes)
+    last = None           # (cost, estimate) of the last retired iterate, normalised, while both came from the identity
 
     def retire():
-        nonlocal result, stop
+        nonlocal result, stop, last
         step = pending[0]
         step["ev"].synchronize()
         host = st.host[step["slot"]]
@@ -334,6 +368,13 @@ def run_ntf_steps(st, rank, Ft, n_iter, update_rule, beta, sparsity_coefficients
                 raise _GuessMissed()
             if code != 0:
                 raise err.EngineError("hals grid barrier timed out; result invalid")
+        if step["ident"]:
+            if float(host[st.cost_at + 1]) != 0.0:
+                raise _IdentityUnreliable()
+            c, e = float(host[st.cost_at]) / norm2_host, float(host[st.cost_at + 2]) / norm2_host
+            if tol is not None and tol > 0 and last is not None and abs(last[0] - c) < tol + e + last[1]:
+                raise _IdentityNearStop()
+            last = (c, e)
         pending.pop(0)
         result = step["Ft"]
         if _dist.is_sharded(st.group) and update_rule == "hals" and 0 not in fixed_modes and step["nstat"] >= 1:
@@ -352,11 +393,11 @@ def run_ntf_steps(st, rank, Ft, n_iter, update_rule, beta, sparsity_coefficients
         st.select(iteration % st.blocks.shape[0])
         st.last_step_async = False
         Ft, nstat = _one_ntf_step_dev(st, rank, Ft, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
-                                      alpha, delta, fuse_next=True, host_norm=True)   # (fuse_next also in the last iteration: every cost of a run
-        #                                        comes from the same kernel, whatever n_iter_max -- bitwise repeatable)
+                                      alpha, delta, fuse_next=True, host_norm=True, ident=ident)   # (fuse_next also in the last
+        #                    iteration: every cost of a run comes from the same kernel, whatever n_iter_max -- bitwise repeatable)
         st.sync_next = False
         st.host[st.slot].copy_(st.block, non_blocking=cuda)
-        pending.append(dict(it=iteration, slot=st.slot, Ft=Ft, nstat=nstat, async0=st.last_step_async,
+        pending.append(dict(it=iteration, slot=st.slot, Ft=Ft, nstat=nstat, async0=st.last_step_async, ident=ident,
                             ev=main.record_event() if cuda else _NoEvent()))
         iteration += 1
         try:
@@ -379,6 +420,23 @@ def run_ntf_steps(st, rank, Ft, n_iter, update_rule, beta, sparsity_coefficients
             st.async_misses += 1
             Ft = result
             iteration = failed
+        except _IdentityUnreliable as why:
+            # this iteration again, and every later one, with the pass over T (every rank: the words are replicated)
+            failed = pending[0]["it"]
+            main.synchronize()
+            pending.clear()
+            st.direct_cost, ident = True, False
+            Ft = result
+            iteration = failed
+            if isinstance(why, _IdentityNearStop) and hasattr(retired, "revise_last"):
+                # the iterate before it too: the stopping test then compares two costs of the same kind.  Its pass leaves the
+                # partial product the repeated iteration starts from (st.partial finds it)
+                tree = (st.nway == 3 and math.isinf(alpha) and 0 not in fixed_modes and 1 not in fixed_modes
+                        and hasattr(st.eng, "mttkrp3_from_partial"))
+                words = torch.zeros(3, dtype=torch.float64, device=st.T.device)
+                _ntf_cost(st.eng, st, Ft, update_rule, beta, sparsity_coefficients, words, fuse_next=tree, host_norm=True)
+                retired.revise_last(float(words[0]) / norm2_host)
+            last = None
     if cuda and pending:
         main.synchronize()
     return result
@@ -386,6 +444,14 @@ def run_ntf_steps(st, rank, Ft, n_iter, update_rule, beta, sparsity_coefficients
 
 class _GuessMissed(Exception):
     """Leading-mode-sharded run: the device-side stopping decision of the mode-0 solve missed (status 3 / 4)."""
+
+
+class _IdentityUnreliable(Exception):
+    """The Gram-identity cost's own error estimate is above 5e-4 of the cost (an almost exact fit)."""
+
+
+class _IdentityNearStop(_IdentityUnreliable):
+    """Two consecutive identity costs differ by `tol` give or take their error estimates: the stopping test needs better."""
 
 
 class _NoEvent:
@@ -438,8 +504,12 @@ def compute_ntf(tensor_in, rank, factors_in, n_iter_max=100, tol=1e-8,
             return True
         return False
 
+    def revise_last(cost):
+        cost_fct_vals[-1] = cost
+    retired.revise_last = revise_last
+
     Ft = run_ntf_steps(st, rank, Ft, n_iter_max, update_rule, beta, sparsity_coefficients, fixed_modes, normalize,
-                       alpha, delta, retired)
+                       alpha, delta, retired, tol=tol)
     # the reference returns np.array(factors), which needs equal mode sizes on NumPy >= 1.24; a list always works
     factors = [like_input(f.t(), factors_in[i]) for i, f in enumerate(Ft)]
     if return_costs:

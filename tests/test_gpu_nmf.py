@@ -216,8 +216,45 @@ def test_early_stop_drops_the_speculative_iteration(golden, built_lib, rule, bet
     assert len(cs) == first + 1 == len(toc) and first < 11
     Uk, Vk, ck, _ = compute_nmf(X, 10, U0, V0, n_iter_max=first + 1, tol=0, update_rule=rule, beta=beta,
                                 return_costs=True, deterministic=True)
-    assert cs == ck[:first + 1] == costs[:first + 1]
+    assert ck[:first + 1] == costs[:first + 1]
+    if rule == "mu":
+        assert cs == ck
+    else:           # HALS: the two costs the stopping test fires on come from the streaming kernel, the others from the Gram
+        assert cs[:first - 1] == ck[:first - 1]                 # identity (test_hals_cost_near_the_stopping_threshold)
+        np.testing.assert_allclose(cs, ck, rtol=5e-4)
     assert np.array_equal(Us, Uk) and np.array_equal(Vs, Vk)
+
+
+def test_hals_cost_near_the_stopping_threshold(built_lib, monkeypatch):
+    """The Gram-identity cost carries an absolute error of ~1e-9 ||X||^2; the stopping test (nmf.py:320) compares a cost
+    DIFFERENCE with `tol`.  Once two consecutive costs differ by `tol` give or take their error estimates, both are evaluated
+    again by the streaming kernel (and every later one): the run stops where a run with NNF_COST=direct stops -- and where the
+    fp64 oracle stops --, and the two costs the test fired on are bitwise those of that run."""
+    from nn_fac_amd import nmf as nmf_mod
+    made = []
+
+    class Spy(nmf_mod._StepBuffers):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            made.append(self)
+    monkeypatch.setattr(nmf_mod, "_StepBuffers", Spy)
+    X, U0, V0 = orc.synth_nmf(2000, 300, 8, seed=9, dtype=np.float32)
+    kw = dict(update_rule="hals", return_costs=True, deterministic=True)
+    _, _, costs, _ = nmf_mod.compute_nmf(X, 8, U0, V0, n_iter_max=16, tol=0, **kw)
+    assert not made[-1].direct_cost
+    k = 8
+    tol = 0.5 * (abs(costs[k - 1] - costs[k]) + abs(costs[k] - costs[k + 1]))
+    Us, Vs, cs, _ = nmf_mod.compute_nmf(X, 8, U0, V0, n_iter_max=16, tol=tol, **kw)
+    assert made[-1].direct_cost
+    monkeypatch.setenv("NNF_COST", "direct")
+    Ud, Vd, cd, _ = nmf_mod.compute_nmf(X, 8, U0, V0, n_iter_max=16, tol=tol, **kw)
+    assert len(cs) == len(cd) < 16
+    assert cs[-2:] == cd[-2:]
+    np.testing.assert_allclose(cs, cd, rtol=5e-4)
+    assert np.array_equal(Us, Ud) and np.array_equal(Vs, Vd)
+    _, _, co, _ = orc.compute_nmf(X.astype(np.float64), 8, U0.astype(np.float64), V0.astype(np.float64), n_iter_max=16,
+                                  tol=tol, update_rule="hals", return_costs=True, deterministic=True)
+    assert len(co) == len(cs)
 
 
 def test_nndsvd_known_answer_and_oracle(golden, built_lib):

@@ -106,7 +106,9 @@ def test_ntf_mid_size_vs_oracle(built_lib):
 @pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 1)])
 def test_ntf_early_stop_drops_the_speculative_iteration(built_lib, rule, beta):
     """compute_ntf keeps one iteration in flight ahead of the stopping test (run_ntf_steps): a stop at iteration k returns
-    the factors and costs of iteration k, bit for bit."""
+    the factors of iteration k, bit for bit, and its costs -- bit for bit too where one kernel evaluates every cost (MU); a
+    HALS run evaluates the two costs the stopping test fires on by the pass over T instead of the Gram identity
+    (test_ntf_hals_cost_near_the_stopping_threshold), within 1e-4 of each other."""
     from nn_fac_amd.ntf import compute_ntf
     T, F0 = orc.synth_ntf((30, 25, 20), 4, seed=5, dtype=np.float32)
     kw = dict(update_rule=rule, beta=beta, alpha=math.inf, sparsity_coefficients=[None] * 3, normalize=[False] * 3,
@@ -118,9 +120,89 @@ def test_ntf_early_stop_drops_the_speculative_iteration(built_lib, rule, beta):
     Fs, cs, toc = compute_ntf(T, 4, F0, n_iter_max=12, tol=tol, **kw)
     assert len(cs) == first + 1 == len(toc) and first < 11
     Fk, ck, _ = compute_ntf(T, 4, F0, n_iter_max=first + 1, tol=0, **kw)
-    assert cs == ck == costs[:first + 1]
+    assert ck == costs[:first + 1]
+    if rule == "mu":
+        assert cs == ck
+    else:
+        assert cs[:first - 1] == ck[:first - 1]
+        np.testing.assert_allclose(cs, ck, rtol=5e-4)
     for a, b in zip(Fs, Fk):
         assert np.array_equal(a, b)
+
+
+def _spy_states(monkeypatch):
+    from nn_fac_amd import ntf as ntf_mod
+    made = []
+
+    class Spy(ntf_mod._NtfState):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            made.append(self)
+    monkeypatch.setattr(ntf_mod, "_NtfState", Spy)
+    return made
+
+
+@pytest.mark.parametrize("noise,expect_direct", [(0.3, False), (0.0, True)])
+@pytest.mark.parametrize("shape,R", [((60, 50, 40), 6), ((9, 8, 7, 6), 3)])
+def test_ntf_hals_cost_through_the_gram_identity_and_its_guard(built_lib, shape, R, noise, expect_direct, monkeypatch):
+    """HALS loops take the cost from the reference's own expression (ntf.py:462-470) on the last mode's operands, inner
+    products in fp64 (nnf_nmf_gram_cost_f32 with the two Grams of `cross`): no pass over T.  With a real residual that is what
+    runs and agrees with the fp64 oracle and with the pass over T (NNF_COST=direct); on an almost exact fit the kernel's
+    error estimate flags the iterate and the run goes on with the pass over T -- same factors either way."""
+    from nn_fac_amd.ntf import compute_ntf
+    rng = np.random.RandomState(11)
+    true = [rng.rand(s, R) for s in shape]
+    T = true[0]
+    for f in true[1:]:                                   # the CP model, one mode at a time: (..., R) x (dim, R) -> (..., dim, R)
+        T = T[..., None, :] * f
+    T = T.sum(-1)
+    T = (T + noise * rng.rand(*shape)).astype(np.float32)
+    if noise:
+        F0 = [rng.rand(s, R).astype(np.float32) for s in shape]
+    else:
+        F0 = [(f * (1 + 1e-3 * rng.rand(*f.shape))).astype(np.float32) for f in true]
+    iters = 6
+    kw = dict(n_iter_max=iters, tol=0, update_rule="hals", return_costs=True, alpha=math.inf)
+    Fo, co, _ = orc.compute_ntf(T.astype(np.float64), R, [f.astype(np.float64) for f in F0], **kw)
+    made = _spy_states(monkeypatch)
+    nm = len(shape)
+    F, costs, _ = compute_ntf(T, R, F0, sparsity_coefficients=[None] * nm, normalize=[False] * nm, **kw)
+    assert made[-1].direct_cost == expect_direct
+    assert len(costs) == iters
+    np.testing.assert_allclose(costs, co, rtol=2e-3, atol=2e-9)
+    for a, b in zip(F, Fo):
+        assert rel(a, b) < 2e-3
+    monkeypatch.setenv("NNF_COST", "direct")
+    F2, costs2, _ = compute_ntf(T, R, F0, sparsity_coefficients=[None] * nm, normalize=[False] * nm, **kw)
+    for a, b in zip(F, F2):
+        assert np.array_equal(a, b)                       # the cost evaluation never touches the factors
+    np.testing.assert_allclose(costs, costs2, rtol=5e-4, atol=1e-10)
+
+
+def test_ntf_hals_cost_near_the_stopping_threshold(built_lib, monkeypatch):
+    """The identity cost carries an absolute error of ~1e-9 ||T||^2; the stopping test (ntf.py:337) compares a cost DIFFERENCE
+    with `tol`.  Once two consecutive costs differ by `tol` give or take their error estimates, both are evaluated again by the
+    pass over T (and every later one): the run stops at the iteration a run with NNF_COST=direct stops at, and the two costs
+    the test fired on are bitwise those of that run."""
+    from nn_fac_amd.ntf import compute_ntf
+    T, F0 = orc.synth_ntf((40, 30, 20), 4, seed=3, dtype=np.float32)
+    kw = dict(update_rule="hals", alpha=math.inf, sparsity_coefficients=[None] * 3, normalize=[False] * 3, return_costs=True)
+    _, costs, _ = compute_ntf(T, 4, F0, n_iter_max=14, tol=0, **kw)
+    k = 7
+    tol = 0.5 * (abs(costs[k - 1] - costs[k]) + abs(costs[k] - costs[k + 1]))
+    made = _spy_states(monkeypatch)
+    Fs, cs, _ = compute_ntf(T, 4, F0, n_iter_max=14, tol=tol, **kw)
+    assert made[-1].direct_cost
+    monkeypatch.setenv("NNF_COST", "direct")
+    Fd, cd, _ = compute_ntf(T, 4, F0, n_iter_max=14, tol=tol, **kw)
+    assert len(cs) == len(cd) < 14
+    assert cs[-2:] == cd[-2:]
+    np.testing.assert_allclose(cs, cd, rtol=5e-4)          # (the guard's own bound: few terms, little averaging at this size)
+    for a, b in zip(Fs, Fd):
+        assert np.array_equal(a, b)
+    _, co, _ = orc.compute_ntf(T.astype(np.float64), 4, [f.astype(np.float64) for f in F0], n_iter_max=14, tol=tol,
+                               update_rule="hals", return_costs=True, alpha=math.inf)
+    assert len(co) == len(cs)
 
 
 @pytest.mark.parametrize("shape,R", [((7, 1, 5), 3), ((17, 5, 1), 1), ((6, 5, 4), 1), ((1, 33, 2), 4)])

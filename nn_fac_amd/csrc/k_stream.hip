@@ -1063,6 +1063,8 @@ extern "C" int nnf_xty_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, i
     return nnf_xty_impl(ctx, cur, X, m, n, ldx, Ut, r, ldu, out, ldo, (hipStream_t)stream);
 }
 
+int nnf_xht_lds_launch(nnf_ctx* ctx, int MT, int REM, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r,
+                       int64_t ldv, float* out, int64_t ldo, hipStream_t st);   // k_xht_lds.hip
 int nnf_xht_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V,
                  int r, int64_t ldv, float* out, int64_t ldo, hipStream_t st) {
     if (!ctx || !X || !V || !out || m < 1 || n < 1 || r < 1 || ldx < n || ldv < n || ldo < m) return NNF_ERR_ARG;
@@ -1072,6 +1074,10 @@ int nnf_xht_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, in
     // ranks 51, 52: three tiles + four leftover ranks next to the 4-row-tile body do not fit 256 registers (84 bytes of scratch,
     // drains inside the chunk loop: 292 us against 238 us for the padded four tiles at 100000 x 2000, tools/probes/rank_step_probe.py)
     if (MT == 3 && REM == 4) { MT = 4; REM = 0; }
+    // X staged through LDS in 256-byte row pieces (k_xht_lds.hip) where the load path, not the MFMA rate, bounds the product
+    const char* pick = getenv("NNF_XHT");       // measurement knob: "direct" keeps the register-fragment kernel
+    if (x_vec_ok(X, ldx) && MT + (REM > 0) <= 2 && !(pick && pick[0] == 'd'))
+        return nnf_xht_lds_launch(ctx, MT, REM, X, m, n, ldx, V, r, ldv, out, ldo, st);
     if (!x_vec_ok(X, ldx)) {
         MT = (r + 15) / 16;
         DISPATCH_MT(launch_xht, 0, false, ctx, cur, X, m, n, ldx, V, r, ldv, out, ldo, st)

@@ -70,10 +70,11 @@ def test_gram_of_short_factors(eng, K, r):
 
 
 @pytest.mark.parametrize("m", [70001, 98304, 100000, 131072, 131075, 300007])
-@pytest.mark.parametrize("n,r", [(70, 50), (129, 64)])
+@pytest.mark.parametrize("n,r", [(70, 50), (129, 64), (70, 30), (129, 18), (64, 16), (500, 20)])
 def test_xht_row_tilings(eng, m, n, r):
     """X H^T picks its rows-per-workgroup from m (one balanced round of (3,2)- or (4,3)-tile workgroups, or several
-    rounds of 256-row workgroups): every branch, with ragged ends, against an fp64 product on the device."""
+    rounds of 256-row workgroups): every branch, with ragged ends, against an fp64 product on the device -- in both kernel
+    forms (ranks <= 32 stage X through LDS in 256-byte row pieces, k_xht_lds.hip; the others read fragments directly)."""
     g = torch.Generator(device="cuda").manual_seed(m + n)
     X = torch.rand(m, n, device="cuda", generator=g)
     V = torch.rand(r, n, device="cuda", generator=g)
@@ -81,6 +82,23 @@ def test_xht_row_tilings(eng, m, n, r):
     got = eng.xht(X, V).double()
     assert float((got - want).norm() / want.norm()) < 1e-5
     assert float((got - want).abs().max() / want.abs().max()) < 1e-5      # no row block missed or doubled
+
+
+@pytest.mark.parametrize("m,n,r", [(1000, 260, 30), (513, 130, 17), (64, 64, 16), (300, 7, 3), (5, 300, 2), (257, 1, 1),
+                                   (1, 257, 1), (250000, 500, 30), (40000, 2000, 32), (777, 333, 20), (131075, 70, 19)])
+def test_xht_lds_staged_equals_direct_fragments(eng, m, n, r, monkeypatch):
+    """The LDS-staged X H^T (k_xht_lds.hip) changes how X reaches the MFMA operands, not the arithmetic: same k order per
+    accumulator as nnf_xht_kernel (NNF_XHT=direct) -- the results are equal bit for bit; padded rows with NaN in the padding."""
+    g = torch.Generator(device="cuda").manual_seed(m * 3 + n + r)
+    buf = torch.full((m, n + 4 * (r % 3)), float("nan"), device="cuda")
+    buf[:, :n] = torch.rand(m, n, device="cuda", generator=g) - 0.25
+    X = buf[:, :n]
+    V = torch.rand(r, n, device="cuda", generator=g)
+    got = eng.xht(X, V).clone()
+    monkeypatch.setenv("NNF_XHT", "direct")
+    want = eng.xht(X, V)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want)
 
 
 def test_views_with_leading_dimension(eng):

@@ -150,7 +150,7 @@ __device__ __forceinline__ void nnf_xht_lds_body(const float* __restrict__ X, in
 // The first n_hi workgroups take NTH row tiles per wave, the others NTH-1 (nnf_xht_kernel's split: one round of resident
 // workgroups covers the matrix where it can).
 template <int MT, int REM, int NTH>
-__global__ __launch_bounds__(256, 2) void nnf_xht_lds_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+__global__ __launch_bounds__(256, (NTH == 2 ? 3 : 2)) void nnf_xht_lds_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                              const float* __restrict__ V, int64_t ldv, int r,
                                                              float* __restrict__ out, int64_t ldo, int a_vec_ok, int n_hi) {
     constexpr int MTA = MT + (REM > 0 ? 1 : 0);
@@ -174,7 +174,21 @@ static int launch_xht_lds(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, in
     const int64_t T = nnf_cdiv(m, 16), waves = 4 * slots;
     int nth = 4;
     int64_t n_hi, grid;
-    if (T > 4 * waves) {            // several rounds of 256-row workgroups
+    // A row pitch that is not a whole number of 128-byte lines leaves every 256-byte piece sharing its first and last line with
+    // the neighbouring chunks' pieces of the same row: the wave comes back for them one chunk later, after everything the XCD's
+    // 64 resident workgroups fetched in between -- 4 MB with 64-row waves, the size of the L2 (250000 x 500: 660 MB fetched for
+    // 500 MB, 127 us).  32-row waves (48 KB of LDS: three workgroups per CU) halve that distance: 559 MB, 120 us.  Aligned pitches
+    // have no shared lines and keep the 64-row waves (100000 x 2000 rank 32: 157 us against 175).
+    static const int pin = [] { const char* e = getenv("NNF_XHT_NT"); return e ? atoi(e) : 0; }();       // measurement knob
+    // (rows start on a line every 128 / gcd(pitch mod 128, 128) rows: the narrow form from every fourth row on -- with every
+    //  second row aligned, 100000 x 2000, the 64-row waves stay ahead, 159 us against 190)
+    int64_t off = (ldx * 4) % 128, gcd = 128;
+    while (off) { const int64_t t = gcd % off; gcd = off; off = t; }
+    const bool shared_lines = pin ? pin == 2 : (128 / gcd >= 4);
+    if (shared_lines) {
+        nth = 2;
+        n_hi = grid = nnf_cdiv(m, 128);
+    } else if (T > 4 * waves) {            // several rounds of 256-row workgroups
         n_hi = grid = nnf_cdiv(m, 256);
     } else if (T > 2 * waves) {     // one round: (4,3) or (3,2) tiles per wave
         nth = T > 3 * waves ? 4 : 3;
@@ -189,6 +203,9 @@ static int launch_xht_lds(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, in
     nnf_probe(ctx, NNF_PROBE_XHT, 0, st);
     if (nth == 4)
         hipLaunchKernelGGL((nnf_xht_lds_kernel<MT, REM, 4>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
+                           a_vec_ok, (int)n_hi);
+    else if (nth == 2)
+        hipLaunchKernelGGL((nnf_xht_lds_kernel<MT, REM, 2>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
                            a_vec_ok, (int)n_hi);
     else
         hipLaunchKernelGGL((nnf_xht_lds_kernel<MT, REM, 3>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,

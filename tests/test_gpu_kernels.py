@@ -85,7 +85,7 @@ def test_xht_row_tilings(eng, m, n, r):
 
 
 @pytest.mark.parametrize("m,n,r", [(1000, 260, 30), (513, 130, 17), (64, 64, 16), (300, 7, 3), (5, 300, 2), (257, 1, 1),
-                                   (1, 257, 1), (250000, 500, 30), (40000, 2000, 32), (777, 333, 20), (131075, 70, 19)])
+                                   (1, 257, 1), (250000, 500, 30), (40000, 2000, 32), (777, 333, 20), (131075, 70, 19), (70001, 500, 17), (300, 36, 32)])
 def test_xht_lds_staged_equals_direct_fragments(eng, m, n, r, monkeypatch):
     """The LDS-staged X H^T (k_xht_lds.hip) changes how X reaches the MFMA operands, not the arithmetic: same k order per
     accumulator as nnf_xht_kernel (NNF_XHT=direct) -- the results are equal bit for bit; padded rows with NaN in the padding."""

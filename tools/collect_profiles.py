@@ -19,7 +19,7 @@ configs = sys.argv[2:] or ["B", "C", "D"]
 MAIN = {"B": ["nnf_xty_kernel", "nnf_xht_kernel", "nnf_cost_kernel", "nnf_hals_kernel", "nnf_hals_wave_kernel", "nnf_gram_cost_kernel",
               "nnf_gram_kernel"],
         "C": ["nnf_mu_left_kernel", "nnf_mu_right_kernel", "nnf_cost_kernel"],
-        "D": ["nnf_mu_left_kernel", "nnf_mttkrp_rows_kernel", "nnf_xht_kernel", "nnf_hals_wave_kernel"]}
+        "D": ["nnf_mttkrp_rows_kernel", "nnf_xht_lds_kernel", "nnf_hals_wave_kernel", "nnf_gram_cost_kernel", "nnf_mu_left_kernel"]}
 for cfg in configs:
     O = os.path.join(G, f"prof_{cfg}")
     if not os.path.isdir(O):
@@ -36,7 +36,8 @@ for cfg in configs:
             fh.write(line[-1])
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in ("fetch", "write", "sq"):
-        for f in glob.glob(os.path.join(O, d, "**", "*counter_collection.csv"), recursive=True):
+        # (gpurun merges into gpurun_out/: files of earlier calls stay -- only the newest pass of each kind counts)
+        for f in sorted(glob.glob(os.path.join(O, d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
             for r in csv.DictReader(open(f)):
                 for k in MAIN.get(cfg, []):
                     if k in r["Kernel_Name"]:

@@ -101,6 +101,31 @@ def test_xht_lds_staged_equals_direct_fragments(eng, m, n, r, monkeypatch):
     assert torch.equal(got, want)
 
 
+def test_xht_lds_staged_random_shapes(eng, monkeypatch):
+    """Sixty random (m, n, r <= 32, pitch) draws -- every row-tile split (32- / 48- / 64-row waves, one round or several), aligned
+    and unaligned pitches, ragged column tails of every length class -- LDS-staged against fragment-load kernel, bit for bit."""
+    rng = np.random.RandomState(20261005)
+    for case in range(60):
+        m = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 127, 129, 1000, 4097, 33000, 70001, 98305, 140000]))
+        n = int(rng.choice([1, 3, 4, 5, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 500, 513]))
+        r = int(rng.choice([1, 2, 3, 15, 16, 17, 18, 19, 20, 29, 30, 31, 32]))
+        pad = int(rng.choice([0, 0, 4, 12, 28, 100]))
+        g = torch.Generator(device="cuda").manual_seed(case)
+        buf = torch.full((m, n + pad), float("nan"), device="cuda")
+        buf[:, :n] = torch.rand(m, n, device="cuda", generator=g) - 0.25
+        X = buf[:, :n]
+        V = torch.rand(r, n, device="cuda", generator=g)
+        monkeypatch.delenv("NNF_XHT", raising=False)
+        got = eng.xht(X, V).clone()
+        monkeypatch.setenv("NNF_XHT", "direct")
+        want = eng.xht(X, V)
+        assert torch.isfinite(got).all(), (m, n, r, pad)
+        assert torch.equal(got, want), (m, n, r, pad)
+        if case % 10 == 0:
+            ref = V.double() @ X.double().t()
+            assert float((got.double() - ref).norm() / ref.norm()) < 1e-5
+
+
 def test_views_with_leading_dimension(eng):
     """Row-sharded / padded storage: ld > cols, base pointer not 16-byte aligned."""
     rng = np.random.RandomState(5)

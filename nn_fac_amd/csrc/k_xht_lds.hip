@@ -14,15 +14,11 @@
 // The rank-side operand, the chunk loop, the leftover-rank FMAs and the epilogue are those of nnf_xht_kernel.
 // For ranks <= 32 (at most two staged rank tiles: 64 KB of X tiles + 16 KB of V images, two workgroups per CU).  Measured (tools/
 // probes/xht_probe.py): 250000 x 500 rank 30 (config D's partial product) 148 -> 127 us, 100000 x 2000 rank 32 188 -> 159, rank 16
-// 180 -> 153 (5.2 TB/s).  Ranks 33..64 were built too -- 8 waves sharing one image (160 KB, one workgroup per CU): 304-316 us
+// 180 -> 153 (5.2 TB/s); with 32-row waves where the pitch leaves shared boundary lines (launch_xht_lds) 127 -> 117.  Ranks 33..64 were built too -- 8 waves sharing one image (160 KB, one workgroup per CU): 304-316 us
 // against 228-245; 32-column steps with 128-byte pieces, three workgroups per CU: 234-254 -- and dropped: from three rank tiles
 // on the product is bound by the fp32 MFMA rate (6.1 row tiles per SIMD at 100000 rows = 167 us at 100 %, 7 on the busiest), not by
 // how X arrives.  They, and unaligned X, stay on nnf_xht_kernel.
 #include "k_stream_common.h"
-#ifndef XHT_LDS_ABL
-#define XHT_LDS_ABL 0   // timing-only ablations; 0 = the product
-#endif
-NNF_BUILD_FLAGS(k_xht_lds, "XHT_LDS_ABL=" NNF_STR(XHT_LDS_ABL))
 
 template <int MT, int REM, int NT>
 __device__ __forceinline__ void nnf_xht_lds_body(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,

@@ -373,6 +373,33 @@ def roof(kernel, bound, algo, ms, peak, unit, **more):
     return d
 
 
+def attach_traffic(entries, cfg_name):
+    """`traffic` of a roofline entry = HBM bytes per launch from the PMC passes of this same command committed under profiles/
+    (tools/bench_profile.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs, FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md, tools/collect_profiles.py) -- counters cannot be read from inside the process that is
+    being timed, so this is the committed figure for this configuration's shape, named as such; null where none was collected."""
+    path = os.path.join(ROOT, "profiles", f"r03_{cfg_name}_traffic.json")
+    if not os.path.exists(path):
+        return
+    try:
+        with open(path) as fh:
+            table = json.load(fh)
+    except (OSError, ValueError):
+        return
+    used = set()
+    for e in entries:
+        for key, row in table.items():
+            if key.startswith("_") or key in used or not isinstance(row, dict):
+                continue
+            if e["kernel"].startswith(key) and row.get("hbm_bytes_per_launch"):
+                e["traffic"] = int(row["hbm_bytes_per_launch"])
+                e["traffic_source"] = f"profiles/r03_{cfg_name}_traffic.json (PMC passes of this command, mean of {row.get('launches')} launches)"
+                if e.get("algorithmic_bytes"):
+                    e["traffic_over_algorithmic"] = e["traffic"] / e["algorithmic_bytes"]
+                used.add(key)
+                break
+
+
 def with_inloop(entry, times, algo, peak, unit, where):
     """Re-price a roofline entry on the launches of the product's loop: `launch_ms` / `achieved` / `frac` become the in-loop
     figures (mean over every launch recorded, nothing trimmed); the stand-alone figures move to `standalone`."""
@@ -454,7 +481,8 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta, loop_times=None, steps=20
         out.append(roof(f"V-side sweep kernel ({n} columns, rank {r}; few-column layout, per sweep over {ns} fixed sweeps)", "valu",
                         2.0 * r * r * n, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", algorithmic_flops=2.0 * r * r * n,
                         us_per_sweep=ms * 1e3, in_loop_solve=solves.get("V"),
-                        note="latency bound; in_loop_solve: the persistent solve of the loop, beside the cost kernel"))
+                        note="fixed-count launches (nnf_hals_sweeps_f32: four lanes per column), latency bound; in_loop_solve: the "
+                             "persistent solve of the loop -- nnf_hals_wave_kernel, one wave per column, 1.5-1.7 us per sweep"))
     else:
         k = 2.0 if float(beta) != 2.0 else 1.0
         c = torch.zeros(1, dtype=torch.float64, device=X.device)
@@ -622,7 +650,7 @@ def bench_ntf(cx, args, cfg, steps, warmup, with_cpu, with_kernels):
             torch.cuda.synchronize()
         Y = torch.empty((R, I, I), dtype=torch.float32, device=T.device)
         ms = eng.time_kernel("xht", lambda: eng.ttm3(T, Ft[2], 2, out=Y))
-        rl.append(roof("nnf_xht_kernel as T x_2 F2^T (the partial product Y, R x I x J, of the dimension tree)", "hbm", yb, ms,
+        rl.append(roof("nnf_xht_lds_kernel as T x_2 F2^T (the partial product Y, R x I x J, of the dimension tree)", "hbm", yb, ms,
                        HBM_PEAK_GBS, "GB/s", algorithmic_bytes=yb, algorithmic_flops=fl, tflops=fl / ms / 1e9))
         with_inloop(rl[-1], il_y.times()[-steps:], yb, HBM_PEAK_GBS, "GB/s",
                     f"HIP events around this kernel's launches in {steps} further iterations of the same loop")
@@ -700,6 +728,8 @@ def main():
             workload = (f"NTF hals, {cfg['m']}^3 rank {cfg['r']} per GPU ({cfg['ref']} of BASELINE.json), alpha=inf, "
                         f"delta=0.01, maxiter=100")
         rl = res.get("rooflines") or []
+        if rl and not args.shape and world == 1:
+            attach_traffic(rl, args.config)
         out = {
             "metric": what + shape_note,
             "value": res["value"],

@@ -381,3 +381,33 @@ def test_deep_nmf_driver_against_reference_fixture(golden, built_lib):
     for i in range(3):
         assert rel(W[i], Wo[i]) < 2e-4 and rel(H[i], Ho[i]) < 2e-4
     np.testing.assert_allclose(rec, reco, rtol=2e-4)
+
+
+@pytest.mark.parametrize("fixed,sparsity,normalize", [([0], [None, None], [False, False]), ([], [0.1, 0.05], [False, False]),
+                                                       ([], [None, 0.2], [True, False]), ([1], [None, None], [False, False]),
+                                                       ([], [None, None], [False, True])])
+def test_hals_options_against_oracle(built_lib, fixed, sparsity, normalize, monkeypatch):
+    """Fixed modes, sparsity terms (matrix 1-norms added to the identity cost afterwards, nmf.py:452) and normalised factors through
+    the HALS loop: factors, costs and sweep counts against the fp64 oracle; same factors whichever kernel evaluates the cost
+    (mode 1 fixed: there is no V update whose operands could carry the identity, the streaming kernel runs)."""
+    from nn_fac_amd.nmf import compute_nmf
+    X, U0, V0 = orc.synth_nmf(1500, 260, 9, seed=21, dtype=np.float32)
+    kw = dict(n_iter_max=5, tol=0, update_rule="hals", return_costs=True, deterministic=True)
+    sw, swo = [], []
+    U, V, costs, _ = compute_nmf(X, 9, U0, V0, sparsity_coefficients=list(sparsity), fixed_modes=list(fixed),
+                                 normalize=list(normalize), sweep_log=sw, **kw)
+    Uo, Vo, co, _ = orc.compute_nmf(X.astype(np.float64), 9, U0.astype(np.float64), V0.astype(np.float64),
+                                    sparsity_coefficients=list(sparsity), fixed_modes=list(fixed), normalize=list(normalize),
+                                    sweeps=swo, **kw)
+    # sweep counts equal -- up to ONE solve stopping a sweep apart (a stop within fp32 noise of the threshold, DESIGN.md section 4:
+    # 93 against 92 sweeps in the last solve of the normalised-U case), the factors then compared at the looser documented bound
+    off = [i for i, (a, b) in enumerate(zip(sw, swo)) if a != b]
+    assert len(sw) == len(swo) and len(off) <= 1 and all(abs(sw[i] - swo[i]) == 1 for i in off), (sw, swo)
+    bound = HALS_FRO if not off else 2e-3
+    assert rel(U, Uo) < bound and rel(V, Vo) < bound
+    np.testing.assert_allclose(costs, co, rtol=HALS_COST)
+    monkeypatch.setenv("NNF_COST", "direct")
+    U2, V2, costs2, _ = compute_nmf(X, 9, U0, V0, sparsity_coefficients=list(sparsity), fixed_modes=list(fixed),
+                                    normalize=list(normalize), **kw)
+    assert np.array_equal(U, U2) and np.array_equal(V, V2)
+    np.testing.assert_allclose(costs, costs2, rtol=5e-4)

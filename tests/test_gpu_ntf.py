@@ -296,3 +296,42 @@ def test_ntf_order_n(built_lib, shape, R, rule, beta):
         assert F[i].shape == Fo[i].shape and rel(F[i], Fo[i]) < tol, (i, rel(F[i], Fo[i]))
     np.testing.assert_allclose(costs, co, rtol=2e-3 if rule == "hals" else 1e-4)
     assert sw == swo
+
+
+@pytest.mark.parametrize("shape,R,fixed,sparsity,normalize", [
+    ((30, 25, 20), 4, [2], [0.05, None, None], [False, False, False]),
+    ((30, 25, 20), 4, [0], [None, None, None], [False, True, False]),
+    ((30, 25, 20), 4, [], [None, 0.1, 0.02], [True, False, False]),
+    ((12, 10, 9, 8), 3, [3], [None, 0.05, None, None], [False, False, True, False]),
+    ((12, 10, 9, 8), 3, [0, 2], [None] * 4, [False] * 4),
+])
+def test_ntf_hals_options_against_oracle(built_lib, shape, R, fixed, sparsity, normalize, monkeypatch):
+    """Fixed modes (the LAST UPDATED mode, whose operands carry the identity cost, is then not the last mode), sparsity terms
+    (added to the identity cost afterwards: matrix 1-norms, ntf.py:466-470) and normalised factors, order 3 and 4: factors, costs
+    and inner sweep counts against the fp64 oracle; the factors do not depend on how the cost is evaluated."""
+    from nn_fac_amd.ntf import compute_ntf
+    rng = np.random.RandomState(sum(shape) + R + len(fixed))
+    true = [rng.rand(s, R) for s in shape]
+    T = true[0]
+    for f in true[1:]:
+        T = T[..., None, :] * f
+    T = (T.sum(-1) + 0.05 * rng.rand(*shape)).astype(np.float32)
+    F0 = [rng.rand(s, R).astype(np.float32) + 0.1 for s in shape]
+    kw = dict(n_iter_max=5, tol=0, update_rule="hals", return_costs=True, alpha=math.inf, fixed_modes=list(fixed),
+              sparsity_coefficients=list(sparsity), normalize=list(normalize))
+    sw, swo = [], []
+    F, costs, _ = compute_ntf(T, R, F0, sweep_log=sw, **kw)
+    kwo = dict(kw, sparsity_coefficients=list(sparsity), fixed_modes=list(fixed), normalize=list(normalize))
+    Fo, co, _ = orc.compute_ntf(T.astype(np.float64), R, [f.astype(np.float64) for f in F0], sweeps=swo, **kwo)
+    assert sw == swo
+    np.testing.assert_allclose(costs, co, rtol=2e-3)
+    for i, (a, b) in enumerate(zip(F, Fo)):
+        assert rel(a, b) < 2e-3, i
+        if i in fixed:
+            assert np.array_equal(np.asarray(a), F0[i])
+    monkeypatch.setenv("NNF_COST", "direct")
+    F2, costs2, _ = compute_ntf(T, R, F0, **dict(kw, sparsity_coefficients=list(sparsity), fixed_modes=list(fixed),
+                                                 normalize=list(normalize)))
+    for a, b in zip(F, F2):
+        assert np.array_equal(a, b)
+    np.testing.assert_allclose(costs, costs2, rtol=5e-4)

@@ -179,12 +179,25 @@ class Engine:
 
     def _check_rowsync_columns(self, rowsync, ncols):
         """normalize=True / nonzero=True need a grid-wide reduction per ROW update, which the generic kernel does with every
-        column resident (one per thread, 4 x 128-thread workgroups per CU): say so here instead of a bare status code."""
+        column resident (one per thread, 4 x 128-thread workgroups per CU): say so here instead of a bare status code.
+        (normalize alone goes on beyond that limit, row by row: _hals_solve_rowwalk; the nonzero guard does not.)"""
         if rowsync and ncols > self.ROWSYNC_MAX_COLUMNS:
-            raise EngineError(f"hals_nnls_acc with normalize=True or nonzero=True is built for at most "
+            raise EngineError(f"hals_nnls_acc with nonzero=True (and fixed-count sweeps with normalize=True) is built for at most "
                               f"{self.ROWSYNC_MAX_COLUMNS} columns (got {ncols}): every row update needs all columns "
                               f"resident on the device at once; normalise the shorter factor, or split the columns and "
                               f"normalise on the host between outer iterations")
+
+    def _hals_solve_rowwalk(self, UtM, UtU, V, max_sweeps, delta, sparsity, st):
+        """hals_nnls_acc(..., normalize=True) on more columns than the generic kernel keeps resident: the rows are walked from
+        the host -- row update over all columns (nnf_hals_row_update_f32), row norm, scaling (nnf_hals_row_scale_f32), r x 2
+        launches per sweep and one host round trip per sweep for the stopping rule of nnls.py:156 -- the one-device form of the
+        row-sharded protocol (dist.sharded_hals_solve_rownorm, which this calls without a group).  Correct and slow (a sweep of a
+        rank-50 factor is 100 launches): the option is on no BASELINE configuration."""
+        from . import dist as _dist
+        eps, cnt, eps0 = _dist.sharded_hals_solve_rownorm(self, UtM, UtU, V, None, budget=int(max_sweeps), delta=float(delta),
+                                                          sparsity=sparsity)
+        st[:4] = torch.tensor([eps, float(cnt), eps0, 0.0], dtype=torch.float64)
+        return st
 
     HALS_MAX_SWEEPS_PER_LAUNCH = 1000     # NNF_HALS_MAX_SWEEPS (exchange tags hold the sweep index in 10 bits)
 
@@ -197,6 +210,8 @@ class Engine:
             raise EngineError("hals_solve: shape mismatch")
         st = status if status is not None else torch.empty(ST_WORDS, dtype=torch.float64, device=V.device)
         flags = self._hals_flags(sparsity, normalize, nonzero)
+        if normalize and not nonzero and ncols > self.ROWSYNC_MAX_COLUMNS and int(max_sweeps) > 0:
+            return self._hals_solve_rowwalk(UtM, UtU, V, max_sweeps, delta, sparsity, st)
         self._check_rowsync_columns(normalize or nonzero, ncols)
         total, first = int(max_sweeps), min(int(max_sweeps), self.HALS_MAX_SWEEPS_PER_LAUNCH)
         _lib.check(self.lib.nnf_hals_solve_f32(self.ctx, _ptr(UtM), _ld(UtM), _ptr(UtU), _ld(UtU), _ptr(V),
@@ -219,8 +234,13 @@ class Engine:
         if UtM.shape != (r, ncols) or V_in.shape != (r, ncols) or Ga.shape[0] < r or (Gb is not None and
                                                                                        (Gb.shape != Ga.shape or _ld(Gb) != _ld(Ga))):
             raise EngineError("hals_solve_cross: shape mismatch")
-        self._check_rowsync_columns(normalize, ncols)
         st = status if status is not None else torch.empty(ST_WORDS, dtype=torch.float64, device=V_out.device)
+        if normalize and ncols > self.ROWSYNC_MAX_COLUMNS and int(max_sweeps) > 0:
+            if V_out.data_ptr() != V_in.data_ptr():
+                V_out.copy_(V_in)
+            return self._hals_solve_rowwalk(UtM, Ga if Gb is None else self.hadamard(Ga[:r, :r], Gb[:r, :r]), V_out, max_sweeps,
+                                            delta, sparsity, st)
+        self._check_rowsync_columns(normalize, ncols)
         _lib.check(self.lib.nnf_hals_solve_cross_f32(self.ctx, _ptr(UtM), _ld(UtM), _ptr(Ga), _ptr(Gb) if Gb is not None else None,
                                                      _ld(Ga), _ptr(V_in), _ld(V_in), _ptr(V_out), _ld(V_out), r, ncols,
                                                      int(max_sweeps), float(delta), float(sparsity or 0.0),

@@ -642,3 +642,29 @@ def test_c_abi_rccl_communicator_single_rank(built_lib):
     torch.cuda.synchronize()
     assert torch.equal(a, a0) and torch.equal(b, b0)
     comm.close()
+
+
+def test_hals_normalize_beyond_the_resident_column_limit(built_lib):
+    """normalize=True needs the norm of a whole row after every row update (nnls.py:179-185); the generic kernel does that with
+    every column resident (<= 131072).  Beyond, the rows are walked from the host (Engine._hals_solve_rowwalk: row update, norm,
+    scaling -- the one-device form of the row-sharded protocol): same result, same sweep count as the oracle; nonzero=True,
+    which has no row-walked form, says so."""
+    from nn_fac_amd.update_rules.nnls import hals_nnls_acc
+    from nn_fac_amd.engine import EngineError
+    rng = np.random.RandomState(17)
+    r, n = 5, 140001
+    A = rng.rand(40, r)
+    UtU = A.T @ A
+    UtM = A.T @ (A @ rng.rand(r, n) + 0.1 * rng.rand(40, n))
+    V0 = rng.rand(r, n)
+    for sp in (None, 0.05):
+        Vo, epso, cnto, _ = orc.hals_nnls_acc(UtM, UtU, V0, maxiter=6, alpha=math.inf, delta=0.01, sparsity_coefficient=sp,
+                                              normalize=True)
+        V, eps, cnt, _ = hals_nnls_acc(UtM.astype(np.float32), UtU.astype(np.float32), V0.astype(np.float32), maxiter=6,
+                                       alpha=math.inf, delta=0.01, sparsity_coefficient=sp, normalize=True)
+        assert cnt == cnto
+        assert rel(V, Vo) < 2e-4 and abs(eps - epso) <= 5e-3 * abs(epso)
+        np.testing.assert_allclose(np.linalg.norm(np.asarray(V, dtype=np.float64), axis=1), 1.0, rtol=1e-5)
+    with pytest.raises(EngineError):
+        hals_nnls_acc(UtM.astype(np.float32), UtU.astype(np.float32), V0.astype(np.float32), maxiter=3, alpha=math.inf,
+                      nonzero=True)

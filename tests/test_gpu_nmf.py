@@ -411,3 +411,17 @@ def test_hals_options_against_oracle(built_lib, fixed, sparsity, normalize, monk
                                     normalize=list(normalize), **kw)
     assert np.array_equal(U, U2) and np.array_equal(V, V2)
     np.testing.assert_allclose(costs, costs2, rtol=5e-4)
+
+
+def test_hals_normalised_long_factor(built_lib):
+    """normalize=[True, False] with more rows than the generic sweep kernel keeps resident (131072 columns of U^T): the U-side
+    solve walks its rows from the host (Engine._hals_solve_rowwalk) -- two iterations against the fp64 oracle."""
+    from nn_fac_amd.nmf import compute_nmf
+    X, U0, V0 = orc.synth_nmf(140001, 40, 4, seed=33, dtype=np.float32)
+    kw = dict(n_iter_max=2, tol=0, update_rule="hals", return_costs=True, deterministic=True, normalize=[True, False])
+    sw, swo = [], []
+    U, V, costs, _ = compute_nmf(X, 4, U0, V0, sweep_log=sw, **kw)
+    Uo, Vo, co, _ = orc.compute_nmf(X.astype(np.float64), 4, U0.astype(np.float64), V0.astype(np.float64), sweeps=swo, **kw)
+    assert sw == swo
+    assert rel(U, Uo) < HALS_FRO and rel(V, Vo) < HALS_FRO
+    np.testing.assert_allclose(costs, co, rtol=HALS_COST)

@@ -286,8 +286,8 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
     # the streaming kernel.  Row-sharded: every operand is replicated (||X||^2 summed once), so the cost needs no collective.
     # NNF_COST=direct in the environment forces the streaming kernel.
     # `tol` given (the caller stops on |cost[i-1] - cost[i]| < tol, nmf.py:320): an iterate whose difference to its predecessor
-    # is within the two error estimates of `tol` is treated the same way, and the predecessor's cost is re-evaluated by the
-    # streaming kernel too and handed to `retired.revise_last` -- the stopping test never compares costs it cannot tell apart.
+    # is within the two error estimates of `tol` is treated the same way.  At either switch the predecessor's cost is re-evaluated
+    # by the streaming kernel too and handed to `retired.revise_last` -- the stopping test never compares costs of two kinds.
     ident = (cuda and update_rule == "hals" and 1 not in fixed_modes and isinstance(eng, _engine.Engine)
              and not ws.direct_cost and os.environ.get("NNF_COST") != "direct")
     if ident and ws.normx2 is None:
@@ -433,11 +433,13 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
             fall_back()
             Ut, V = result                        # factors of the last iteration that retired cleanly
             iteration = failed
-        except _IdentityUnreliable as why:
+        except _IdentityUnreliable:
             failed = pending[0]["it"]
             drain()
             pending.clear()
-            if isinstance(why, _IdentityNearStop) and hasattr(retired, "revise_last"):
+            if last is not None and hasattr(retired, "revise_last"):
+                # whichever test failed: the iterate before it was costed by the identity -- re-evaluate it too, so that the
+                # stopping test never compares a cost of one kind with a cost of the other
                 scratch = torch.zeros_like(ws.block)
                 _step_cost(eng, X, result[0], result[1], update_rule, beta, sparsity_coefficients, scratch, group)
                 retired.revise_last(float(scratch[16]))

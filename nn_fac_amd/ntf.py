@@ -349,7 +349,7 @@ def run_ntf_steps(st, rank, Ft, n_iter, update_rule, beta, sparsity_coefficients
     HALS costs come from the Gram identity (_ntf_cost) while the kernel's own error estimate stays below 5e-4 of the cost
     and -- `tol` given: the caller stops on |cost[i-1] - cost[i]| < tol (ntf.py:337) -- while that difference is further
     from `tol` than the two estimates together.  The first iterate that fails either test is evaluated again by the pass
-    over T, and so is every later one; in the second case the previous iterate's cost is re-evaluated as well and handed to
+    over T, and so is every later one; the previous iterate's cost is re-evaluated as well and handed to
     `retired.revise_last`, so that the stopping test only ever compares two costs of the same kind."""
     cuda = st.T.is_cuda
     main = torch.cuda.current_stream(st.T.device) if cuda else None
@@ -420,7 +420,7 @@ def run_ntf_steps(st, rank, Ft, n_iter, update_rule, beta, sparsity_coefficients
             st.async_misses += 1
             Ft = result
             iteration = failed
-        except _IdentityUnreliable as why:
+        except _IdentityUnreliable:
             # this iteration again, and every later one, with the pass over T (every rank: the words are replicated)
             failed = pending[0]["it"]
             main.synchronize()
@@ -428,9 +428,10 @@ def run_ntf_steps(st, rank, Ft, n_iter, update_rule, beta, sparsity_coefficients
             st.direct_cost, ident = True, False
             Ft = result
             iteration = failed
-            if isinstance(why, _IdentityNearStop) and hasattr(retired, "revise_last"):
-                # the iterate before it too: the stopping test then compares two costs of the same kind.  Its pass leaves the
-                # partial product the repeated iteration starts from (st.partial finds it)
+            if last is not None and hasattr(retired, "revise_last"):
+                # whichever test failed, the iterate before it was costed by the identity: re-evaluate it too -- the stopping test
+                # then compares two costs of the same kind.  Its pass leaves the partial product the repeated iteration starts
+                # from (st.partial finds it)
                 tree = (st.nway == 3 and math.isinf(alpha) and 0 not in fixed_modes and 1 not in fixed_modes
                         and hasattr(st.eng, "mttkrp3_from_partial"))
                 words = torch.zeros(3, dtype=torch.float64, device=st.T.device)

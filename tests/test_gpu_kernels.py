@@ -531,10 +531,12 @@ def test_mu_right_accumulate_then_apply(eng, beta):
     assert rel(got.cpu().numpy(), want.cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("rule,beta,extra", [("hals", 2, []), ("mu", 1, []), ("mu", 2, []), ("hals", 2, ["normalize"])])
+@pytest.mark.parametrize("rule,beta,extra", [("hals", 2, []), ("mu", 1, []), ("mu", 2, []), ("hals", 2, ["normalize"]),
+                                             ("hals", 2, ["-", "stop"])])
 def test_row_sharded_two_ranks_on_one_gpu(built_lib, rule, beta, extra):
     """Two gloo ranks sharing the GPU run the real sharded step (tools/dist_gpu_check.py) against the single-process run;
-    "normalize": the sharded factor is normalised (row norms across both ranks, nnf_hals_row_update_f32 / _scale_f32)."""
+    "normalize": the sharded factor is normalised (row norms across both ranks, nnf_hals_row_update_f32 / _scale_f32);
+    "stop": a run with `tol` between two cost differences -- the identity cost's near-threshold switch in a sharded run."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -542,6 +544,8 @@ def test_row_sharded_two_ranks_on_one_gpu(built_lib, rule, beta, extra):
                           "127.0.0.1", "--master-port", "29533", os.path.join(root, "tools", "dist_gpu_check.py"), rule,
                           str(beta)] + extra, capture_output=True, text=True, timeout=300, env=env)
     assert "DIST_GPU_CHECK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    if "stop" in extra:     # + the stopping test under the identity cost: both ranks switch to the direct cost together
+        assert "DIST_GPU_STOP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 @pytest.mark.parametrize("layout", LAYOUTS + ["generic"])

@@ -48,4 +48,33 @@ if rank == 0:
     tol = 5e-4 if NORM[0] else 1e-4      # (normalised: six iterations of 100-sweep solves, the row norms summed in another order)
     assert sweeps == s1 and relV < tol and relU < tol and len(costs) == len(c1) == iters and all(abs(a - b) <= tol * b for a, b in zip(costs, c1))
     print("DIST_GPU_CHECK_OK")
+if len(sys.argv) > 4 and sys.argv[4] == "stop" and RULE == "hals":
+    # the stopping test under the Gram-identity cost in a SHARDED run: `tol` between two cost differences of the run above -- both
+    # ranks must take the near-threshold branch together (its cost pass is a collective) and stop where the single process stops
+    d = [abs(costs[i - 1] - costs[i]) for i in range(1, len(costs))]
+    tol = 0.5 * (d[2] + d[3])
+
+    def stopper(cs):
+        def retired(it, cost, s):
+            cs.append(cost)
+            return it > 0 and abs(cs[-2] - cs[-1]) < tol
+
+        def revise_last(cost):
+            cs[-1] = cost
+        retired.revise_last = revise_last
+        return retired
+    Ut2 = torch.from_numpy(U0[lo:hi].T.copy()).cuda()
+    ws2 = nm._StepBuffers(Xl, r)
+    cs2 = []
+    nm.run_steps(eng, ws2, Xl, r, Ut2, torch.from_numpy(V0).cuda(), 12, RULE, BETA, [None, None], [], NORM, True, stopper(cs2),
+                 group=dist.group.WORLD, tol=tol)
+    if rank == 0:
+        ws3 = nm._StepBuffers(Xd, r)
+        cs3 = []
+        nm.run_steps(eng, ws3, Xd, r, torch.from_numpy(U0.T.copy()).cuda(), torch.from_numpy(V0).cuda(), 12, RULE, BETA,
+                     [None, None], [], NORM, True, stopper(cs3), tol=tol)
+        print("stop: sharded", len(cs2), "iterations, single", len(cs3), "direct cost from", ws2.direct_cost, ws3.direct_cost)
+        assert len(cs2) == len(cs3) < 12 and ws2.direct_cost and ws3.direct_cost
+        assert all(abs(a - b) <= 1e-4 * b for a, b in zip(cs2, cs3))
+        print("DIST_GPU_STOP_OK")
 dist.barrier(); dist.destroy_process_group()

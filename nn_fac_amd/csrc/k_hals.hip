@@ -220,11 +220,12 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     // NNF_HALS_FORCE=lane|quad pins the column layout (tests exercise both kernels on the same fixtures)
     const char* force = getenv("NNF_HALS_FORCE");
     const bool force_lane = force && force[0] == 'l', force_quad = force && force[0] == 'q', force_wave = force && force[0] == 'w';
+    const bool force_mfma = force && force[0] == 'm';
     // fewer still (<= 4800, a persistent solve from its first sweep): one wave per column, push form (k_hals_wave.hip)
-    const bool wave = !generic && MODE == 0 && sweep0 == 0 && !force_lane && !force_quad && nsweeps <= NNF_HALS_MAX_SWEEPS &&
+    const bool wave = !generic && MODE == 0 && sweep0 == 0 && !force_lane && !force_quad && !force_mfma && nsweeps <= NNF_HALS_MAX_SWEEPS &&
                       nnf_hals_wave_fits(ctx, r, ncols, max_blocks);
     (void)force_wave;
-    const bool quad = !wave && !generic && !force_lane && (ncols <= 32768 || force_quad) && (int64_t)(r + 16) * (ldv > ldm ? ldv : ldm) * 4 < (int64_t)0x7fff0000 &&
+    const bool quad = !wave && !generic && !force_lane && !force_mfma && (ncols <= 32768 || force_quad) && (int64_t)(r + 16) * (ldv > ldm ? ldv : ldm) * 4 < (int64_t)0x7fff0000 &&
                       nnf_hals_quad_fits(ctx, r, ncols, max_blocks);
     if (getenv("NNF_HALS_DEBUG"))
         fprintf(stderr, "[nnf hals] r=%d ncols=%lld mode=%d sweeps=%d layout=%s\n", r, (long long)ncols, MODE, nsweeps,
@@ -234,6 +235,10 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     size_t gfloats = gs_off + (want_gs ? (size_t)RP * RS : 0);
     if (quad && nnf_hals_quad_gram_floats(r) > gfloats) gfloats = nnf_hals_quad_gram_floats(r);
     if (wave && nnf_hals_wave_gram_floats(r) > gfloats) gfloats = nnf_hals_wave_gram_floats(r);
+    // many columns, ranks 48..100: the push form on the matrix cores (k_hals_mfma.hip) when every column stays resident
+    const bool try_mfma = !generic && !quad && !wave && !force_lane && nsweeps > 0 && nnf_hals_mfma_supported(RP);
+    float* Gm = try_mfma ? (float*)cur.take(nnf_hals_mfma_gram_floats(RP) * 4) : nullptr;
+    if (try_mfma && !Gm) return NNF_ERR_WORKSPACE;
     float* Gp = (float*)cur.take(gfloats * 4);   // padded Gram, then the (1/diag, nz) pairs (quad: scaled Gram, 1/diag)
     float* dinv = Gp ? Gp + (size_t)RP * RS : nullptr;
     unsigned* counter = (unsigned*)cur.take(256);
@@ -323,6 +328,13 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
         hals_args a{UtM, ldm, Gp, dinv, want_gs ? Gp + gs_off : nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status,
                     sweep_partials, snapshots, snap_stride, sweep0, Vsrc, ldvs};
         nnf_probe(ctx, NNF_PROBE_HALS, 0, st);
+        rc = NNF_ERR_UNSUPPORTED;
+        if (try_mfma) rc = nnf_hals_mfma_run(ctx, RP, UtU, ldg, Gm, a, max_blocks, &nblocks, st);
+        if (rc == NNF_OK) {
+            if (getenv("NNF_HALS_DEBUG")) fprintf(stderr, "[nnf hals] -> mfma kernel, %d workgroups\n", nblocks);
+        } else if (rc != NNF_ERR_UNSUPPORTED || force_mfma) {
+            return rc;
+        } else
         if (RP <= 48) rc = nnf_hals_fast_part0(ctx, RP, a, max_blocks, &nblocks, st);
         else if (RP <= 64) rc = nnf_hals_fast_part1(ctx, RP, a, max_blocks, &nblocks, st);
         else if (RP <= 104) rc = nnf_hals_fast_part2(ctx, RP, a, max_blocks, &nblocks, st);

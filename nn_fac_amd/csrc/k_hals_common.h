@@ -349,6 +349,9 @@ struct hals_args {
     int sweep0;           // mode 0: sweeps already done by earlier launches of the same solve (nnf_hals_solve_continue_f32)
     const float* Vsrc;    // start values (r x ncols, row stride ldvs); == V for an in-place solve (quad kernel; the other
     int64_t ldvs;         // layouts get a copy made by the entry point)
+    const float* Mimg;    // k_hals_mfma.hip: Gram image in MFMA fragment order, in-block couplings; padded rank of the dinv table
+    const float* Mlt;
+    int rp;
 };
 
 // Continuation of a solve longer than one launch can tag (NNF_HALS_MAX_SWEEPS): `status` holds the state the previous launch
@@ -374,6 +377,12 @@ size_t nnf_hals_wave_gram_floats(int r);
 size_t nnf_hals_wave_snap_floats(int r, int64_t ncols);
 int nnf_hals_wave_run(nnf_ctx*, const float* UtU, const float* UtU2, int64_t ldg, float* Gw, float* snap, unsigned* counter,
                       hals_args a, int* nblocks_out, hipStream_t);
+
+// k_hals_mfma.hip: push form on the matrix cores, many columns, ranks 48..100 (resident columns only)
+bool nnf_hals_mfma_supported(int RP);
+size_t nnf_hals_mfma_gram_floats(int RP);
+int nnf_hals_mfma_run(nnf_ctx*, int RP, const float* UtU, int64_t ldg, float* gram, hals_args a, int max_blocks_cap, int* nblocks_out,
+                      hipStream_t);
 
 // k_hals_quad.hip: four lanes per column, for solves with few columns
 bool nnf_hals_quad_fits(nnf_ctx*, int r, int64_t ncols, int max_blocks_cap);

@@ -175,6 +175,21 @@ int nnf_hals_sweeps_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float
                         int r, int64_t ncols, int nsweeps, float sparsity, unsigned flags, double* nodelta_f64,
                         float* snapshots, int64_t snap_stride, void* stream);
 
+/* The same blind sweeps as a CONTINUATION of a solve (the chunks of the row-sharded protocol; nnls.py:156-196 run in pieces):
+ * `sweeps_done` sweeps of this solve have run in earlier calls.  At ranks 64..100 and many columns the sweeps run on the matrix
+ * cores (k_hals_mfma.hip) and keep a scaled residual per column next to V; resid_in / resid_out (nnf_hals_resid_floats() floats
+ * each, opaque layout, caller-owned; distinct buffers) hand it from call to call, and then the chunks of a solve leave bit for
+ * bit what ONE call of all the sweeps leaves.  resid_in NULL (first chunk, or a caller that does not care): the residual is
+ * formed from V; resid_out NULL: not kept.  The other kernel layouts carry no state and ignore both.
+ * snap_first: the first sweep of this call (0-based) that writes a snapshot -- `head` blind sweeps and a window of snapshots
+ * are ONE launch; snapshot block j receives V after sweep snap_first + j + 1 of this call (nsweeps - snap_first blocks). */
+int nnf_hals_sweeps_ex_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V, int64_t ldv,
+                           int r, int64_t ncols, int nsweeps, int sweeps_done, float sparsity, unsigned flags,
+                           double* nodelta_f64, float* snapshots, int64_t snap_stride, int snap_first, const float* resid_in,
+                           float* resid_out, void* stream);
+/* Floats per residual-state buffer of nnf_hals_sweeps_ex_f32 for an r x ncols factor; 0 when the layout that runs keeps none. */
+int nnf_hals_resid_floats(nnf_ctx* ctx, int r, int64_t ncols, int64_t* floats_out);
+
 /* Row-sharded solves that normalise the SHARDED factor (nmf(normalize=[True, .]) over several ranks): the row
  * norm of nnls.py:179-185 runs over the columns of all ranks, once per row update, so the host walks the rows:
  *   nnf_hals_row_update_f32  row k of V (r x ncols: this rank's columns) gets the update of nnls.py:162-170;

@@ -45,6 +45,9 @@ SIGNATURES = {
     "nnf_hals_row_scale_f32": (_i32, [_p, _p, _i64, _i64, _i32, _p, _i64, _p]),
     "nnf_hals_stop_restore_f32": (_i32, [_p, _p, _i32, _i32, _i32, _f64, _p, _i64, _i32, _i64, _p, _i64, _p, _p]),
     "nnf_hals_sweeps_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _f32, _u32, _p, _p, _i64, _p]),
+    "nnf_hals_sweeps_ex_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _i32, _f32, _u32, _p, _p, _i64, _i32,
+                                      _p, _p, _p]),
+    "nnf_hals_resid_floats": (_i32, [_p, _i32, _i64, C.POINTER(_i64)]),
     "nnf_ctx_set_probe": (_i32, [_p, _p, _p]),
     "nnf_ctx_set_probe_kernel": (_i32, [_p, _i32]),
     "nnf_ctx_set_probe_ring": (_i32, [_p, C.POINTER(_p), _i32]),

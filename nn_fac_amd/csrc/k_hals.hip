@@ -199,11 +199,22 @@ static int64_t lane_resident_blocks(nnf_ctx* ctx, int RP) {
     return rc == NNF_OK ? nb : 0;
 }
 
+// Many columns at ranks 64..100: the push form on the matrix cores (k_hals_mfma.hip); below rank 64 a k-block has too few
+// MFMAs to cover its own gather -> update -> scatter chain (measured: 9.7-10.6 against 9.4-9.6 us per sweep at rank 50).
+static bool hals_mfma_default(int RP, int64_t ncols) {
+    const char* force = getenv("NNF_HALS_FORCE");
+    if (force && (force[0] == 'l' || force[0] == 'q' || force[0] == 'w')) return false;
+    if (!nnf_hals_mfma_supported(RP)) return false;
+    if (force && force[0] == 'm') return true;
+    return RP >= 64 && ncols > 32768;
+}
+
 template <int MODE>
 static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V, int64_t ldv,
                       int r, int64_t ncols, int nsweeps, double delta, float sparsity, unsigned flags, double* status,
                       double* nodelta_out, hipStream_t st, float* snapshots = nullptr, int64_t snap_stride = 0,
-                      int sweep0 = 0, const float* UtU2 = nullptr, const float* Vsrc = nullptr, int64_t ldvs = 0) {
+                      int sweep0 = 0, const float* UtU2 = nullptr, const float* Vsrc = nullptr, int64_t ldvs = 0,
+                      int snap_first = 0, const float* resid_in = nullptr, float* resid_out = nullptr) {
     if (!ctx || !UtM || !UtU || !V || r < 1 || ncols < 1 || ldm < ncols || ldv < ncols || ldg < r || nsweeps < 0)
         return NNF_ERR_ARG;
     if (MODE == 0 && !status) return NNF_ERR_ARG;
@@ -222,10 +233,11 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     const bool force_lane = force && force[0] == 'l', force_quad = force && force[0] == 'q', force_wave = force && force[0] == 'w';
     const bool force_mfma = force && force[0] == 'm';
     // fewer still (<= 4800, a persistent solve from its first sweep): one wave per column, push form (k_hals_wave.hip)
-    const bool wave = !generic && MODE == 0 && sweep0 == 0 && !force_lane && !force_quad && !force_mfma && nsweeps <= NNF_HALS_MAX_SWEEPS &&
+    const bool want_mfma = !generic && nsweeps > 0 && hals_mfma_default(RP, ncols);
+    const bool wave = !generic && MODE == 0 && sweep0 == 0 && !force_lane && !force_quad && !(force_mfma && want_mfma) && nsweeps <= NNF_HALS_MAX_SWEEPS &&
                       nnf_hals_wave_fits(ctx, r, ncols, max_blocks);
     (void)force_wave;
-    const bool quad = !wave && !generic && !force_lane && !force_mfma && (ncols <= 32768 || force_quad) && (int64_t)(r + 16) * (ldv > ldm ? ldv : ldm) * 4 < (int64_t)0x7fff0000 &&
+    const bool quad = !wave && !generic && !force_lane && !(force_mfma && want_mfma) && (ncols <= 32768 || force_quad) && (int64_t)(r + 16) * (ldv > ldm ? ldv : ldm) * 4 < (int64_t)0x7fff0000 &&
                       nnf_hals_quad_fits(ctx, r, ncols, max_blocks);
     if (getenv("NNF_HALS_DEBUG"))
         fprintf(stderr, "[nnf hals] r=%d ncols=%lld mode=%d sweeps=%d layout=%s\n", r, (long long)ncols, MODE, nsweeps,
@@ -236,7 +248,7 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     if (quad && nnf_hals_quad_gram_floats(r) > gfloats) gfloats = nnf_hals_quad_gram_floats(r);
     if (wave && nnf_hals_wave_gram_floats(r) > gfloats) gfloats = nnf_hals_wave_gram_floats(r);
     // many columns, ranks 48..100: the push form on the matrix cores (k_hals_mfma.hip) when every column stays resident
-    const bool try_mfma = !generic && !quad && !wave && !force_lane && nsweeps > 0 && nnf_hals_mfma_supported(RP);
+    const bool try_mfma = want_mfma && !quad && !wave;
     float* Gm = try_mfma ? (float*)cur.take(nnf_hals_mfma_gram_floats(RP) * 4) : nullptr;
     if (try_mfma && !Gm) return NNF_ERR_WORKSPACE;
     float* Gp = (float*)cur.take(gfloats * 4);   // padded Gram, then the (1/diag, nz) pairs (quad: scaled Gram, 1/diag)
@@ -302,6 +314,7 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
             return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
         hals_args a{UtM, ldm, nullptr, nullptr, nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status, sweep_partials,
                     snapshots, snap_stride, sweep0, Vsrc, ldvs};
+        a.snap_first = snap_first;
         rc = nnf_hals_quad_run(ctx, UtU, UtU2, ldg, Gp, counter, a, &nblocks, st);
         if (rc != NNF_OK) return rc;
         if (nsweeps == 0) return NNF_OK;
@@ -327,12 +340,15 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
             return NNF_ERR_UNSUPPORTED;   // 32-bit buffer offsets
         hals_args a{UtM, ldm, Gp, dinv, want_gs ? Gp + gs_off : nullptr, V, ldv, r, ncols, nsweeps, delta, sp, MODE, sy, status,
                     sweep_partials, snapshots, snap_stride, sweep0, Vsrc, ldvs};
+        a.snap_first = snap_first;
+        a.resid_in = resid_in;
+        a.resid_out = resid_out;
         nnf_probe(ctx, NNF_PROBE_HALS, 0, st);
         rc = NNF_ERR_UNSUPPORTED;
         if (try_mfma) rc = nnf_hals_mfma_run(ctx, RP, UtU, ldg, Gm, a, max_blocks, &nblocks, st);
         if (rc == NNF_OK) {
             if (getenv("NNF_HALS_DEBUG")) fprintf(stderr, "[nnf hals] -> mfma kernel, %d workgroups\n", nblocks);
-        } else if (rc != NNF_ERR_UNSUPPORTED || force_mfma) {
+        } else if (rc != NNF_ERR_UNSUPPORTED) {
             return rc;
         } else
         if (RP <= 48) rc = nnf_hals_fast_part0(ctx, RP, a, max_blocks, &nblocks, st);
@@ -367,6 +383,31 @@ extern "C" int nnf_hals_sweeps_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, 
     }
     return hals_entry<1>(ctx, UtM, ldm, UtU, ldg, V, ldv, r, ncols, nsweeps, 0.0, sparsity, flags, nullptr, nodelta_f64,
                          (hipStream_t)stream, snapshots, snap_stride);
+}
+
+// Blind sweeps that CONTINUE a solve (the chunks of the row-sharded protocol, dist.py): `sweeps_done` sweeps of this solve
+// have run already in earlier calls.  The matrix-core kernel (k_hals_mfma.hip) keeps a per-column residual next to V; handed
+// from call to call through resid_in / resid_out (nnf_hals_resid_floats() floats each, opaque layout; NULL: the launch forms
+// its residual from scratch) the chunks of a solve give bit for bit what one launch of all the sweeps gives.  The other
+// layouts carry no state and ignore the three arguments.  snap_first: the first sweep of this call (0-based) that writes a
+// snapshot -- a chunk = `head` blind sweeps + a window of snapshots is ONE launch; block j holds V after sweep snap_first + j + 1.
+extern "C" int nnf_hals_sweeps_ex_f32(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* UtU, int64_t ldg, float* V,
+                                      int64_t ldv, int r, int64_t ncols, int nsweeps, int sweeps_done, float sparsity,
+                                      unsigned flags, double* nodelta_f64, float* snapshots, int64_t snap_stride, int snap_first,
+                                      const float* resid_in, float* resid_out, void* stream) {
+    if (sweeps_done < 0 || snap_first < 0 || (snapshots && snap_first >= nsweeps && nsweeps > 0)) return NNF_ERR_ARG;
+    if (snapshots && ((flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) || snap_stride < (int64_t)r * ncols)) return NNF_ERR_ARG;
+    return hals_entry<1>(ctx, UtM, ldm, UtU, ldg, V, ldv, r, ncols, nsweeps, 0.0, sparsity, flags, nullptr, nodelta_f64,
+                         (hipStream_t)stream, snapshots, snap_stride, sweeps_done, nullptr, nullptr, 0, snap_first, resid_in,
+                         resid_out);
+}
+
+// floats of residual state per buffer for nnf_hals_sweeps_ex_f32 on an r x ncols factor (0: the layout that runs carries none)
+extern "C" int nnf_hals_resid_floats(nnf_ctx* ctx, int r, int64_t ncols, int64_t* floats_out) {
+    if (!ctx || r < 1 || ncols < 1 || !floats_out) return NNF_ERR_ARG;
+    const int RP = pick_rp(r);
+    *floats_out = (RP > 0 && hals_mfma_default(RP, ncols)) ? (int64_t)nnf_hals_mfma_resid_floats(RP, ncols) : 0;
+    return NNF_OK;
 }
 
 // Solves longer than one launch can tag (max_sweeps > 1000, e.g. hals_nnls_acc(maxiter=5000)): the caller chains launches of

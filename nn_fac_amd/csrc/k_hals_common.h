@@ -352,6 +352,9 @@ struct hals_args {
     const float* Mimg;    // k_hals_mfma.hip: Gram image in MFMA fragment order, in-block couplings; padded rank of the dinv table
     const float* Mlt;
     int rp;
+    const float* resid_in;   // k_hals_mfma.hip, mode 1: residual state of the solve so far / where to leave it (may be NULL)
+    float* resid_out;
+    int snap_first;          // mode 1: the first sweep (0-based, within this launch) that writes a snapshot
 };
 
 // Continuation of a solve longer than one launch can tag (NNF_HALS_MAX_SWEEPS): `status` holds the state the previous launch
@@ -381,6 +384,7 @@ int nnf_hals_wave_run(nnf_ctx*, const float* UtU, const float* UtU2, int64_t ldg
 // k_hals_mfma.hip: push form on the matrix cores, many columns, ranks 48..100 (resident columns only)
 bool nnf_hals_mfma_supported(int RP);
 size_t nnf_hals_mfma_gram_floats(int RP);
+size_t nnf_hals_mfma_resid_floats(int RP, int64_t ncols);
 int nnf_hals_mfma_run(nnf_ctx*, int RP, const float* UtU, int64_t ldg, float* gram, hals_args a, int max_blocks_cap, int* nblocks_out,
                       hipStream_t);
 

@@ -346,8 +346,8 @@ __global__ __launch_bounds__(256, (RP > 104 ? 1 : 2)) void nnf_hals_kernel(hals_
         if (a.mode == 1) {
             if (threadIdx.x == 0) a.sweep_partials[(size_t)(s - 1) * nblocks + blockIdx.x] = bs;
             if constexpr (RES) {
-                if (a.snapshots != nullptr && gtid < a.ncols) {   // V after sweep s (fire-and-forget stores)
-                    float* sp_ = a.snapshots + (size_t)(s - 1) * a.snap_stride + gtid;
+                if (a.snapshots != nullptr && gtid < a.ncols && s > a.snap_first) {   // V after sweep s (fire-and-forget stores)
+                    float* sp_ = a.snapshots + (size_t)(s - 1 - a.snap_first) * a.snap_stride + gtid;
 #pragma unroll
                     for (int k = 0; k < RP; ++k)
                         if (k < a.r) sp_[(int64_t)k * a.ncols] = v2[k / 2][k & 1];

@@ -39,10 +39,13 @@
 #ifndef MFMA_NREF_V
 #define MFMA_NREF_V 32      // sweeps between two from-scratch residuals
 #endif
-#ifndef MFMA_DBG
-#define MFMA_DBG 0          // timing-only ablations: 1 no MFMAs, 2 VALU stages not interleaved (all in front of the block's MFMAs)
+#ifndef MFMA_EARLY
+#define MFMA_EARLY 1        // one more from-scratch residual after the FIRST sweep of a solve (its steps are the large ones)
 #endif
-NNF_BUILD_FLAGS(k_hals_mfma, "MFMA_NREF_V=" NNF_STR(MFMA_NREF_V) " MFMA_DBG=" NNF_STR(MFMA_DBG))
+#ifndef MFMA_DBG
+#define MFMA_DBG 0          // timing-only ablations: 1 no MFMAs, 4 no row updates (gather and scatter stay)
+#endif
+NNF_BUILD_FLAGS(k_hals_mfma, "MFMA_NREF_V=" NNF_STR(MFMA_NREF_V) " MFMA_EARLY=" NNF_STR(MFMA_EARLY) " MFMA_DBG=" NNF_STR(MFMA_DBG))
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -101,7 +104,7 @@ struct mfma_cfg {
 template <int RT, int REM, int NKB, bool GUARD>
 struct mfma_sweeper {
     using C = mfma_cfg<RT, REM, NKB>;
-    static constexpr int RTQ = C::RTQ, NM = RT * 4, NS = 11;
+    static constexpr int RTQ = C::RTQ, NM = RT * 4;
     static constexpr int NBUF = RTQ == 1 ? 2 : 1;   // A fragments: double-buffered while they are one float4 per lane, else
                                                     // ONE set whose two pieces are refilled as the block's MFMAs release them
     using LT = typename std::conditional<GUARD, f32x16, f32x8>::type;
@@ -110,12 +113,44 @@ struct mfma_sweeper {
     float (&v)[4 * NKB];
     unsigned img_addr;
     uint64_t lbase;
+    unsigned ga, gr, sr;   // this lane's LDS byte addresses in the wave's transpose scratch (see below)
     f32x4 af[NBUF][RTQ];
     LT lt[2];
     f32x16 xt[2];
-    float t[2][4], w[4], d[4], dn[4];
+    f32x4 w, stp;          // the block's residuals / steps, lane = column
+    float d[4], dn[4];     // B operands of this block / of the next one
     float nd;
 
+    // Gather and scatter go THROUGH LDS, not through the VALU (tools/probes/permlane_rate.hip: fp32 MFMAs and VALU instructions
+    // never overlap on a SIMD -- even a v_mov adds its full issue time -- and a v_permlane swap costs three v_mov; the 16 copies
+    // + 16 swaps per block of the register version were a third of the sweep).  The wave owns 5 KB of LDS:
+    //   gather:  every lane stores its four registers of the tile's column tile ct at [ct][lane] (ds_write_b128 x 4); lane
+    //            (ct, n) reads back what lane (g, n) stored for ct: the block's 4 residuals of ITS column, one ds_read_b128;
+    //   scatter: every lane stores its column's 4 steps at [lane] (one ds_write_b128); lane (k, n) reads step k of column
+    //            16 ct + n (ds_read_b32 x 4, conflict-free: 4 n + k covers 64 consecutive words).
+    // A wave's LDS operations execute in order, so no barrier and no second buffer are needed.
+    __device__ __forceinline__ void issue_gather(int kb) {
+        if (kb < C::NTB) {
+            const int rt = kb / 4, g = kb % 4;
+            // only the 16 lanes of row group g hold rows of this block: the stores run under that exec mask (a quarter of the
+            // LDS write traffic; the wave is otherwise always fully active, the mask is saved and put back all the same)
+            uint64_t keep;
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, %6\n\ts_mov_b32 exec_hi, %7\n\t"
+                         "ds_write_b128 %1, %2\n\tds_write_b128 %1, %3 offset:1024\n\tds_write_b128 %1, %4 offset:2048\n\t"
+                         "ds_write_b128 %1, %5 offset:3072\n\ts_mov_b64 exec, %0"
+                         : "=&s"(keep)
+                         : "v"(ga), "v"(acc[rt][0]), "v"(acc[rt][1]), "v"(acc[rt][2]), "v"(acc[rt][3]),
+                           "i"(g == 0 ? 0xffffu : g == 1 ? 0xffff0000u : 0u), "i"(g == 2 ? 0xffffu : g == 3 ? 0xffff0000u : 0u));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w) : "v"(gr), "i"(g * 256));
+        } else {
+            w = f32x4{accx[0], accx[1], accx[2], accx[3]};
+        }
+    }
+    __device__ __forceinline__ void issue_scatter() {
+        asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(ga), "v"(stp));
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dn[ct]) : "v"(sr), "i"(4096 + ct * 256));
+    }
     __device__ __forceinline__ void issue_af(int buf, int q, int kb) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[buf][q]) : "v"(img_addr), "i"((kb * RTQ + q) * 1024));
     }
@@ -124,106 +159,51 @@ struct mfma_sweeper {
         else asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(lt[buf]) : "s"(lbase), "i"(kb * C::LTF * 4));
         if constexpr (REM > 0) asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(xt[buf]) : "s"(lbase), "i"(kb * C::LTF * 4 + 64));
     }
-    __device__ __forceinline__ void wait_all() {   // (two A-fragment registers either way: 2 buffers x 1 piece or 1 x 2)
+    // every hand-issued load in flight lands here (scalar loads return out of order: lgkmcnt(0) is the only usable wait)
+    __device__ __forceinline__ void wait_all() {
         f32x4& a0 = af[0][0];
         f32x4& a1 = af[NBUF - 1][RTQ - 1];
-        if constexpr (REM > 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+s"(lt[0]), "+s"(lt[1]), "+s"(xt[0]), "+s"(xt[1]));
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+s"(lt[0]), "+s"(lt[1]));
+        if constexpr (REM > 0)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(a0), "+v"(a1), "+s"(lt[0]), "+s"(lt[1]), "+s"(xt[0]), "+s"(xt[1]), "+v"(w), "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+s"(lt[0]), "+s"(lt[1]), "+v"(w), "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]));
     }
 
-    // Stage `st` (0..10) of the VALU work of k-block kb: results in dn[] (the block's steps, scattered to B-operand layout),
-    // v[], nd, accx[].  Stages are separated by pins so that hipcc leaves each one where it is called.  The gather runs in two
-    // halves (rows 0,1 then 2,3 of the block) on 8 temporaries.
-    __device__ __forceinline__ void stage(int kb, int st) {
-        const bool tile_block = kb < C::NTB;
-        const int rt = kb / 4, g = kb % 4, lb = kb & 1;
-        switch (st) {
-            case 0:
-            case 3:   // copies of the tile's registers (the swaps below are destructive)
-                if (tile_block) {
+    // The VALU work of k-block kb on its residuals w: the four row updates of nnls.py:162-170 in order, the bookkeeping, the
+    // leftover rows' push.  Leaves the steps in stp.  l[0..5] = -G'[k0+i][k0+j], j < i.
+    __device__ __forceinline__ void update(int kb) {
+        const int lb = kb & 1;
+        const LT l = lt[lb];
+        float s0, s1, s2, s3;
+        asm("v_max_f32 %0, %1, -%2" : "=v"(s0) : "v"(w[0]), "v"(v[4 * kb]));
+        if constexpr (GUARD) s0 *= l[8];
+        const float x1 = fmaf(l[0], s0, w[1]);
+        asm("v_max_f32 %0, %1, -%2" : "=v"(s1) : "v"(x1), "v"(v[4 * kb + 1]));
+        if constexpr (GUARD) s1 *= l[9];
+        const float x2 = fmaf(l[2], s1, fmaf(l[1], s0, w[2]));
+        asm("v_max_f32 %0, %1, -%2" : "=v"(s2) : "v"(x2), "v"(v[4 * kb + 2]));
+        if constexpr (GUARD) s2 *= l[10];
+        const float x3 = fmaf(l[5], s2, fmaf(l[4], s1, fmaf(l[3], s0, w[3])));
+        asm("v_max_f32 %0, %1, -%2" : "=v"(s3) : "v"(x3), "v"(v[4 * kb + 3]));
+        if constexpr (GUARD) s3 *= l[11];
+        stp = f32x4{s0, s1, s2, s3};
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int i = (st == 0 ? 0 : 2) + h;
-#pragma unroll
-                        for (int ct = 0; ct < 4; ++ct) t[h][ct] = acc[rt][ct][i];
-                        pin4(t[h]);
-                    }
-                }
-                break;
-            case 1:
-            case 4:
-                if (tile_block) {
-                    pl_s16(t[0][0], t[0][1]);
-                    pl_s16(t[1][0], t[1][1]);
-                    pl_s16(t[0][2], t[0][3]);
-                    pl_s16(t[1][2], t[1][3]);
-                    pin4(t[0]);
-                    pin4(t[1]);
-                }
-                break;
-            case 2:
-            case 5: {   // w[i] lane (ct, n) = acc[rt][ct][i] lane (g, n)
-                const int i0 = st == 2 ? 0 : 2;
-                if (tile_block) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        if (g == 0 || g == 2) pl_s32(t[h][0], t[h][2]);
-                        else pl_s32(t[h][1], t[h][3]);
-                        w[i0 + h] = t[h][g];
-                    }
-                } else {
-                    w[i0] = accx[i0];
-                    w[i0 + 1] = accx[i0 + 1];
-                }
-                asm volatile("" : "+v"(w[i0]), "+v"(w[i0 + 1]));
-                break;
-            }
-            case 6: {   // rows 0, 1 of the block (nnls.py:162-170); l[0..5] = -G'[k0+i][k0+j], j < i
-                const LT l = lt[lb];
-                asm("v_max_f32 %0, %1, -%2" : "=v"(dn[0]) : "v"(w[0]), "v"(v[4 * kb]));
-                if constexpr (GUARD) dn[0] *= l[8];
-                const float x1 = fmaf(l[0], dn[0], w[1]);
-                asm("v_max_f32 %0, %1, -%2" : "=v"(dn[1]) : "v"(x1), "v"(v[4 * kb + 1]));
-                if constexpr (GUARD) dn[1] *= l[9];
-                w[2] = fmaf(l[2], dn[1], fmaf(l[1], dn[0], w[2]));
-                w[3] = fmaf(l[4], dn[1], fmaf(l[3], dn[0], w[3]));
-                asm volatile("" : "+v"(dn[0]), "+v"(dn[1]), "+v"(w[2]), "+v"(w[3]));
-                break;
-            }
-            case 7: {   // rows 2, 3
-                const LT l = lt[lb];
-                asm("v_max_f32 %0, %1, -%2" : "=v"(dn[2]) : "v"(w[2]), "v"(v[4 * kb + 2]));
-                if constexpr (GUARD) dn[2] *= l[10];
-                const float x3 = fmaf(l[5], dn[2], w[3]);
-                asm("v_max_f32 %0, %1, -%2" : "=v"(dn[3]) : "v"(x3), "v"(v[4 * kb + 3]));
-                if constexpr (GUARD) dn[3] *= l[11];
-                asm volatile("" : "+v"(dn[2]), "+v"(dn[3]));
-                break;
-            }
-            case 8:   // the block's bookkeeping
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[4 * kb + i] += dn[i];
-                    nd = fmaf(dn[i], dn[i], nd);
-                }
-                asm volatile("" : "+v"(v[4 * kb]), "+v"(v[4 * kb + 1]), "+v"(v[4 * kb + 2]), "+v"(v[4 * kb + 3]), "+v"(nd));
-                break;
-            case 9:   // leftover rows: accx[j] += X[j][i] dn[i]   (X = -G'; the block of the leftover rows itself included)
-                if constexpr (REM > 0) {
-                    const f32x16 x = xt[lb];
-#pragma unroll
-                    for (int j = 0; j < REM; ++j) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) accx[j] = fmaf(x[4 * j + i], dn[i], accx[j]);
-                    }
-                    pin4(accx);
-                }
-                break;
-            case 10:   // scatter: dn[ct] becomes the B operand of column tile ct
-                tr4(dn);
-                pin4(dn);
-                break;
+        for (int i = 0; i < 4; ++i) {
+            v[4 * kb + i] += stp[i];
+            nd = fmaf(stp[i], stp[i], nd);
         }
+        if constexpr (REM > 0) {   // leftover rows: accx[j] += X[j][i] step[i]   (X = -G'; their own block included)
+            const f32x16 x = xt[lb];
+#pragma unroll
+            for (int j = 0; j < REM; ++j) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accx[j] = fmaf(x[4 * j + i], stp[i], accx[j]);
+            }
+        }
+        // finish here (hipcc otherwise keeps every block's steps alive to the end of the sweep)
+        asm volatile("" : "+v"(v[4 * kb]), "+v"(v[4 * kb + 1]), "+v"(v[4 * kb + 2]), "+v"(v[4 * kb + 3]), "+v"(nd), "+v"(stp));
+        if constexpr (REM > 0) pin4(accx);
     }
 
     // MFMA order of block kb: the tile the NEXT block gathers from first, then the other tiles of the same float4 piece of the
@@ -242,6 +222,8 @@ struct mfma_sweeper {
     }
 
     // One Gauss-Seidel sweep over the wave's 64 columns.  Returns this lane's (= column's) sum of squared steps.
+    // Block kb's MFMAs carry the next block's preparation in their shadow (what hides is LATENCY -- LDS round trips, scalar
+    // loads -- not VALU time):   M0..M7 | gather(kb+1) out | M8..M11 | wait, row updates of kb+1, scatter out | M12.. | wait.
     __device__ __forceinline__ float sweep() {
         nd = 0.f;
         issue_lt(0, 0);
@@ -249,13 +231,16 @@ struct mfma_sweeper {
 #pragma unroll
         for (int q = 0; q < RTQ; ++q) issue_af(0, q, 0);
         if (NBUF == 2 && NKB > 1) issue_af(1, 0, 1);
+        issue_gather(0);
         wait_all();
-#pragma unroll
-        for (int st = 0; st < NS; ++st) stage(0, st);
+        update(0);
+        issue_scatter();
         if (NKB > 2) issue_lt(0, 2);
+        wait_all();
+        constexpr int MG = 7;                           // gather goes out behind MFMA MG: 4 MFMAs behind the tile's own (hazard)
+        constexpr int MU = NM >= 16 ? 11 : NM - 3;      // row updates + scatter behind MFMA MU
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            // B operands of this block; the stages below build the next block's
 #pragma unroll
             for (int i = 0; i < 4; ++i) d[i] = dn[i];
             asm volatile("s_nop 1" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
@@ -263,24 +248,20 @@ struct mfma_sweeper {
             const bool more = kb + 1 < NKB;
             const int nfirst = 4 * piece_tiles(first_piece(kb));   // MFMAs on the first piece
             if (NBUF == 1 && kb > 0 && first_piece(kb) != first_piece(kb - 1)) wait_all();   // (that piece was issued last: rare)
-            if ((MFMA_DBG & 2) && more) {
-#pragma unroll
-                for (int st = 0; st < NS; ++st) stage(kb + 1, st);
-            }
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 const int r2 = tile_at(kb, m / 4), ct = m % 4;
                 if (!(MFMA_DBG & 1)) mfma_acc(acc[r2][ct], af[cb][r2 / 4][r2 % 4], d[ct]);
                 else if (m == 0) acc[r2][ct][0] += d[ct] * af[cb][0][0];
-                if (!(MFMA_DBG & 2) && more) {
-#pragma unroll
-                    for (int st = 0; st < NS; ++st) {
-                        const int slot = NM > 8 ? 7 + (st * (NM - 8)) / NS : NM - 1;
-                        if (slot == m) stage(kb + 1, st);
-                    }
+                if (more && m == MG) issue_gather(kb + 1);
+                if (more && m == MU) {
+                    wait_all();
+                    if (!(MFMA_DBG & 4)) update(kb + 1);
+                    else stp = w;
+                    issue_scatter();
                 }
                 if (NBUF == 1 && m == nfirst - 1 && m != NM - 1) {   // the first piece is released: refill it for the next block
-                    wait_all();
+                    if (m < MU) wait_all();   // (else the wait above has already passed)
                     if (more) issue_af(0, first_piece(kb), kb + 1);
                 }
             }
@@ -374,12 +355,15 @@ __global__ __launch_bounds__(256, 2) void nnf_hals_mfma_kernel(hals_args a) {
     using C = mfma_cfg<RT, REM, NKB>;
     constexpr int RP = 4 * NKB;
     __shared__ f32x4 img[C::IMG];
+    __shared__ f32x4 tsc[4][5 * 64];   // per wave: gather [ct][lane], scatter [lane]
     __shared__ double red2[2][2][4];
     __shared__ unsigned lds_flag;
     if (threadIdx.x == 0) lds_flag = 1u;
     const int nblocks = gridDim.x;
     const int lane = threadIdx.x & 63;
     const unsigned img_addr = (unsigned)(uintptr_t)&img[lane];
+    const unsigned tbase = (unsigned)(uintptr_t)&tsc[threadIdx.x >> 6][0];
+    const unsigned t_ga = tbase + lane * 16, t_gr = tbase + (lane >> 4) * 1024 + (lane & 15) * 16, t_sr = tbase + (lane & 15) * 16 + (lane >> 4) * 4;
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     {   // stage the Gram image (prepared in fragment order by nnf_hals_mfma_prep_kernel)
         const f32x4* src = reinterpret_cast<const f32x4*>(a.Mimg);
@@ -415,21 +399,36 @@ __global__ __launch_bounds__(256, 2) void nnf_hals_mfma_kernel(hals_args a) {
         asm volatile("" : "+v"(vo));   // (opaque: hipcc otherwise merges the two variants' loads back into one hoisted set)
 #pragma unroll
         for (int k = 0; k < RP; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvs, vo, k * ldvs4, 0));
+        // The residual state.  A launch starts from scratch unless the caller hands over the state its predecessor left
+        // (nnf_hals_sweeps_ex_f32: blind chunks of ONE solve continue bit for bit where the last one stopped); from-scratch
+        // residuals are scheduled on the ABSOLUTE sweep index (sweeps_done + s), so chunking does not move them.
+        float* const st_out = a.resid_out ? a.resid_out + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (RT * 4 + 1) * 256 + lane * 4 : nullptr;
         int fresh = 1;
+        if (a.resid_in != nullptr && (a.sweep0 % MFMA_NREF_V) != 0 && !(MFMA_EARLY && a.sweep0 == 1)) {
+            const float* st_in = a.resid_in + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (RT * 4 + 1) * 256 + lane * 4;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = *reinterpret_cast<const f32x4*>(st_in + (rt * 4 + ct) * 256);
+            const f32x4 ax = *reinterpret_cast<const f32x4*>(st_in + RT * 4 * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accx[j] = ax[j];
+            fresh = 0;
+        }
         int s = 1;
 #pragma unroll 1
         for (;;) {
             asm volatile("" : "+v"(fresh));
             if (__builtin_amdgcn_readfirstlane(fresh)) mfma_residual<RT, REM, NKB>(acc, accx, v, img_addr, rb, voff0, ldm4, a.Mlt, a.sp);
-            mfma_sweeper<RT, REM, NKB, GUARD> sw{acc, accx, v, img_addr, (uint64_t)a.Mlt};
+            mfma_sweeper<RT, REM, NKB, GUARD> sw{acc, accx, v, img_addr, (uint64_t)a.Mlt, t_ga, t_gr, t_sr};
             const float f = sw.sweep();
             const double nd = gtid < a.ncols ? (double)f : 0.0;
             const double bs = hals_block_sum1<256>(nd, red2[s & 1][0]);
             done = s;
             if (a.mode == 1) {
                 if (threadIdx.x == 0) a.sweep_partials[(size_t)(s - 1) * nblocks + blockIdx.x] = bs;
-                if (a.snapshots != nullptr) {   // V after sweep s (fire-and-forget stores; rows >= r, idle lanes: outside the descriptor)
-                    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.snapshots + (size_t)(s - 1) * a.snap_stride, 0,
+                if (a.snapshots != nullptr && s > a.snap_first) {   // V after sweep s (fire-and-forget stores; rows >= r, idle lanes: outside the descriptor)
+                    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.snapshots + (size_t)(s - 1 - a.snap_first) * a.snap_stride, 0,
                                                                         (int)((int64_t)a.r * a.ncols * 4), 0x00020000);
                     int so = 0;
                     const int step = (int)(a.ncols * 4);
@@ -450,8 +449,15 @@ __global__ __launch_bounds__(256, 2) void nnf_hals_mfma_kernel(hals_args a) {
                 if (!(eps >= a.delta * eps0)) break;   // nnls.py:156: sweep s was the last one
             }
             if (s >= a.max_sweeps) break;
-            fresh = (s % MFMA_NREF_V) == 0;
+            fresh = ((a.sweep0 + s) % MFMA_NREF_V) == 0 || (MFMA_EARLY && a.sweep0 + s == 1);
             ++s;
+        }
+        if (st_out != nullptr) {   // (the tiles are complete: the sweep ends with the MFMA -> reader distance)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<f32x4*>(st_out + (rt * 4 + ct) * 256) = acc[rt][ct];
+            *reinterpret_cast<f32x4*>(st_out + RT * 4 * 256) = f32x4{accx[0], accx[1], accx[2], accx[3]};
         }
 #pragma unroll
         for (int k = 0; k < RP; ++k) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), rv, voff0, k * ldv4, 0);
@@ -520,6 +526,13 @@ size_t nnf_hals_mfma_gram_floats(int RP) {
     mfma_shape s;
     if (!mfma_shape_of(RP, s)) return 0;
     return (size_t)s.nkb * ((s.rt + 3) / 4) * 256 + (size_t)s.nkb * 32 + 64;
+}
+
+// floats of residual state a chunked solve of `ncols` columns carries from launch to launch (0: rank not covered)
+size_t nnf_hals_mfma_resid_floats(int RP, int64_t ncols) {
+    mfma_shape s;
+    if (!mfma_shape_of(RP, s) || ncols < 1) return 0;
+    return (size_t)nnf_cdiv(ncols, 256) * 4 * (s.rt * 4 + 1) * 256;
 }
 
 template <int RT, int REM, int NKB>

@@ -233,8 +233,8 @@ __global__ __launch_bounds__(64) void nnf_hals_quad_kernel(hals_args a) {
         const double bs = nnf_wave_sum_f64(valid ? (double)f : 0.0);   // the workgroup IS one wave: no LDS, no barrier
         if (a.mode == 1) {
             if (threadIdx.x == 0) a.sweep_partials[(size_t)(s - 1) * nblocks + blockIdx.x] = bs;
-            if (a.snapshots != nullptr && valid) {   // V after sweep s (fire-and-forget stores)
-                float* sp_ = a.snapshots + (size_t)(s - 1) * a.snap_stride + col;
+            if (a.snapshots != nullptr && valid && s > a.snap_first) {   // V after sweep s (fire-and-forget stores)
+                float* sp_ = a.snapshots + (size_t)(s - 1 - a.snap_first) * a.snap_stride + col;
 #pragma unroll
                 for (int j = 0; j < CH; ++j)
                     if (q * CH + j < a.r) sp_[(int64_t)(q * CH + j) * a.ncols] = v[j];

@@ -129,6 +129,7 @@ class SweepGuess:
         self.max_chunk = max_chunk
         self.window = window
         self.snap = None
+        self.state = None
 
     def snapshots(self, F, W, blocks=None):
         """One (>= W) x r x (block columns) contiguous buffer per column block (a single-block F: one buffer shaped like F)."""
@@ -144,13 +145,42 @@ class SweepGuess:
         return self.snap
 
 
-def _blind_sweeps(eng, cross, gram, F, blocks, nsweeps, sparsity, snaps=None):
-    """`nsweeps` blind sweeps over every column block; the blocks' per-sweep sums of squared steps added in block order."""
+    def residual_state(self, eng, F, blocks=None):
+        """Two residual-state buffers per column block (Engine.hals_resid_floats elements each; None when the sweep kernel that
+        runs keeps no state): a chunk reads one and leaves the other, so the state at the START of a chunk survives it (the
+        re-run of an overshoot that ended before the snapshot window starts from it)."""
+        blocks = blocks or [(0, int(F.shape[1]))]
+        fn = getattr(eng, "hals_resid_floats", None)
+        sizes = [int(fn(int(F.shape[0]), hi - lo)) if fn is not None else 0 for lo, hi in blocks]
+        if not any(sizes):
+            self.state = None
+            return None
+        ok = self.state is not None and len(self.state) == len(sizes) and all(
+            a.numel() >= n and a.device == F.device for (a, b), n in zip(self.state, sizes))
+        if not ok:
+            self.state = None
+            self.state = [(torch.empty(max(n, 1), dtype=torch.float32, device=F.device),
+                           torch.empty(max(n, 1), dtype=torch.float32, device=F.device)) for n in sizes]
+        return self.state
+
+
+def _blind_sweeps(eng, cross, gram, F, blocks, nsweeps, sparsity, snaps=None, snap_first=0, done=0, state=None, flip=0):
+    """`nsweeps` blind sweeps over every column block (ONE launch per block: `snap_first` sweeps without and the rest with a
+    snapshot); the blocks' per-sweep sums of squared steps added in block order.  done: sweeps of this solve run before;
+    state / flip: the residual-state pairs of SweepGuess.residual_state -- read from state[b][flip] (when done > 0), left in
+    state[b][1 - flip]."""
     nd = None
     for bi, (lo, hi) in enumerate(blocks):
         whole = lo == 0 and hi == F.shape[1]
+        kw = {}
+        if snaps is not None:
+            kw["snapshots"], kw["snap_first"] = snaps[bi], snap_first
+        if state is not None:
+            kw["sweeps_done"], kw["resid_out"] = done, state[bi][1 - flip]
+            if done > 0:
+                kw["resid_in"] = state[bi][flip]
         part = eng.hals_sweeps(cross if whole else cross[:, lo:hi], gram, F if whole else F[:, lo:hi], nsweeps,
-                               sparsity=sparsity, **({} if snaps is None else {"snapshots": snaps[bi]}))
+                               sparsity=sparsity, **kw)
         nd = part if nd is None else nd + part
     return nd
 
@@ -168,19 +198,16 @@ def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01
     if budget < 1:
         return 1.0, 1, 0.0
     blocks = column_blocks(eng, F)
+    state = guess.residual_state(eng, F, blocks)
+    flip = 0                                       # state[b][flip]: the residual state after `done` sweeps
     C = max(1, min(int(guess.value), guess.max_chunk, budget))
     while done < budget:
         C = max(1, min(C, budget - done))
         W = max(1, min(C, int(guess.window)))
         head = C - W
-        parts = []
-        F0 = None
-        if head > 0:
-            F0 = F.clone()
-            parts.append(_blind_sweeps(eng, cross, gram, F, blocks, head, sparsity))
+        F0 = F.clone() if head > 0 else None
         snap = guess.snapshots(F, W, blocks)
-        parts.append(_blind_sweeps(eng, cross, gram, F, blocks, W, sparsity, snap))
-        nd = torch.cat(parts) if len(parts) > 1 else parts[0]
+        nd = _blind_sweeps(eng, cross, gram, F, blocks, C, sparsity, snap, head, done, state, flip)
         allreduce_(nd, group)
         ndh = nd.cpu().tolist()                    # one host round trip per chunk
         stop = None
@@ -193,15 +220,16 @@ def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01
                 break
         if stop is None:
             done += C
+            flip = 1 - flip
             C = min(guess.max_chunk, 2 * C)        # keep going with longer chunks
             continue
         if stop < C - 1:                           # overshoot
             if stop >= head:                       # inside the window: the snapshot after sweep stop+1
                 for (lo, hi), s in zip(blocks, snap):
                     F[:, lo:hi].copy_(s[stop - head])
-            else:                                  # before it: start of the chunk + stop+1 sweeps again
+            else:                                  # before it: start of the chunk + stop+1 sweeps again, from the chunk's start state
                 F.copy_(F0)
-                _blind_sweeps(eng, cross, gram, F, blocks, stop + 1, sparsity)
+                _blind_sweeps(eng, cross, gram, F, blocks, stop + 1, sparsity, None, 0, done, state, flip)
         done += stop + 1
         break
     guess.value = max(8, min(done + 4, guess.max_chunk))
@@ -253,12 +281,8 @@ def sharded_hals_solve_async(eng, cross, gram, F, group, guess, status, budget=1
     C = max(1, min(int(guess.value), guess.max_chunk, budget))
     W = max(1, min(C, int(guess.window)))
     head = C - W
-    parts = []
-    if head > 0:
-        parts.append(_blind_sweeps(eng, cross, gram, F, blocks, head, sparsity))
     snap = guess.snapshots(F, W, blocks)
-    parts.append(_blind_sweeps(eng, cross, gram, F, blocks, W, sparsity, snap))
-    nd = torch.cat(parts) if len(parts) > 1 else parts[0]
+    nd = _blind_sweeps(eng, cross, gram, F, blocks, C, sparsity, snap, head)      # head blind sweeps + the window: one launch
     allreduce_(nd, group)
     for (lo, hi), s in zip(blocks, snap):          # the same decision for every block (it is a function of `nd` alone)
         whole = lo == 0 and hi == F.shape[1]

@@ -248,9 +248,13 @@ class Engine:
                    "nnf_hals_solve_cross_f32")
         return st
 
-    def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False, snapshots=None):
+    def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False, snapshots=None, snap_first=0,
+                    sweeps_done=0, resid_in=None, resid_out=None):
         """Exactly `nsweeps` in-place sweeps; returns the per-sweep LOCAL sum of squared steps (float64, device).
-        snapshots (optional, contiguous float32 [>= nsweeps, r, ncols]): block s receives V after sweep s+1."""
+        snapshots (optional, contiguous float32 [>= nsweeps - snap_first, r, ncols]): block j receives V after sweep
+        snap_first + j + 1.  sweeps_done / resid_in / resid_out: this call continues a solve of which `sweeps_done` sweeps have
+        run (nnf_hals_sweeps_ex_f32): with the residual state handed on (float32 tensors of hals_resid_floats() elements) the
+        chunks of a solve are bit for bit one launch of all its sweeps."""
         _chk2d(UtM, "hals UtM"), _chk2d(UtU, "hals UtU"), _chk2d(V, "hals V")
         r, ncols = V.shape
         self._check_rowsync_columns(normalize or nonzero, ncols)
@@ -258,14 +262,26 @@ class Engine:
         sp, ss = C.c_void_p(0), 0
         if snapshots is not None:
             if (snapshots.dtype != torch.float32 or not snapshots.is_contiguous() or snapshots.dim() != 3
-                    or snapshots.shape[0] < nsweeps or tuple(snapshots.shape[1:]) != (r, ncols)):
-                raise EngineError("hals_sweeps: snapshots must be a contiguous float32 [>= nsweeps, r, ncols] tensor")
+                    or snapshots.shape[0] < nsweeps - int(snap_first) or tuple(snapshots.shape[1:]) != (r, ncols)):
+                raise EngineError("hals_sweeps: snapshots must be a contiguous float32 [>= nsweeps - snap_first, r, ncols] tensor")
             sp, ss = _ptr(snapshots), snapshots.stride(0)
-        _lib.check(self.lib.nnf_hals_sweeps_f32(self.ctx, _ptr(UtM), _ld(UtM), _ptr(UtU), _ld(UtU), _ptr(V),
-                                                _ld(V), r, ncols, int(nsweeps), float(sparsity or 0.0),
-                                                self._hals_flags(sparsity, normalize, nonzero), _ptr(nd), sp, ss,
-                                                self._stream()), "nnf_hals_sweeps_f32")
+        need = self.hals_resid_floats(r, ncols) if (resid_in is not None or resid_out is not None) else 0
+        for t in (resid_in, resid_out):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() < need or t.device != V.device):
+                raise EngineError("hals_sweeps: a residual-state buffer must be a contiguous float32 tensor of hals_resid_floats() elements")
+        ri = _ptr(resid_in) if (resid_in is not None and need > 0) else C.c_void_p(0)
+        ro = _ptr(resid_out) if (resid_out is not None and need > 0) else C.c_void_p(0)
+        _lib.check(self.lib.nnf_hals_sweeps_ex_f32(self.ctx, _ptr(UtM), _ld(UtM), _ptr(UtU), _ld(UtU), _ptr(V),
+                                                   _ld(V), r, ncols, int(nsweeps), int(sweeps_done), float(sparsity or 0.0),
+                                                   self._hals_flags(sparsity, normalize, nonzero), _ptr(nd), sp, ss,
+                                                   int(snap_first), ri, ro, self._stream()), "nnf_hals_sweeps_ex_f32")
         return nd[:int(nsweeps)]
+
+    def hals_resid_floats(self, r, ncols):
+        """Elements of one residual-state buffer for blind chunks on an r x ncols factor (0: the layout that runs keeps no state)."""
+        out = C.c_int64(0)
+        _lib.check(self.lib.nnf_hals_resid_floats(self.ctx, int(r), int(ncols), C.byref(out)), "nnf_hals_resid_floats")
+        return int(out.value)
 
     def hals_row_update(self, UtM, UtU, V, k, sparsity=None, out=None):
         """Row k of V (this rank's columns) gets the update of nnls.py:162-170, in place; returns a 2-element float64 device

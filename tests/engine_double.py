@@ -35,14 +35,15 @@ class OracleEngine:
         c = torch.sum((X - Ut.T @ V) ** 2).reshape(1)
         return c if out is None else out.copy_(c)
 
-    def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False, snapshots=None):
+    def hals_sweeps(self, UtM, UtU, V, nsweeps, sparsity=None, normalize=False, nonzero=False, snapshots=None, snap_first=0,
+                    sweeps_done=0, resid_in=None, resid_out=None):
         log = []
         cur = V.numpy().copy()
         for s in range(nsweeps):   # one sweep at a time so that every intermediate V can be snapshotted
             cur, *_ = orc.hals_nnls_acc(UtM.numpy(), UtU.numpy(), cur, maxiter=1, alpha=math.inf, delta=0.0,
                                         sparsity_coefficient=sparsity, sweep_log=log)
-            if snapshots is not None:
-                snapshots[s].copy_(torch.from_numpy(cur))
+            if snapshots is not None and s >= snap_first:
+                snapshots[s - snap_first].copy_(torch.from_numpy(cur))
         V.copy_(torch.from_numpy(cur))
         return torch.tensor(log, dtype=torch.float64)
 

@@ -175,7 +175,7 @@ def test_chunked_solve_protocol_single_rank(first, max_chunk, window, delta, bud
 
     class Counting(OracleEngine):
         def hals_sweeps(self, UtM, UtU, V, nsweeps, **kw):
-            calls.append((nsweeps, kw.get("snapshots") is not None))
+            calls.append((nsweeps - kw.get("snap_first", 0), kw.get("snapshots") is not None))
             return super().hals_sweeps(UtM, UtU, V, nsweeps, **kw)
 
     F = torch.from_numpy(V0.copy())
@@ -183,7 +183,7 @@ def test_chunked_solve_protocol_single_rank(first, max_chunk, window, delta, bud
     e2, c2, _ = nd.sharded_hals_solve(Counting(), torch.from_numpy(UtM), torch.from_numpy(UtU), F, None, guess,
                                       budget=budget, delta=delta)
     assert c2 == cnt and np.array_equal(F.numpy(), want) and e2 == eps
-    assert all(ns <= window for ns, snapped in calls if snapped)          # only window-sized launches take snapshots
+    assert all(ns <= window for ns, snapped in calls if snapped)          # a chunk is one launch; only its window takes snapshots
     # a second call starts from the remembered count: one chunk, stop inside its window, no re-run
     calls.clear()
     F = torch.from_numpy(V0.copy())

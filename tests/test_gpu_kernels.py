@@ -182,7 +182,9 @@ def _kw(vec):
 LAYOUTS = ["lane", "quad"]      # one lane per column (k_hals_fast.hip) / four lanes per column (k_hals_quad.hip)
 # persistent solves also have the one-wave-per-column push form (k_hals_wave.hip; the default up to 8192 columns -- "wave"
 # forces nothing, it names the default; fixed-count / snapshot launches keep the two layouts above)
-LAYOUTS_SOLVE = LAYOUTS + ["wave"]
+# "mfma": the push form on the matrix cores (k_hals_mfma.hip, ranks 48..100; the default for many columns at ranks >= 64) --
+# forced for every rank it covers, the default layout for the others
+LAYOUTS_SOLVE = LAYOUTS + ["wave", "mfma"]
 
 
 @pytest.mark.parametrize("layout", LAYOUTS_SOLVE)
@@ -289,11 +291,15 @@ def test_hals_does_not_modify_inputs(eng):
                                             (30, 500, "quad"), (50, 2000, "quad"), (96, 8000, "quad"), (70, 16000, "quad"), (100, 4000, "quad"), (128, 3000, "quad"),
                                             (30, 500, "wave"), (50, 2000, "wave"), (100, 4000, "wave"), (128, 3000, "wave"), (64, 8000, "wave"),
                                             (65, 700, "wave"), (3, 50, "wave"), (1, 9, "wave"), (57, 8192, "wave"),
-                                            (100, 20000, "auto"), (120, 9000, "lane"), (64, 70000, "lane"), (56, 40000, "lane"), (34, 40000, "lane")])
+                                            (100, 20000, "auto"), (120, 9000, "lane"), (64, 70000, "lane"), (56, 40000, "lane"), (34, 40000, "lane"),
+                                            (100, 125000, "auto"), (96, 50000, "mfma"), (80, 40000, "auto"), (64, 70000, "auto"), (52, 40000, "mfma"),
+                                            (50, 100000, "mfma"), (48, 20000, "mfma"), (100, 3000, "mfma"), (77, 40000, "auto"), (93, 33000, "auto")])
 def test_hals_large_vs_oracle(eng, r, ncols, layout, monkeypatch):
     """Resident and strided (ncols > resident threads) persistent solves vs the fp64 oracle; sweep counts equal."""
     if layout not in ("auto", "wave"):
         monkeypatch.setenv("NNF_HALS_FORCE", layout)
+    else:
+        monkeypatch.delenv("NNF_HALS_FORCE", raising=False)
     rng = np.random.RandomState(r + ncols)
     A = rng.rand(4 * r, r)
     cols = min(ncols, 4000)                     # oracle on a slice is not possible (global stop rule) -> tile the problem
@@ -461,6 +467,46 @@ def test_hals_sweep_snapshots_at_bench_size(eng):
     assert torch.equal(snaps[1], V2) and torch.equal(nd2, nd[:2])
 
 
+@pytest.mark.parametrize("r,n,sp", [(64, 40000, None), (100, 2000, 0.05), (50, 3000, None), (80, 700, None)])
+def test_hals_mfma_fixed_sweeps_snapshots_and_chunks(eng, r, n, sp, monkeypatch):
+    """The matrix-core layout in fixed-count mode: against the fp64 oracle, snapshot s == a run of s sweeps (bitwise), and chunks
+    that hand the residual state on (nnf_hals_sweeps_ex_f32) == one launch of all the sweeps, bit for bit -- also across a
+    scheduled from-scratch residual (sweep 32) and with the snapshot window starting inside the launch."""
+    monkeypatch.setenv("NNF_HALS_FORCE", "mfma")
+    rng = np.random.RandomState(r + n)
+    A = rng.rand(3 * r, r)
+    UtU, UtM, V0 = dev(A.T @ A), dev(A.T @ (A @ rng.rand(r, n) + 0.1 * rng.rand(3 * r, n))), dev(rng.rand(r, n))
+    assert eng.hals_resid_floats(r, n) > 0
+    log = []
+    Vo, *_ = orc.hals_nnls_acc(UtM.cpu().numpy().astype(np.float64), UtU.cpu().numpy().astype(np.float64), V0.cpu().numpy().astype(np.float64),
+                               maxiter=6, alpha=math.inf, delta=0.0, sparsity_coefficient=sp, sweep_log=log)
+    snaps = torch.empty((4, r, n), dtype=torch.float32, device="cuda")
+    V6 = V0.clone()
+    nd = eng.hals_sweeps(UtM, UtU, V6, 6, sparsity=sp, snapshots=snaps, snap_first=2)
+    assert rel(V6.cpu().numpy(), Vo) < 1e-4
+    np.testing.assert_allclose(nd.cpu().numpy(), log, rtol=5e-3)
+    assert torch.equal(snaps[3], V6)
+    for k in (3, 5):
+        Vk = V0.clone()
+        ndk = eng.hals_sweeps(UtM, UtU, Vk, k, sparsity=sp)
+        assert torch.equal(snaps[k - 3], Vk) and torch.equal(ndk, nd[:k])
+    # chunks 5 + 29 + 4 (the second one crosses the scheduled residual of sweep 32) against 38 sweeps in one launch
+    want = V0.clone()
+    ndw = eng.hals_sweeps(UtM, UtU, want, 38, sparsity=sp)
+    nf = eng.hals_resid_floats(r, n)
+    sa, sb = torch.empty(nf, device="cuda"), torch.empty(nf, device="cuda")
+    got = V0.clone()
+    n1 = eng.hals_sweeps(UtM, UtU, got, 5, sparsity=sp, resid_out=sa)
+    n2 = eng.hals_sweeps(UtM, UtU, got, 29, sparsity=sp, sweeps_done=5, resid_in=sa, resid_out=sb)
+    n3 = eng.hals_sweeps(UtM, UtU, got, 4, sparsity=sp, sweeps_done=34, resid_in=sb, resid_out=sa)
+    assert torch.equal(got, want) and torch.equal(torch.cat([n1, n2, n3]), ndw)
+    # without the state a chunked run agrees to rounding only
+    loose = V0.clone()
+    eng.hals_sweeps(UtM, UtU, loose, 5, sparsity=sp)
+    eng.hals_sweeps(UtM, UtU, loose, 33, sparsity=sp)
+    assert rel(loose.cpu().numpy(), want.cpu().numpy()) < 2e-4
+
+
 @pytest.mark.parametrize("layout", LAYOUTS)
 def test_hals_sweep_snapshots(eng, layout, monkeypatch):
     """nnf_hals_sweeps_f32 with snapshots: block s must hold V after sweep s+1 (what a shorter run would return)."""
@@ -488,12 +534,22 @@ def test_hals_resident_columns_and_blocked_chunks(eng, monkeypatch):
     from nn_fac_amd import dist as nd
     # (the subject is the one-lane-per-column kernel whose resident capacity the blocks exist for; 5000 columns alone would
     # take the few-column layouts, which agree with it to rounding, not bit for bit)
-    monkeypatch.setenv("NNF_HALS_FORCE", "lane")
-    for r in (50, 100):
-        cap = eng.hals_resident_columns(r)
+    _blocked_chunks_case(eng, monkeypatch, "lane", 50)
+
+
+def test_hals_blocked_chunks_on_the_matrix_core_layout(eng, monkeypatch):
+    """The same protocol on k_hals_mfma.hip (rank 64): the chunks hand the residual state on, per column block."""
+    _blocked_chunks_case(eng, monkeypatch, "mfma", 64)
+
+
+def _blocked_chunks_case(eng, monkeypatch, layout, r):
+    from nn_fac_amd import dist as nd
+    monkeypatch.setenv("NNF_HALS_FORCE", layout)
+    for rr in (50, 100):
+        cap = eng.hals_resident_columns(rr)
         assert cap % 256 == 0 and 65536 <= cap <= 2048 * 256
     rng = np.random.RandomState(12)
-    r, n = 50, 5000
+    n = 5000
     A = rng.rand(200, r)
     UtU, UtM, V0 = dev(A.T @ A), dev(A.T @ (A @ rng.rand(r, n) + 0.3 * rng.rand(200, n))), dev(rng.rand(r, n))
     want = V0.clone()

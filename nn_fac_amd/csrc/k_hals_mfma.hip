@@ -113,7 +113,7 @@ struct mfma_sweeper {
     float (&v)[4 * NKB];
     unsigned img_addr;
     uint64_t lbase;
-    unsigned ga, gr, sr;   // this lane's LDS byte addresses in the wave's transpose scratch (see below)
+    unsigned ta, tg, ts;   // this lane's LDS byte addresses in the wave's 2 KB transpose scratch (see below)
     f32x4 af[NBUF][RTQ];
     LT lt[2];
     f32x16 xt[2];
@@ -123,33 +123,32 @@ struct mfma_sweeper {
 
     // Gather and scatter go THROUGH LDS, not through the VALU (tools/probes/permlane_rate.hip: fp32 MFMAs and VALU instructions
     // never overlap on a SIMD -- even a v_mov adds its full issue time -- and a v_permlane swap costs three v_mov; the 16 copies
-    // + 16 swaps per block of the register version were a third of the sweep).  The wave owns 5 KB of LDS:
-    //   gather:  every lane stores its four registers of the tile's column tile ct at [ct][lane] (ds_write_b128 x 4); lane
-    //            (ct, n) reads back what lane (g, n) stored for ct: the block's 4 residuals of ITS column, one ds_read_b128;
-    //   scatter: every lane stores its column's 4 steps at [lane] (one ds_write_b128); lane (k, n) reads step k of column
-    //            16 ct + n (ds_read_b32 x 4, conflict-free: 4 n + k covers 64 consecutive words).
+    // + 16 swaps per block of the register version were a third of the sweep).  The wave owns 2 KB of LDS:
+    //   gather:  the 16 lanes of row group g -- the only ones that hold rows of this block; the stores run under that exec
+    //            mask -- store their four registers of column tile ct at [ct][n] (ds_write_b128 x 4); lane (ct, n) reads its
+    //            column's 4 residuals back with one ds_read_b128;                                           ta = lane * 16
+    //   scatter: every lane stores its column's 4 steps at 1 KB + [lane] (one ds_write_b128); lane (k, n) reads step k of
+    //            column 16 ct + n (ds_read_b32 x 4: 4 n + k covers 64 consecutive words).   tg = (lane % 16) * 16, ts = tg + 4 k
     // A wave's LDS operations execute in order, so no barrier and no second buffer are needed.
     __device__ __forceinline__ void issue_gather(int kb) {
         if (kb < C::NTB) {
             const int rt = kb / 4, g = kb % 4;
-            // only the 16 lanes of row group g hold rows of this block: the stores run under that exec mask (a quarter of the
-            // LDS write traffic; the wave is otherwise always fully active, the mask is saved and put back all the same)
-            uint64_t keep;
+            uint64_t keep;   // (the wave is always fully active; the mask is saved and put back all the same)
             asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, %6\n\ts_mov_b32 exec_hi, %7\n\t"
-                         "ds_write_b128 %1, %2\n\tds_write_b128 %1, %3 offset:1024\n\tds_write_b128 %1, %4 offset:2048\n\t"
-                         "ds_write_b128 %1, %5 offset:3072\n\ts_mov_b64 exec, %0"
+                         "ds_write_b128 %1, %2\n\tds_write_b128 %1, %3 offset:256\n\tds_write_b128 %1, %4 offset:512\n\t"
+                         "ds_write_b128 %1, %5 offset:768\n\ts_mov_b64 exec, %0"
                          : "=&s"(keep)
-                         : "v"(ga), "v"(acc[rt][0]), "v"(acc[rt][1]), "v"(acc[rt][2]), "v"(acc[rt][3]),
+                         : "v"(tg), "v"(acc[rt][0]), "v"(acc[rt][1]), "v"(acc[rt][2]), "v"(acc[rt][3]),
                            "i"(g == 0 ? 0xffffu : g == 1 ? 0xffff0000u : 0u), "i"(g == 2 ? 0xffffu : g == 3 ? 0xffff0000u : 0u));
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w) : "v"(gr), "i"(g * 256));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(w) : "v"(ta));
         } else {
             w = f32x4{accx[0], accx[1], accx[2], accx[3]};
         }
     }
     __device__ __forceinline__ void issue_scatter() {
-        asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(ga), "v"(stp));
+        asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(ta), "v"(stp));
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dn[ct]) : "v"(sr), "i"(4096 + ct * 256));
+        for (int ct = 0; ct < 4; ++ct) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dn[ct]) : "v"(ts), "i"(1024 + ct * 256));
     }
     __device__ __forceinline__ void issue_af(int buf, int q, int kb) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[buf][q]) : "v"(img_addr), "i"((kb * RTQ + q) * 1024));
@@ -221,26 +220,20 @@ struct mfma_sweeper {
         return 4 * (1 - p) + (j - np);   // (RTQ == 2: the other piece)
     }
 
-    // One Gauss-Seidel sweep over the wave's 64 columns.  Returns this lane's (= column's) sum of squared steps.
+    // One Gauss-Seidel sweep over the wave's 64 columns, in two parts: head() = the first SPB k-blocks (and the row updates of
+    // block SPB, which ride in block SPB-1's shadow), tail() = the rest; tail() returns this lane's (= column's) sum of squared
+    // steps.  The persistent solve runs head() of sweep s+1 BEFORE it looks at the global sum of sweep s (lag-one speculation
+    // on a prefix of the sweep: it touches rows [0, 4 (SPB+1)) of v, which the kernel backs up in LDS and puts back if sweep s
+    // turns out to be the last one).  Nothing hand-issued is in flight between the two parts.
     // Block kb's MFMAs carry the next block's preparation in their shadow (what hides is LATENCY -- LDS round trips, scalar
     // loads -- not VALU time):   M0..M7 | gather(kb+1) out | M8..M11 | wait, row updates of kb+1, scatter out | M12.. | wait.
-    __device__ __forceinline__ float sweep() {
-        nd = 0.f;
-        issue_lt(0, 0);
-        if (NKB > 1) issue_lt(1, 1);
+    static constexpr int SPB = NKB >= 12 ? 3 : 0;
+    static constexpr int MG = 7;                           // gather goes out behind MFMA MG: 4 MFMAs behind the tile's own (hazard)
+    static constexpr int MU = NM >= 16 ? 11 : NM - 3;      // row updates + scatter behind MFMA MU
+
+    __device__ __forceinline__ void blocks(int first, int last) {
 #pragma unroll
-        for (int q = 0; q < RTQ; ++q) issue_af(0, q, 0);
-        if (NBUF == 2 && NKB > 1) issue_af(1, 0, 1);
-        issue_gather(0);
-        wait_all();
-        update(0);
-        issue_scatter();
-        if (NKB > 2) issue_lt(0, 2);
-        wait_all();
-        constexpr int MG = 7;                           // gather goes out behind MFMA MG: 4 MFMAs behind the tile's own (hazard)
-        constexpr int MU = NM >= 16 ? 11 : NM - 3;      // row updates + scatter behind MFMA MU
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
+        for (int kb = first; kb < last; ++kb) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) d[i] = dn[i];
             asm volatile("s_nop 1" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
@@ -274,6 +267,25 @@ struct mfma_sweeper {
             }
             if (kb + 3 < NKB) issue_lt((kb + 1) & 1, kb + 3);
         }
+    }
+    __device__ __forceinline__ void head() {
+        nd = 0.f;
+        issue_lt(0, 0);
+        if (NKB > 1) issue_lt(1, 1);
+#pragma unroll
+        for (int q = 0; q < RTQ; ++q) issue_af(0, q, 0);
+        if (NBUF == 2 && NKB > 1) issue_af(1, 0, 1);
+        issue_gather(0);
+        wait_all();
+        update(0);
+        issue_scatter();
+        if (NKB > 2) issue_lt(0, 2);
+        wait_all();
+        blocks(0, SPB);
+        wait_all();
+    }
+    __device__ __forceinline__ float tail() {
+        blocks(SPB, NKB);
         mfma_nop<12>();
         return nd;
     }
@@ -355,7 +367,8 @@ __global__ __launch_bounds__(256, 2) void nnf_hals_mfma_kernel(hals_args a) {
     using C = mfma_cfg<RT, REM, NKB>;
     constexpr int RP = 4 * NKB;
     __shared__ f32x4 img[C::IMG];
-    __shared__ f32x4 tsc[4][5 * 64];   // per wave: gather [ct][lane], scatter [lane]
+    __shared__ f32x4 tsc[4][2 * 64];   // per wave: gather [ct][n] (1 KB), scatter [lane] (1 KB)
+    __shared__ f32x4 bkp[4][4][64];    // per wave: the rows of v the speculative head of a sweep moves
     __shared__ double red2[2][2][4];
     __shared__ unsigned lds_flag;
     if (threadIdx.x == 0) lds_flag = 1u;
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void nnf_hals_mfma_kernel(hals_args a) {
     const int lane = threadIdx.x & 63;
     const unsigned img_addr = (unsigned)(uintptr_t)&img[lane];
     const unsigned tbase = (unsigned)(uintptr_t)&tsc[threadIdx.x >> 6][0];
-    const unsigned t_ga = tbase + lane * 16, t_gr = tbase + (lane >> 4) * 1024 + (lane & 15) * 16, t_sr = tbase + (lane & 15) * 16 + (lane >> 4) * 4;
+    const unsigned t_ta = tbase + lane * 16, t_tg = tbase + (lane & 15) * 16, t_ts = tbase + (lane & 15) * 16 + (lane >> 4) * 4;
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     {   // stage the Gram image (prepared in fragment order by nnf_hals_mfma_prep_kernel)
         const f32x4* src = reinterpret_cast<const f32x4*>(a.Mimg);
@@ -415,13 +428,37 @@ __global__ __launch_bounds__(256, 2) void nnf_hals_mfma_kernel(hals_args a) {
             for (int j = 0; j < 4; ++j) accx[j] = ax[j];
             fresh = 0;
         }
+        mfma_sweeper<RT, REM, NKB, GUARD> sw{acc, accx, v, img_addr, (uint64_t)a.Mlt, t_ta, t_tg, t_ts};
+        constexpr int NBK = 4 * (sw.SPB + 1);   // rows of v that head() moves
+        f32x4* const bk = &bkp[threadIdx.x >> 6][0][lane];
+        // ONE instance of each big piece inside the loop (several call sites of head() / the residual make hipcc merge tiles
+        // and v at every join: 500 spilled registers).  An iteration = [residual from scratch if scheduled] [head of sweep s]
+        // [decision on sweep s-1] [tail of sweep s] [publish].  Residual and head run BEFORE the decision on the previous
+        // sweep arrives -- lag-one speculation on a prefix of the sweep: the residual changes nothing that outlives the solve,
+        // the head's rows of v are backed up in LDS and put back if sweep s-1 was the last one.
         int s = 1;
+        bool pending = false;   // sweep s-1 is published, its global sum not looked at yet
+        bool undo = false;
 #pragma unroll 1
         for (;;) {
-            asm volatile("" : "+v"(fresh));
+            asm volatile("" : "+v"(fresh));   // (opaque: hipcc otherwise specialises the first sweep)
             if (__builtin_amdgcn_readfirstlane(fresh)) mfma_residual<RT, REM, NKB>(acc, accx, v, img_addr, rb, voff0, ldm4, a.Mlt, a.sp);
-            mfma_sweeper<RT, REM, NKB, GUARD> sw{acc, accx, v, img_addr, (uint64_t)a.Mlt, t_ga, t_gr, t_sr};
-            const float f = sw.sweep();
+#pragma unroll
+            for (int b = 0; b < NBK / 4; ++b) bk[b * 64] = f32x4{v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]};
+            sw.head();
+            if (pending) {
+                double tot;
+                ok = hals_collect1(a.sy, s - 1, nblocks, tot, red2[(s - 1) & 1][1], &lds_flag, pf);
+                if (ok) {
+                    if (s == 2 && a.sweep0 == 0) eps0 = tot;
+                    eps = tot;
+                }
+                if (!ok || !(eps >= a.delta * eps0)) {   // nnls.py:156: sweep s-1 was the last one -> sweep s does not take place:
+                    undo = true;                          // its head's rows of v are taken from the backup when V is stored
+                    break;                                // (assigning them to v here makes hipcc keep two copies of everything)
+                }
+            }
+            const float f = sw.tail();
             const double nd = gtid < a.ncols ? (double)f : 0.0;
             const double bs = hals_block_sum1<256>(nd, red2[s & 1][0]);
             done = s;
@@ -441,16 +478,20 @@ __global__ __launch_bounds__(256, 2) void nnf_hals_mfma_kernel(hals_args a) {
                 }
             } else {
                 hals_publish(a.sy, s, nblocks, bs);
-                double tot;
-                ok = hals_collect1(a.sy, s, nblocks, tot, red2[s & 1][1], &lds_flag, pf);
-                if (!ok) break;
-                if (s == 1 && a.sweep0 == 0) eps0 = tot;
-                eps = tot;
-                if (!(eps >= a.delta * eps0)) break;   // nnls.py:156: sweep s was the last one
+                pending = true;
             }
             if (s >= a.max_sweeps) break;
+            // from-scratch residuals are scheduled on the ABSOLUTE sweep index, so chunking does not move them
             fresh = ((a.sweep0 + s) % MFMA_NREF_V) == 0 || (MFMA_EARLY && a.sweep0 + s == 1);
             ++s;
+        }
+        if (a.mode == 0 && ok && done == s && pending) {   // ran to the sweep budget: the last sweep's sum is still due
+            double tot;
+            ok = hals_collect1(a.sy, s, nblocks, tot, red2[s & 1][1], &lds_flag, pf);
+            if (ok) {
+                if (s == 1 && a.sweep0 == 0) eps0 = tot;
+                eps = tot;
+            }
         }
         if (st_out != nullptr) {   // (the tiles are complete: the sweep ends with the MFMA -> reader distance)
 #pragma unroll
@@ -460,7 +501,14 @@ __global__ __launch_bounds__(256, 2) void nnf_hals_mfma_kernel(hals_args a) {
             *reinterpret_cast<f32x4*>(st_out + RT * 4 * 256) = f32x4{accx[0], accx[1], accx[2], accx[3]};
         }
 #pragma unroll
-        for (int k = 0; k < RP; ++k) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), rv, voff0, k * ldv4, 0);
+        for (int k = 0; k < RP; ++k) {
+            float val = v[k];
+            if (k < NBK) {
+                const float old = bk[(k / 4) * 64][k % 4];
+                val = undo ? old : val;
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rv, voff0, k * ldv4, 0);
+        }
     };
     if (all_live) run(std::false_type{});
     else run(std::true_type{});

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from nn_fac_amd.engine import get_engine
 eng = get_engine("cuda:0")
-for r, m in ((50, 100000), (50, 131072), (30, 100000), (64, 100000)):
+cases = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(50, 100000), (50, 131072), (30, 100000), (64, 100000)]
+for r, m in cases:
     g = torch.Generator(device="cuda").manual_seed(1)
     A = torch.rand(300, r, device="cuda", generator=g)
     G = (A.t() @ A).contiguous()

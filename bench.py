@@ -129,7 +129,7 @@ def synth_nmf_block_device(rows, n, r, seed, hseed, device, torch):
 
 
 # ---- CPU baseline ---------------------------------------------------------------------------------------------------
-def cpu_baseline_nmf(X, U, V, r, rule, beta, gpu_sweeps):
+def cpu_baseline_nmf(X, U, V, r, rule, beta, gpu_sweeps, its=3, extras=True):
     """Bounded sample of the same workload through the CPU oracle (the reference's statement sequence): the same X, starting
     from the factors the GPU's timed region started from.  fp32 on all host threads (the headline), fp64 (the reference's
     default dtype) and a 1-thread figure on a row sample."""
@@ -154,13 +154,15 @@ def cpu_baseline_nmf(X, U, V, r, rule, beta, gpu_sweeps):
             sw.append(log)
         return (time.time() - t0) / its, sw
 
-    its = 3
+    its = int(its)
     dt32, sw32 = run(X, U, V, its)
     out = {"value": 1.0 / dt32, "unit": "iterations/s", "cores": int(threads), "kind": "port",
            "sample": f"{its} iterations of one_nmf_step ({rule}, beta={beta:g}) on the full {m}x{n} rank-{r} fp32 problem: "
                      f"the same X as the GPU leg, starting from the factors its timed region started from; "
                      f"NumPy/OpenBLAS threads={threads}",
            "inner_sweeps": sw32, "gpu_inner_sweeps_same_iterations": gpu_sweeps[:its]}
+    if not extras:
+        return out
     dt64, _ = run(X.astype(np.float64), U.astype(np.float64), V.astype(np.float64), 1)
     out["fp64"] = {"value": 1.0 / dt64, "sample": "1 iteration, same start, float64 (the reference's default dtype)"}
     if threadpool_limits is not None:
@@ -173,7 +175,40 @@ def cpu_baseline_nmf(X, U, V, r, rule, beta, gpu_sweeps):
     return out
 
 
-def cpu_baseline_ntf(T, F, R):
+def cpu_baseline_nmf_shard(Xs, Us, V, r, rows_total, gpu_sweeps):
+    """Config E's CPU leg: ONE iteration of the oracle's one_nmf_step on a row shard of the problem -- the first
+    `Xs.shape[0]` rows, same data and start factors as the GPU leg -- scaled to the whole problem: everything that runs per row
+    block (cross products, U-side solve, cost) scales with rows_total / rows; the replicated r x n V-side solve is timed on its
+    own and counted once.  Labelled as a scaled shard figure, not a run of the whole problem."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nnfac_oracle as orc
+    import math
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    ms = int(Xs.shape[0])
+    log = []
+    t0 = time.time()
+    Un, Vn, _ = orc.one_nmf_step(Xs, r, Us, V, None, "hals", 2, [None, None], [], [False, False], True, sweeps=log)
+    t_all = time.time() - t0
+    UtU, UtM = Un.T @ Un, Un.T @ Xs
+    t0 = time.time()
+    orc.hals_nnls_acc(UtM, UtU, V, maxiter=100, alpha=math.inf, delta=0.01)
+    t_v = time.time() - t0
+    scale = rows_total / ms
+    t_whole = scale * max(t_all - t_v, 0.0) + t_v
+    return {"value": 1.0 / t_whole, "unit": "iterations/s", "cores": int(threads), "kind": "port",
+            "sample": f"1 iteration of one_nmf_step (hals) on the first {ms} rows (1/{rows_total // ms} of the {rows_total} x "
+                      f"{Xs.shape[1]} rank-{r} fp32 problem; same data and start factors as the GPU leg): {t_all:.2f} s, of which "
+                      f"the replicated V-side solve {t_v:.2f} s; whole problem = {scale:.0f} x the per-row-block part + the V-side "
+                      f"solve once = {t_whole:.1f} s per iteration -- a SCALED SHARD figure; NumPy/OpenBLAS threads={threads}",
+            "inner_sweeps": log, "gpu_inner_sweeps_first_iteration": gpu_sweeps[:1]}
+
+
+def cpu_baseline_ntf(T, F, R, its=2):
     import numpy as np
     import math
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -185,7 +220,7 @@ def cpu_baseline_ntf(T, F, R):
         threads = os.cpu_count() or 1
     unf = [orc.unfold(T, k) for k in range(3)]
     nrm = float(np.linalg.norm(T.astype(np.float64)))
-    its = 2
+    its = int(its)
     t0 = time.time()
     for _ in range(its):
         F, _ = orc.one_ntf_step(unf, R, F, nrm, "hals", 2, [None] * 3, [], [False] * 3, alpha=math.inf)
@@ -469,11 +504,21 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta, loop_times=None, steps=20
         eng.xht(X, V, out=ws.VMt)
         F = Ut.clone()
         ms = eng.time_kernel("hals", lambda: eng.hals_sweeps(ws.VMt, G, F, ns), reps=5) / ns
-        out.append(roof(f"nnf_hals_kernel (U side: {m} columns, rank {r}; one lane per column, per sweep over {ns} fixed "
-                        f"sweeps)", "valu", 2.0 * r * r * m, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
-                        algorithmic_flops=2.0 * r * r * m, us_per_sweep=ms * 1e3, in_loop_solve=solves.get("U"),
-                        note="Gauss-Seidel row dependence: issue bound of this formulation is ~2.4x the 2r^2m/peak time "
-                             "(DESIGN.md 3); in_loop_solve: the persistent solve of the loop, stopping rule included"))
+        cols_blk = min(m, eng.hals_resident_columns(r)) if hasattr(eng, "hals_resident_columns") else m
+        on_mfma = hasattr(eng, "hals_resid_floats") and eng.hals_resid_floats(r, cols_blk) > 0
+        if on_mfma:
+            out.append(roof(f"nnf_hals_mfma_kernel (U side: {m} columns, rank {r}; push form of the sweep on the matrix cores, "
+                            f"k_hals_mfma.hip, per sweep over {ns} fixed sweeps)", "mfma", 2.0 * r * r * m, ms, MFMA_F32_PEAK_TFLOPS,
+                            "TFLOP/s", algorithmic_flops=2.0 * r * r * m, us_per_sweep=ms * 1e3, in_loop_solve=solves.get("U"),
+                            note="2 r^2 flops per column and sweep as rank-4 MFMA updates of the scaled residual; the four row "
+                                 "updates per k-block stay on the VALU, which never overlaps fp32 MFMAs on a SIMD (DESIGN.md 3); "
+                                 "in_loop_solve: the persistent solve of the loop, stopping rule included"))
+        else:
+            out.append(roof(f"nnf_hals_kernel (U side: {m} columns, rank {r}; one lane per column, per sweep over {ns} fixed "
+                            f"sweeps)", "valu", 2.0 * r * r * m, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
+                            algorithmic_flops=2.0 * r * r * m, us_per_sweep=ms * 1e3, in_loop_solve=solves.get("U"),
+                            note="Gauss-Seidel row dependence: issue bound of this formulation is ~2.4x the 2r^2m/peak time "
+                                 "(DESIGN.md 3); in_loop_solve: the persistent solve of the loop, stopping rule included"))
         G2 = eng.gram(Ut)
         eng.xty(X, Ut, out=ws.UtM)
         F2 = V.clone()
@@ -512,7 +557,7 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta, loop_times=None, steps=20
     return out
 
 
-def bench_nmf(cx, args, cfg, steps, warmup, with_cpu, with_fixed, with_kernels):
+def bench_nmf(cx, args, cfg, steps, warmup, with_cpu, with_fixed, with_kernels, cpu_its=3, steady=False):
     torch = cx.torch
     m, n, r, rule = cfg["m"], cfg["n"], cfg["r"], cfg["rule"]
     beta = args.beta if (args.beta is not None and rule == "mu") else cfg["beta"]
@@ -563,6 +608,26 @@ def bench_nmf(cx, args, cfg, steps, warmup, with_cpu, with_fixed, with_kernels):
     if rule == "hals" and cx.cuda:
         out["cost_evaluation"] = ("streaming kernel (nnf_frob_resid_f32)" if (run.ws.direct_cost or os.environ.get("NNF_COST") == "direct")
                                   else "Gram identity (nnf_nmf_gram_cost_f32), fp64 inner products, guarded by its own error estimate")
+    if steady and rule == "hals" and cx.world == 1:
+        # a window that starts once the inner solves have settled (two consecutive iterations whose sweep counts differ by <= 4
+        # in both solves -- the loop's own settle rule): comparable across boxes and rounds, unlike the default window, which
+        # sits in the transient of the first two dozen iterations
+        extra_its, prev = 0, sweeps[-1] if sweeps else None
+        while extra_its < 80:
+            run.sweeps.clear()
+            run.run(2)
+            extra_its += 2
+            a_, b_ = run.sweeps[-2], run.sweeps[-1]
+            if all(abs(x - y) <= 4 for x, y in zip(a_, b_)):
+                break
+        run.sweeps.clear()
+        sdt, _ = cx.timed(lambda: run.run(steps))
+        ssw = list(run.sweeps)
+        out["steady_state"] = {"iterations_per_s": units * steps / sdt, "ms_per_step": 1e3 * sdt / steps, "steps": steps,
+                               "iterations_before_the_window": warmup + steps + extra_its,
+                               "inner_sweeps_mean": sum(sum(x) for x in ssw) / max(1, len(ssw)),
+                               "inner_sweeps_per_step_last": ssw[-1] if ssw else None,
+                               "rule": "starts once two consecutive iterations differ by <= 4 sweeps in both inner solves"}
     if with_fixed and rule == "hals":
         f = run.fixed_work()
         f["iterations_per_s"] *= units
@@ -584,11 +649,15 @@ def bench_nmf(cx, args, cfg, steps, warmup, with_cpu, with_fixed, with_kernels):
     if host is not None:
         U_s, V_s = start[0].t().contiguous().cpu().numpy(), start[1].cpu().numpy()
         del run, X
-        out["cpu_baseline"] = cpu_baseline_nmf(host, U_s, V_s, r, rule, beta, sweeps)
+        out["cpu_baseline"] = cpu_baseline_nmf(host, U_s, V_s, r, rule, beta, sweeps, its=cpu_its, extras=cpu_its >= 3)
+    elif with_cpu and cfg["scaling"] == "strong" and cx.world == 1 and cx.rank == 0 and cx.cuda:
+        ms = m // 64                 # 1/8 of one of the 8 row blocks: ~10-20 s of CPU work
+        out["cpu_baseline"] = cpu_baseline_nmf_shard(X[:ms].cpu().numpy(), start[0][:, :ms].t().contiguous().cpu().numpy(),
+                                                     start[1].cpu().numpy(), r, m, sweeps)
     return out
 
 
-def bench_ntf(cx, args, cfg, steps, warmup, with_cpu, with_kernels):
+def bench_ntf(cx, args, cfg, steps, warmup, with_cpu, with_kernels, cpu_its=2):
     import math
     torch = cx.torch
     from nn_fac_amd import ntf as ntf_mod
@@ -673,7 +742,7 @@ def bench_ntf(cx, args, cfg, steps, warmup, with_cpu, with_kernels):
     if with_cpu and cx.world == 1 and cx.rank == 0:
         Fs = [f.t().contiguous().cpu().numpy() for f in start]
         del T, st
-        out["cpu_baseline"] = cpu_baseline_ntf(Th, Fs, R)
+        out["cpu_baseline"] = cpu_baseline_ntf(Th, Fs, R, its=cpu_its)
     return out
 
 
@@ -691,8 +760,8 @@ def main():
     world = cx.world
 
     if cfg["kind"] == "nmf":
-        res = bench_nmf(cx, args, cfg, args.steps, args.warmup, not args.no_cpu and cfg["scaling"] == "weak",
-                        not args.no_fixed, not args.no_kernels)
+        res = bench_nmf(cx, args, cfg, args.steps, args.warmup, not args.no_cpu, not args.no_fixed, not args.no_kernels,
+                        steady=(args.config == "B" and not args.no_fixed and not args.shape))
     else:
         res = bench_ntf(cx, args, cfg, args.steps, args.warmup, not args.no_cpu, not args.no_kernels)
 
@@ -713,6 +782,27 @@ def main():
         except Exception as exc:      # an extra: it must never cost the line of the configuration that was asked for
             # (deterministic failures -- an unsupported shape, an allocation -- hit every rank at the same call)
             extra = {"E": {"workload": ewhat, "error": f"{type(exc).__name__}: {exc}"[:300]}}
+        # configs[2] and configs[3], short legs on the same box in the same run: rate, the dominant kernel's roofline (launches
+        # inside the leg's timed loop) and a one-iteration CPU baseline
+        for name in ("C", "D"):
+            xcfg = dict(CONFIGS[name])
+            if cx.cuda:
+                cx.torch.cuda.empty_cache()
+            xwhat = (f"{'NMF mu beta=1' if name == 'C' else 'NTF hals'} {xcfg['m']}{'x' + str(xcfg['n']) if name == 'C' else '^3'} rank "
+                     f"{xcfg['r']} per GPU ({xcfg['ref']} of BASELINE.json), 10 steps after 3 warm-up")
+            try:
+                with_x = world == 1 and not args.no_cpu
+                if xcfg["kind"] == "nmf":
+                    x = bench_nmf(cx, args, xcfg, 10, 3, with_x, False, not args.no_kernels, cpu_its=1)
+                else:
+                    x = bench_ntf(cx, args, xcfg, 10, 3, with_x, not args.no_kernels, cpu_its=1)
+                rlx = x.get("rooflines") or []
+                extra[name] = {"workload": xwhat, "iterations_per_s": x["value"], "ms_per_step": x["ms_per_step"], "steps": 10,
+                               "warmup": 3, "inner_sweeps_per_step_last": x.get("inner_sweeps_per_step_last"),
+                               "final_cost": x["final_cost"], "scaling": "weak", "roofline": rlx[0] if rlx else None,
+                               "cpu_baseline": x.get("cpu_baseline")}
+            except Exception as exc:
+                extra[name] = {"workload": xwhat, "error": f"{type(exc).__name__}: {exc}"[:300]}
 
     if cx.rank == 0:
         rule, beta = res["rule"], res["beta"]
@@ -758,6 +848,8 @@ def main():
             out["fixed_work"] = res["fixed_work"]
         if "nondeterministic" in res:
             out["nondeterministic"] = res["nondeterministic"]
+        if "steady_state" in res:
+            out["steady_state"] = res["steady_state"]
         if "cost_evaluation" in res:
             out["config"]["cost_evaluation"] = res["cost_evaluation"]
         if getattr(cx, "spun", False):

@@ -397,6 +397,9 @@ class NmfRun:
                 "inner": "10 sweeps per solve (delta=0, maxiter=10)"}
 
 
+PROFILE_TAG = "r04"      # profiles/<tag>_<config>_traffic.json: the committed PMC collection attach_traffic() may quote
+
+
 def roof(kernel, bound, algo, ms, peak, unit, **more):
     """One roofline entry: `algo` algorithmic flops (bound mfma / valu) or bytes (bound hbm) per launch, `ms` mean launch."""
     achieved = algo / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
@@ -408,12 +411,23 @@ def roof(kernel, bound, algo, ms, peak, unit, **more):
     return d
 
 
-def attach_traffic(entries, cfg_name):
+def library_build_flags():
+    """The -D switches every translation unit of the loaded library was compiled with (nnf_build_flags)."""
+    import ctypes
+    from nn_fac_amd import _lib
+    buf = ctypes.create_string_buffer(16384)
+    n = _lib.load().nnf_build_flags(buf, 16384)
+    return buf.value.decode() if 0 < n < 16384 else ""
+
+
+def attach_traffic(entries, cfg_name, shape):
     """`traffic` of a roofline entry = HBM bytes per launch from the PMC passes of this same command committed under profiles/
     (tools/bench_profile.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs, FETCH_SIZE doubled per the gfx950
     correction of MI355X_MICROARCH.md, tools/collect_profiles.py) -- counters cannot be read from inside the process that is
-    being timed, so this is the committed figure for this configuration's shape, named as such; null where none was collected."""
-    path = os.path.join(ROOT, "profiles", f"r03_{cfg_name}_traffic.json")
+    being timed.  The committed file names the shape and the library build switches it was collected with: the figure is
+    attached only when both equal this run's (else `traffic` stays null and `traffic_note` says why); it is a figure of that
+    collection, named as such in `traffic_source`, not a counter of this process."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{cfg_name}_traffic.json")
     if not os.path.exists(path):
         return
     try:
@@ -421,14 +435,24 @@ def attach_traffic(entries, cfg_name):
             table = json.load(fh)
     except (OSError, ValueError):
         return
+    meta = table.get("_meta") or {}
+    why = None
+    if meta.get("shape") != list(shape):
+        why = f"committed traffic was collected at shape {meta.get('shape')}, this run is {list(shape)}"
+    elif meta.get("build_flags") != library_build_flags():
+        why = "committed traffic was collected with a library built with other -D switches"
     used = set()
     for e in entries:
         for key, row in table.items():
             if key.startswith("_") or key in used or not isinstance(row, dict):
                 continue
             if e["kernel"].startswith(key) and row.get("hbm_bytes_per_launch"):
+                if why:
+                    e["traffic_note"] = why
+                    break
                 e["traffic"] = int(row["hbm_bytes_per_launch"])
-                e["traffic_source"] = f"profiles/r03_{cfg_name}_traffic.json (PMC passes of this command, mean of {row.get('launches')} launches)"
+                e["traffic_source"] = (f"profiles/{PROFILE_TAG}_{cfg_name}_traffic.json (PMC passes of this command at commit "
+                                       f"{meta.get('commit', '?')}, mean of {row.get('launches')} launches)")
                 if e.get("algorithmic_bytes"):
                     e["traffic_over_algorithmic"] = e["traffic"] / e["algorithmic_bytes"]
                 used.add(key)
@@ -492,7 +516,8 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta, loop_times=None, steps=20
         # the two persistent solves as the loop runs them (stopping rule on the device): launches alternate U side, V side
         ts, sw = run.inloop(eng, "hals", 2, steps)
         solves = {}
-        if sw and len(ts) >= 2 * len(sw) and all(len(x) == 2 for x in sw):
+        cap = eng.hals_resident_columns(r) if hasattr(eng, "hals_resident_columns") else m
+        if sw and len(ts) >= 2 * len(sw) and all(len(x) == 2 for x in sw) and m <= cap:   # (a solve = one launch)
             for side, name in ((0, "U"), (1, "V")):
                 dur = [ts[2 * i + side] for i in range(len(sw))]
                 cnt = [x[side] for x in sw]
@@ -502,9 +527,15 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta, loop_times=None, steps=20
         ns = 20
         G = eng.gram(V)
         eng.xht(X, V, out=ws.VMt)
-        F = Ut.clone()
-        ms = eng.time_kernel("hals", lambda: eng.hals_sweeps(ws.VMt, G, F, ns), reps=5) / ns
-        cols_blk = min(m, eng.hals_resident_columns(r)) if hasattr(eng, "hals_resident_columns") else m
+        # (more columns than the resident kernel holds -- config E on one device: the loop solves them in resident blocks, and
+        # one such block is what this entry times)
+        from nn_fac_amd import dist as _nd
+        blk = _nd.column_blocks(eng, Ut)[0]
+        cols_blk = blk[1] - blk[0]
+        F = Ut[:, :cols_blk].clone() if cols_blk < m else Ut.clone()
+        VMb = ws.VMt[:, :cols_blk] if cols_blk < m else ws.VMt
+        ms = eng.time_kernel("hals", lambda: eng.hals_sweeps(VMb, G, F, ns), reps=5) / ns
+        m_all, m = m, cols_blk
         on_mfma = hasattr(eng, "hals_resid_floats") and eng.hals_resid_floats(r, cols_blk) > 0
         if on_mfma:
             out.append(roof(f"nnf_hals_mfma_kernel (U side: {m} columns, rank {r}; push form of the sweep on the matrix cores, "
@@ -519,6 +550,7 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta, loop_times=None, steps=20
                             algorithmic_flops=2.0 * r * r * m, us_per_sweep=ms * 1e3, in_loop_solve=solves.get("U"),
                             note="Gauss-Seidel row dependence: issue bound of this formulation is ~2.4x the 2r^2m/peak time "
                                  "(DESIGN.md 3); in_loop_solve: the persistent solve of the loop, stopping rule included"))
+        m = m_all
         G2 = eng.gram(Ut)
         eng.xty(X, Ut, out=ws.UtM)
         F2 = V.clone()
@@ -651,7 +683,7 @@ def bench_nmf(cx, args, cfg, steps, warmup, with_cpu, with_fixed, with_kernels, 
         del run, X
         out["cpu_baseline"] = cpu_baseline_nmf(host, U_s, V_s, r, rule, beta, sweeps, its=cpu_its, extras=cpu_its >= 3)
     elif with_cpu and cfg["scaling"] == "strong" and cx.world == 1 and cx.rank == 0 and cx.cuda:
-        ms = m // 64                 # 1/8 of one of the 8 row blocks: ~10-20 s of CPU work
+        ms = m // 8                  # one of the 8 row blocks (what a rank of the 8-GPU run holds): ~10 s of CPU work
         out["cpu_baseline"] = cpu_baseline_nmf_shard(X[:ms].cpu().numpy(), start[0][:, :ms].t().contiguous().cpu().numpy(),
                                                      start[1].cpu().numpy(), r, m, sweeps)
     return out
@@ -819,7 +851,7 @@ def main():
                         f"delta=0.01, maxiter=100")
         rl = res.get("rooflines") or []
         if rl and not args.shape and world == 1:
-            attach_traffic(rl, args.config)
+            attach_traffic(rl, args.config, (cfg["m"], cfg["n"], cfg["r"]))
         out = {
             "metric": what + shape_note,
             "value": res["value"],

@@ -19,7 +19,22 @@ configs = sys.argv[2:] or ["B", "C", "D"]
 MAIN = {"B": ["nnf_xty_kernel", "nnf_xht_kernel", "nnf_cost_kernel", "nnf_hals_kernel", "nnf_hals_wave_kernel", "nnf_gram_cost_kernel",
               "nnf_gram_kernel"],
         "C": ["nnf_mu_left_kernel", "nnf_mu_right_kernel", "nnf_cost_kernel"],
-        "D": ["nnf_mttkrp_rows_kernel", "nnf_xht_lds_kernel", "nnf_hals_wave_kernel", "nnf_gram_cost_kernel", "nnf_mu_left_kernel"]}
+        "D": ["nnf_mttkrp_rows_kernel", "nnf_xht_lds_kernel", "nnf_hals_wave_kernel", "nnf_gram_cost_kernel", "nnf_mu_left_kernel"],
+        "E": ["nnf_xty_kernel", "nnf_xht_kernel", "nnf_hals_mfma_kernel", "nnf_hals_wave_kernel", "nnf_gram_cost_kernel", "nnf_gram_kernel"]}
+SHAPES = {"B": [100000, 2000, 50], "C": [100000, 2000, 50], "D": [500, 500, 30], "E": [1000000, 4000, 100]}
+
+
+def _meta(cfg):
+    """What the collection belongs to: commit, shape, and the -D switches of the library it ran (bench.py attaches the traffic
+    figures only to a run of the same shape and build)."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    try:
+        commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        commit = "?"
+    return {"commit": commit, "shape": SHAPES.get(cfg), "build_flags": bench.library_build_flags()}
 for cfg in configs:
     O = os.path.join(G, f"prof_{cfg}")
     if not os.path.isdir(O):
@@ -55,6 +70,7 @@ for cfg in configs:
             e["mfma_busy_frac"] = (sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(cs["SQ_VALU_MFMA_BUSY_CYCLES"])) / \
                 (32 * sum(cs["SQ_BUSY_CYCLES"]) / len(cs["SQ_BUSY_CYCLES"]))
         out[k] = e
+    out["_meta"] = _meta(cfg)
     out["_note"] = ("separate --pmc passes of `python3 bench.py --config %s --steps 3 --warmup 1 --no-cpu --no-fixed --no-extra "
                     "--no-kernels` (tools/bench_profile.sh); FETCH_SIZE doubled per the gfx950 correction; means over the "
                     "launches of each kernel" % cfg)

@@ -140,6 +140,16 @@ int nnf_frob_resid_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
  * own cost line IS this identity (ntf.py:462-470): V = the last updated factor (transposed), UtM = its MTTKRP right-hand side. */
 int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU, const float* UtU_b,
                           int64_t ldg, int r, int64_t n, const double* normx2_f64, double* out_f64, void* stream);
+/* The same with the caller's figures for the rounding of the cross term: sigma_a = relative rms error of a UtM entry, bias_a =
+ * |relative mean error| (both >= 0).  nnf_nmf_gram_cost_f32 assumes 6e-8 / 0 -- what the W^T X kernel leaves at 100000 rows;
+ * the error grows with the rows one workgroup sums in fp32 (1e6 x 4000 rank 100 on one device: 9.5e-7 rms, -2.2e-7 mean,
+ * tools/probes/accum_error_probe.py), and a mean error does not average down: the estimate becomes
+ *     4 sqrt((2 sigma_a ||V .* UtM||_F)^2 + sigma_B^2) + 4 bias_a |<V, UtM>|.
+ * A driver measures the two once per run (nn_fac_amd/nmf.py: the cross product summed in one piece against the same summed
+ * in 16 row blocks). */
+int nnf_nmf_gram_cost_cal_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
+                              const float* UtU_b, int64_t ldg, int r, int64_t n, const double* normx2_f64, double sigma_a,
+                              double bias_a, double* out_f64, void* stream);
 
 /* hals_nnls_acc (nnls.py:147-198) on device: V (r x ncols, in/out) is swept in place until
  *   eps >= delta*eps0 fails, or sweeps == max_sweeps                         (nnls.py:156)

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
                                                             int64_t ldm, const float* __restrict__ G, const float* __restrict__ G2,
                                                             int64_t ldg, int r, int64_t n,
                                                             double* __restrict__ partial, unsigned* __restrict__ ticket,
-                                                            const double* __restrict__ normx2, double* __restrict__ out) {
+                                                            const double* __restrict__ normx2, double* __restrict__ out,
+                                                            double sigma_a, double bias_a) {
     extern __shared__ float gc_sh[];
     float* g = gc_sh;                    // r x r
     float* vc = gc_sh + (size_t)r * r;   // 16 columns x r
@@ -258,20 +259,33 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
     if (threadIdx.x == 0) {
         gm = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
         const double cost = normx2[0] - 2.0 * tot[0] + tot[2];
-        // fp32 storage of UtM (relative rms 2^-24/sqrt(3) = 3.4e-8, measured 5.5e-8 with the accumulation) and of UtU:
-        //   sigma_A = 2 * 6e-8 * || V .* UtM ||_F,   sigma_B <= 4e-8 * max|UtU| * ||V||_F^2  (= trace of V V^T >= ||V V^T||_F)
-        const double sa = 2.0 * 6e-8 * sqrt(tot[1]), sb = 4e-8 * (double)gm * tot[3];
-        const double est = 4.0 * sqrt(sa * sa + sb * sb);
+        // fp32 storage of UtM (relative rms 2^-24/sqrt(3) = 3.4e-8, measured 5.5e-8 with the accumulation at config B) and of UtU:
+        //   sigma_A = 2 * sigma_a * || V .* UtM ||_F,   sigma_B <= 4e-8 * max|UtU| * ||V||_F^2  (= trace of V V^T >= ||V V^T||_F)
+        // sigma_a is the caller's figure for the relative rms rounding of a UtM entry -- it grows with the rows one workgroup of
+        // the cross-product kernel sums in fp32 (tools/probes/accum_error_probe.py: 5.7e-8 at 100000 x 2000 rank 50, 9.5e-7 at
+        // 1e6 x 4000 rank 100, there with a MEAN of -2.2e-7) -- and bias_a its figure for the relative mean: a bias does not
+        // average down over the entries, it enters with the whole inner product.
+        const double sa = 2.0 * sigma_a * sqrt(tot[1]), sb = 4e-8 * (double)gm * tot[3];
+        const double est = 4.0 * sqrt(sa * sa + sb * sb) + 2.0 * 2.0 * bias_a * fabs(tot[0]);
         out[0] = cost;
         out[1] = (est <= 5e-4 * cost) ? 0.0 : 1.0;      // (a NaN or a non-positive cost lands on 1)
         out[2] = est;
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call (stream-ordered)
     }
 }
+extern "C" int nnf_nmf_gram_cost_cal_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
+                                         const float* UtU_b, int64_t ldg, int r, int64_t n, const double* normx2_f64, double sigma_a,
+                                         double bias_a, double* out_f64, void* stream);
 extern "C" int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
                                      const float* UtU_b, int64_t ldg, int r, int64_t n, const double* normx2_f64, double* out_f64,
                                      void* stream) {
+    return nnf_nmf_gram_cost_cal_f32(ctx, V, ldv, UtM, ldm, UtU, UtU_b, ldg, r, n, normx2_f64, 6e-8, 0.0, out_f64, stream);
+}
+extern "C" int nnf_nmf_gram_cost_cal_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
+                                         const float* UtU_b, int64_t ldg, int r, int64_t n, const double* normx2_f64, double sigma_a,
+                                         double bias_a, double* out_f64, void* stream) {
     if (!ctx || !V || !UtM || !UtU || !normx2_f64 || !out_f64 || r < 1 || n < 1 || ldv < n || ldm < n || ldg < r) return NNF_ERR_ARG;
+    if (!(sigma_a >= 0.0) || !(bias_a >= 0.0)) return NNF_ERR_ARG;
     if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nwg = nnf_cdiv(n, 16);
@@ -289,7 +303,7 @@ extern "C" int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, 
         attr = true;
     }
     hipLaunchKernelGGL(nnf_gram_cost_kernel, dim3((int)nwg), dim3(256), shm, st, V, ldv, UtM, ldm, UtU, UtU_b, ldg, r, n, partial,
-                       ticket, normx2_f64, out_f64);
+                       ticket, normx2_f64, out_f64, sigma_a, bias_a);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
 }

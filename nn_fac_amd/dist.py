@@ -57,6 +57,12 @@ def allreduce_(t, group):
     return t
 
 
+def allreduce_max_(t, group):
+    if is_sharded(group):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
 def allreduce_cost_(block, group):
     """The cost word of an iteration's 24-double status block ([16]) summed over the row blocks -- and, in the same
     collective, copies of the error words of the iteration's two solves ([3], [11] -> [17], [18]).  A solve's error word is

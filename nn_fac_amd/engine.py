@@ -134,9 +134,10 @@ class Engine:
                                                _ld(V), r, _ptr(o), self._stream()), "nnf_frob_resid_f32")
         return o
 
-    def gram_cost(self, V, UtM, UtU, normx2, out, UtU_b=None):
-        """||X - U V||^2 through the Gram identity (nnf_nmf_gram_cost_f32): `normx2` a 1-element float64 device tensor holding
-        ||X||^2, `out` >= 3 float64 on the device: {cost, 1 if the fp32 operands do not carry it to 5e-4, error estimate}."""
+    def gram_cost(self, V, UtM, UtU, normx2, out, UtU_b=None, rounding=None):
+        """||X - U V||^2 through the Gram identity (nnf_nmf_gram_cost_cal_f32): `normx2` a 1-element float64 device tensor holding
+        ||X||^2, `out` >= 3 float64 on the device: {cost, 1 if the fp32 operands do not carry it to 5e-4, error estimate}.
+        rounding = (relative rms, |relative mean|) of the rounding error of a UtM entry (default: 6e-8, 0)."""
         _chk2d(V, "gram_cost V"), _chk2d(UtM, "gram_cost UtM"), _chk2d(UtU, "gram_cost UtU")
         r, n = V.shape
         if UtM.shape != (r, n) or UtU.shape[0] < r or UtU.shape[1] < r or normx2.dtype != torch.float64 or out.dtype != torch.float64 \
@@ -144,10 +145,28 @@ class Engine:
             raise EngineError("gram_cost: shape / dtype mismatch")
         if UtU_b is not None and (UtU_b.shape != UtU.shape or _ld(UtU_b) != _ld(UtU)):
             raise EngineError("gram_cost: the two Grams of a Hadamard pair must share shape and leading dimension")
-        _lib.check(self.lib.nnf_nmf_gram_cost_f32(self.ctx, _ptr(V), _ld(V), _ptr(UtM), _ld(UtM), _ptr(UtU),
-                                                  _ptr(UtU_b) if UtU_b is not None else None, _ld(UtU), r, n,
-                                                  _ptr(normx2), _ptr(out), self._stream()), "nnf_nmf_gram_cost_f32")
+        sa, ba = (6e-8, 0.0) if rounding is None else (float(rounding[0]), float(rounding[1]))
+        _lib.check(self.lib.nnf_nmf_gram_cost_cal_f32(self.ctx, _ptr(V), _ld(V), _ptr(UtM), _ld(UtM), _ptr(UtU),
+                                                      _ptr(UtU_b) if UtU_b is not None else None, _ld(UtU), r, n,
+                                                      _ptr(normx2), sa, ba, _ptr(out), self._stream()), "nnf_nmf_gram_cost_cal_f32")
         return out
+
+    def cross_rounding(self, X, Ut, blocks=16):
+        """(relative rms, |relative mean|) of the rounding error the W^T X kernel leaves in an entry of U^T X at THIS shape: the
+        product summed in one piece (row splits of the launch plan, fp32 accumulators per workgroup) against the same product
+        summed over `blocks` row blocks in float64 -- whose fp32 chains are `blocks` times shorter, so that the difference is
+        the long chains' error to ~1/sqrt(blocks).  Two passes over X, once per run (nmf.run_steps)."""
+        m = int(X.shape[0])
+        full = self.xty(X, Ut).double()
+        acc = torch.zeros_like(full)
+        step = -(-m // int(blocks))
+        step = -(-step // 256) * 256
+        for lo in range(0, m, step):
+            hi = min(m, lo + step)
+            acc += self.xty(X[lo:hi], Ut[:, lo:hi]).double()
+        rel = (full - acc) / acc.clamp_min(1e-300)
+        rel = torch.where(acc > 0, rel, torch.zeros_like(rel))
+        return float(rel.pow(2).mean().sqrt()), abs(float(rel.mean()))
 
     def dot(self, A, B):
         _chk2d(A, "dot A"), _chk2d(B, "dot B")

@@ -184,6 +184,7 @@ class _StepBuffers:
         self.safe_solve = False           # set by run_steps after a persistent solve timed out (chunked launches from then on)
         self.direct_cost = False          # set by run_steps when the Gram-identity cost said it cannot carry the residual
         self.normx2 = None                # ||X||^2 (float64 device scalar; row-sharded: summed over the ranks), on first use
+        self.cross_rounding = None        # (rms, |mean|) of the relative rounding of a U^T X entry at this shape, on first use
         # the r x r Gram of an update is independent of its cross product (nmf.py:407-408, :432-433): it runs on a side
         # stream, with its own context (a context's workspace serves one stream at a time), under the streaming kernel
         self.side_eng, self.side_stream = _engine.get_side_engine(X.device) if X.is_cuda else (None, None)
@@ -293,6 +294,15 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
     if ident and ws.normx2 is None:
         ws.normx2 = eng.dot(X, X)
         _dist.allreduce_(ws.normx2, group)
+    if ident and ws.cross_rounding is None:
+        # what the cross-product kernel's fp32 accumulation leaves in U^T X at this shape (it grows with the rows a workgroup
+        # sums: 5.7e-8 rms at config B, 9.5e-7 rms with a -2.2e-7 mean at 1e6 x 4000 rank 100): measured once per run, never
+        # below the figures the estimate was calibrated with; row-sharded: the largest over the ranks, so that every rank's
+        # (replicated) cost kernel flags the same iterates
+        sa, ba = eng.cross_rounding(X, Ut)
+        cal = torch.tensor([max(1.5 * sa, 6e-8), 1.5 * ba], dtype=torch.float64, device=X.device)
+        _dist.allreduce_max_(cal, group)
+        ws.cross_rounding = tuple(float(v) for v in cal.cpu())
     overlap = (cuda and update_rule == "hals" and 1 not in fixed_modes and isinstance(eng, _engine.Engine) and not ident
                and ws.cost_stream is not None
                and (not _dist.is_sharded(group) or _dist.opt_in("NNF_SHARDED_OVERLAP", group)))
@@ -397,7 +407,7 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
         ws.sync_next = False
         if ident:
             # words 19..21 of the block: {cost, 1 = not reliable, error estimate}; the V update's operands are still in place
-            eng.gram_cost(V, ws.UtM, ws.G2, ws.normx2, ws.block[19:22])
+            eng.gram_cost(V, ws.UtM, ws.G2, ws.normx2, ws.block[19:22], rounding=ws.cross_rounding)
             _add_sparsity_terms(Ut, V, sparsity_coefficients, ws.block[19:20], group)
             _dist.allreduce_errs_(ws.block, group)
             ws.host[ws.slot].copy_(ws.block, non_blocking=True)

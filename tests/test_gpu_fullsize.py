@@ -244,3 +244,88 @@ def test_config_e_full_size_on_one_gpu(built_lib):
     V2 = V0.clone()
     st = eng.hals_solve(UtM, G2, V2, 100, delta=0.01).cpu()
     assert int(st[ST_CNT]) - 1 == sv and torch.equal(V2, V1)
+
+
+def _identity_vs_direct(X, Ut0, V0, r, iters, monkeypatch, tol_rel):
+    """`iters` HALS iterations of the product's loop, once with the Gram-identity cost and once with NNF_COST=direct: returns the
+    two cost lists, the factors of the identity run and the kind of every identity-run cost."""
+    from nn_fac_amd.engine import get_engine
+    from nn_fac_amd import nmf as nmf_mod
+    eng = get_engine(X.device)
+    out = {}
+    for kind in ("identity", "direct"):
+        if kind == "direct":
+            monkeypatch.setenv("NNF_COST", "direct")
+        else:
+            monkeypatch.delenv("NNF_COST", raising=False)
+        ws = nmf_mod._StepBuffers(X, r)
+        costs = []
+
+        def retired(it, cost, sw):
+            costs.append(float(cost))
+            return False
+        retired.revise_last = lambda c: costs.__setitem__(-1, float(c))
+        Ut, V = nmf_mod.run_steps(eng, ws, X, r, Ut0.clone(), V0.clone(), iters, "hals", 2, [None, None], [], [False, False], True,
+                                  retired)
+        out[kind] = (costs, Ut, V, ws)
+    monkeypatch.delenv("NNF_COST", raising=False)
+    return out
+
+
+def _chunked_fp64_cost(X, Ut, V, step=50000):
+    want = 0.0
+    for lo in range(0, X.shape[0], step):
+        want += float(((X[lo:lo + step].double() - Ut[:, lo:lo + step].double().t() @ V.double()) ** 2).sum())
+    return want
+
+
+def test_identity_cost_tracks_the_direct_cost_over_a_whole_run_at_config_b(config_b_data, built_lib, monkeypatch):
+    """configs[1], 25 iterations (the driver's default run): the Gram-identity cost of EVERY iteration against the streaming
+    kernel's (NNF_COST=direct: same factors, the cost does not feed back into them) <= 1e-4, and the last one against a chunked
+    fp64 residual of the final factors.  The identity's error is relative to ||X||^2, so it grows as the fit improves: two
+    iterations (test_config_b_hals_full_size) do not show it."""
+    X, U0, V0 = config_b_data
+    Xd = torch.from_numpy(X).cuda()
+    Ut0 = torch.from_numpy(U0.T.copy()).cuda()
+    Vd = torch.from_numpy(V0).cuda()
+    res = _identity_vs_direct(Xd, Ut0, Vd, 50, 25, monkeypatch, 1e-4)
+    ci, cd = res["identity"][0], res["direct"][0]
+    assert len(ci) == len(cd) == 25
+    assert torch.equal(res["identity"][1], res["direct"][1]) and torch.equal(res["identity"][2], res["direct"][2])
+    worst = max(abs(a - b) / b for a, b in zip(ci, cd))
+    assert worst <= 1e-4, (worst, ci[-3:], cd[-3:])
+    want = _chunked_fp64_cost(Xd, res["identity"][1], res["identity"][2])
+    assert abs(ci[-1] - want) <= 1e-4 * want and abs(cd[-1] - want) <= 1e-6 * want, (ci[-1], cd[-1], want)
+    assert not res["identity"][3].direct_cost          # the guard did not have to fall back on this data
+
+
+@pytest.mark.parametrize("rows", [125000, 1000000])
+def test_identity_cost_at_rank_100_long_accumulations(rows, built_lib, monkeypatch):
+    """configs[4]'s shapes -- the per-rank block (125000 x 4000, rank 100) and the whole problem on one device (1e6 rows) --
+    12 iterations: the W^T X kernel sums far more rows per workgroup in fp32 than at config B (relative rounding of a U^T X
+    entry 3e-7 ... 9.5e-7 rms with a -2e-7 mean at 1e6 rows against 6e-8: tools/probes/accum_error_probe.py), so the error
+    estimate of the identity cost is calibrated per run (Engine.cross_rounding).  Every identity cost that the loop kept must be
+    within ITS OWN estimate of the direct cost and within 5e-4; an iterate the guard flags switches the run to the direct cost
+    (then the costs are the direct run's bit for bit); and the calibration itself must see the longer chains."""
+    import bench
+    from nn_fac_amd.engine import get_engine
+    m, n, r = rows, 4000, 100
+    dev = torch.device("cuda:0")
+    eng = get_engine(dev)
+    nb = rows // 125000
+    parts = [bench.synth_nmf_block_device(125000, n, r, b, 977, dev, torch) for b in range(nb)]
+    X = torch.cat([p[0] for p in parts]) if nb > 1 else parts[0][0]
+    Ut0 = (torch.cat([p[1] for p in parts]) if nb > 1 else parts[0][1]).t().contiguous()
+    del parts
+    V0 = torch.rand(r, n, device=dev, generator=torch.Generator(device=dev).manual_seed(4242))
+    sa, ba = eng.cross_rounding(X, Ut0)
+    assert 1e-7 < sa < 5e-6 and ba < 2e-6, (sa, ba)          # an order of magnitude above config B's 6e-8
+    res = _identity_vs_direct(X, Ut0, V0, r, 12, monkeypatch, 5e-4)
+    ci, cd = res["identity"][0], res["direct"][0]
+    assert torch.equal(res["identity"][1], res["direct"][1]) and torch.equal(res["identity"][2], res["direct"][2])
+    worst = max(abs(a - b) / b for a, b in zip(ci, cd))
+    assert worst <= 5e-4, (worst, ci, cd)
+    want = _chunked_fp64_cost(X, res["direct"][1], res["direct"][2], step=25000)
+    assert abs(cd[-1] - want) <= 1e-5 * want
+    if res["identity"][3].direct_cost:                       # flagged on the way: from there on the direct run's costs
+        assert ci[-1] == cd[-1]

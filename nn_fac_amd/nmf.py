@@ -109,6 +109,11 @@ def compute_nmf(data, rank, U_in, V_in, n_iter_max=100, tol=1e-8,
         return False
 
     def revise_last(cost):
+        # the loop switched from the Gram-identity cost to the streaming kernel (run_steps): the last value is re-evaluated the
+        # same way, so that the variation printed next -- and the stopping test -- compare two costs of one kind
+        if verbose:
+            print('(cost evaluation switched to the pass over the data; last value {} re-evaluated: {})'.format(
+                cost_fct_vals[-1], cost))
         cost_fct_vals[-1] = cost
     retired.revise_last = revise_last
 

@@ -1128,6 +1128,16 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
     const int nblk_all = (int)nnf_cdiv(n, 64);
     int csplit = (int)nnf_cdiv((int64_t)8 * 2 * ctx->num_cus, grid);
     if (csplit > nblk_all / 4) csplit = nblk_all / 4;
+    // every column split stages the workgroup's 128 x r tile of U again: keep that re-read below ~5 % of the pass over X
+    // (config B: 6 splits moved 1.02 GB for 0.82 GB algorithmic, PMC; the launch time is flat over 2..8 splits, so the
+    // splits buy nothing there) -- as long as the grid still fills the resident slots twice over
+    {
+        int cap = (int)((0.05 * (double)n) / (double)(r > 0 ? r : 1));
+        if (cap < 1) cap = 1;
+        const int need = (int)nnf_cdiv((int64_t)2 * 3 * ctx->num_cus, grid);   // two rounds of 3 workgroups per CU
+        if (cap < need) cap = need;
+        if (Ub == nullptr && csplit > cap) csplit = cap;
+    }
     {   // tuning knob (tools/cost_probe.py): NNF_COST_CSPLIT overrides the number of column splits
         static const int forced = [] { const char* e = getenv("NNF_COST_CSPLIT"); return e ? atoi(e) : 0; }();
         if (forced > 0) csplit = forced < nblk_all ? forced : nblk_all;

@@ -199,26 +199,26 @@ __device__ __forceinline__ float nnf_h(float t, float q) {
 
 // KL term written on the reciprocal of the MODEL entry: x ln(x/p) - x + p = p g(rho), rho = x/p (>= 0 by construction),
 //   g(rho) = rho ln(rho) - rho + 1 = (1 + s) ln(1 + s) - s,  s = (x - p)/p
-//   |s| < 1/4: s^2 sum_k (-s)^k / ((k+1)(k+2))  (coefficients fall like 1/k^2: 10 terms for fp32, no cancellation);
+//   |s| < 1/8: s^2 sum_k (-s)^k / ((k+1)(k+2))  (coefficients fall like 1/k^2: 6 terms for fp32, no cancellation);
 //   otherwise rho ln(rho) - s directly (rho = 0, a zero data entry: 0 * ln(tiny) - (-1) = 1, the term is p as in the reference).
 // 1/p is the reciprocal the fused KL update needs anyway (R = x/p): one transcendental and three FMAs per entry less than
 // the form on 1/x (x h((p-x)/x)) -- the divergence rides on the same fp32 pipe as the MFMAs of nnf_mu_left_kl_cost_f32.
 __device__ __forceinline__ float nnf_kl_term(float x, float p) {
     const float rp = __builtin_amdgcn_rcpf(p);
     const float rho = x * rp, s = (x - p) * rp;
-    float a = -1.f / 110.f;                       // k = 9
-    a = fmaf(a, s, 1.f / 90.f);
-    a = fmaf(a, s, -1.f / 72.f);
-    a = fmaf(a, s, 1.f / 56.f);
-    a = fmaf(a, s, -1.f / 42.f);
-    a = fmaf(a, s, 1.f / 30.f);
-    a = fmaf(a, s, -1.f / 20.f);
-    a = fmaf(a, s, 1.f / 12.f);
-    a = fmaf(a, s, -1.f / 6.f);
-    a = fmaf(a, s, 0.5f);
+    // |s| < 1/8: six terms reach fp32 (term k = s^k 2/((k+1)(k+2)) relative to the first: 1.4e-7 at k = 6) -- the divergence
+    // rides on the same fp32 pipe as the MFMAs of nnf_mu_left_kl_cost_f32, every instruction per entry is 4.5 us at config C;
+    // beyond it rho ln(rho) - s has lost at most four of its 24 bits to cancellation (|s| >= 1/8: the two terms are >= 0.1,
+    // their difference >= s^2/2 (1 - |s|/3) >= 7e-3).
+    float a = 1.f / 42.f;                         // k = 5
+    a = fmaf(a, s, -1.f / 30.f);
+    a = fmaf(a, s, 1.f / 20.f);
+    a = fmaf(a, s, -1.f / 12.f);
+    a = fmaf(a, s, 1.f / 6.f);
+    a = fmaf(a, -s, 0.5f);
     const float series = s * s * a;
     const float direct = fmaf(rho * 0.69314718056f, __builtin_amdgcn_logf(fmaxf(rho, 1e-37f)), -s);
-    return p * (fabsf(s) < 0.25f ? series : direct);
+    return p * (fabsf(s) < 0.125f ? series : direct);
 }
 
 template <int OP>

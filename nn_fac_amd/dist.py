@@ -242,13 +242,16 @@ def sharded_hals_solve(eng, cross, gram, F, group, guess, budget=100, delta=0.01
     return eps, done + 1, eps0
 
 
-def sharded_hals_solve_rownorm(eng, cross, gram, F, group, budget=100, delta=0.01, sparsity=None):
-    """hals_nnls_acc(..., normalize=True) on the local columns F (r x m_local) of a factor whose columns are spread over the
-    ranks: the row norm of nnls.py:179-185 runs over ALL columns, once per row update, so the rows are walked from the host --
-    row update on the local columns (Engine.hals_row_update), ONE all-reduce of {sum of squared steps, sum of squares of the
-    row}, scaling (Engine.hals_row_scale) -- and the stopping rule of nnls.py:156 is applied once per sweep.  r collectives
-    per sweep: correct and slow; the option is not on any BASELINE configuration.  Returns (eps, cnt, eps0) like
-    sharded_hals_solve."""
+def sharded_hals_solve_rownorm(eng, cross, gram, F, group, budget=100, delta=0.01, sparsity=None, normalize=True, nonzero=False):
+    """hals_nnls_acc(..., normalize=True and / or nonzero=True) on the local columns F (r x m_local) of a factor whose columns
+    are spread over the ranks -- or are more than the generic kernel keeps resident on one device: the row norm of
+    nnls.py:179-185 and the all-zero test / max(V) of nnls.py:172-177 run over ALL columns, once per row update, so the rows
+    are walked from the host -- row update on the local columns (Engine.hals_row_update), ONE all-reduce of {sum of squared
+    steps, sum of squares of the row}, then the non-zero guard (a row left all zero is refilled with 1e-16 max(V), the maximum
+    all-reduced; a zero Gram diagonal raises ZeroColumnWhenUnautorized, nnls.py:176-177) and the scaling
+    (Engine.hals_row_scale) -- and the stopping rule of nnls.py:156 is applied once per sweep.  r collectives per sweep:
+    correct and slow; the options are on no BASELINE configuration.  Returns (eps, cnt, eps0) like sharded_hals_solve."""
+    from .utils import errors as err
     r = int(F.shape[0])
     ncols_total = torch.tensor([int(F.shape[1])], dtype=torch.int64, device=F.device)
     if group is not None and dist.get_world_size(group) > 1:
@@ -256,12 +259,23 @@ def sharded_hals_solve_rownorm(eng, cross, gram, F, group, budget=100, delta=0.0
     ncols_total = int(ncols_total.item())
     eps0, eps, done = 0.0, 1.0, 0
     acc = torch.zeros(1, dtype=torch.float64, device=F.device)
+    diag = torch.diagonal(gram)[:r].cpu() if nonzero else None      # (replicated: the same on every rank)
     while done < budget:
         acc.zero_()
         for k in range(r):
             st = eng.hals_row_update(cross, gram, F, k, sparsity=sparsity)
             allreduce_(st, group)
-            eng.hals_row_scale(F, k, st[1:2], ncols_total)
+            if nonzero:
+                if float(diag[k]) == 0.0:
+                    raise err.ZeroColumnWhenUnautorized("Column " + str(k) + " of U is zero with nonzero condition")
+                if float(st[1].item()) == 0.0:                      # the updated row is all zero on every rank (nnls.py:173-174)
+                    vmax = F.max().reshape(1).double()
+                    allreduce_max_(vmax, group)
+                    fill = float(1e-16 * vmax.item())
+                    F[k].fill_(fill)
+                    st[1] = fill * fill * ncols_total
+            if normalize:
+                eng.hals_row_scale(F, k, st[1:2], ncols_total)
             acc.add_(st[0:1])
         eps = float(acc.item())                    # one host round trip per sweep (nnls.py:187-196)
         if done == 0:

@@ -199,14 +199,14 @@ class Engine:
     def _check_rowsync_columns(self, rowsync, ncols):
         """normalize=True / nonzero=True need a grid-wide reduction per ROW update, which the generic kernel does with every
         column resident (one per thread, 4 x 128-thread workgroups per CU): say so here instead of a bare status code.
-        (normalize alone goes on beyond that limit, row by row: _hals_solve_rowwalk; the nonzero guard does not.)"""
+        (persistent solves go on beyond that limit, row by row from the host: _hals_solve_rowwalk; fixed-count sweeps do not.)"""
         if rowsync and ncols > self.ROWSYNC_MAX_COLUMNS:
-            raise EngineError(f"hals_nnls_acc with nonzero=True (and fixed-count sweeps with normalize=True) is built for at most "
+            raise EngineError(f"fixed-count sweeps with normalize=True / nonzero=True are built for at most "
                               f"{self.ROWSYNC_MAX_COLUMNS} columns (got {ncols}): every row update needs all columns "
                               f"resident on the device at once; normalise the shorter factor, or split the columns and "
                               f"normalise on the host between outer iterations")
 
-    def _hals_solve_rowwalk(self, UtM, UtU, V, max_sweeps, delta, sparsity, st):
+    def _hals_solve_rowwalk(self, UtM, UtU, V, max_sweeps, delta, sparsity, st, normalize=True, nonzero=False):
         """hals_nnls_acc(..., normalize=True) on more columns than the generic kernel keeps resident: the rows are walked from
         the host -- row update over all columns (nnf_hals_row_update_f32), row norm, scaling (nnf_hals_row_scale_f32), r x 2
         launches per sweep and one host round trip per sweep for the stopping rule of nnls.py:156 -- the one-device form of the
@@ -214,7 +214,7 @@ class Engine:
         rank-50 factor is 100 launches): the option is on no BASELINE configuration."""
         from . import dist as _dist
         eps, cnt, eps0 = _dist.sharded_hals_solve_rownorm(self, UtM, UtU, V, None, budget=int(max_sweeps), delta=float(delta),
-                                                          sparsity=sparsity)
+                                                          sparsity=sparsity, normalize=normalize, nonzero=nonzero)
         st[:4] = torch.tensor([eps, float(cnt), eps0, 0.0], dtype=torch.float64)
         return st
 
@@ -229,8 +229,8 @@ class Engine:
             raise EngineError("hals_solve: shape mismatch")
         st = status if status is not None else torch.empty(ST_WORDS, dtype=torch.float64, device=V.device)
         flags = self._hals_flags(sparsity, normalize, nonzero)
-        if normalize and not nonzero and ncols > self.ROWSYNC_MAX_COLUMNS and int(max_sweeps) > 0:
-            return self._hals_solve_rowwalk(UtM, UtU, V, max_sweeps, delta, sparsity, st)
+        if (normalize or nonzero) and ncols > self.ROWSYNC_MAX_COLUMNS and int(max_sweeps) > 0:
+            return self._hals_solve_rowwalk(UtM, UtU, V, max_sweeps, delta, sparsity, st, normalize=normalize, nonzero=nonzero)
         self._check_rowsync_columns(normalize or nonzero, ncols)
         total, first = int(max_sweeps), min(int(max_sweeps), self.HALS_MAX_SWEEPS_PER_LAUNCH)
         _lib.check(self.lib.nnf_hals_solve_f32(self.ctx, _ptr(UtM), _ld(UtM), _ptr(UtU), _ld(UtU), _ptr(V),
@@ -276,6 +276,13 @@ class Engine:
         chunks of a solve are bit for bit one launch of all its sweeps."""
         _chk2d(UtM, "hals UtM"), _chk2d(UtU, "hals UtU"), _chk2d(V, "hals V")
         r, ncols = V.shape
+        if (normalize or nonzero) and ncols > self.ROWSYNC_MAX_COLUMNS and snapshots is None and int(nsweeps) > 0:
+            # more columns than the generic kernel keeps resident: the rows are walked from the host, one sweep per call of the
+            # row-walk (the wall-clock rule's one-sweep probe of nmf() / hals_nnls_acc(deterministic=False) lands here)
+            from . import dist as _dist
+            vals = [_dist.sharded_hals_solve_rownorm(self, UtM, UtU, V, None, budget=1, delta=0.0, sparsity=sparsity,
+                                                     normalize=normalize, nonzero=nonzero)[0] for _ in range(int(nsweeps))]
+            return torch.tensor(vals, dtype=torch.float64, device=V.device)
         self._check_rowsync_columns(normalize or nonzero, ncols)
         nd = torch.zeros(max(int(nsweeps), 1), dtype=torch.float64, device=V.device)
         sp, ss = C.c_void_p(0), 0

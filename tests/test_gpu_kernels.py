@@ -707,10 +707,12 @@ def test_c_abi_rccl_communicator_single_rank(built_lib):
 def test_hals_normalize_beyond_the_resident_column_limit(built_lib):
     """normalize=True needs the norm of a whole row after every row update (nnls.py:179-185); the generic kernel does that with
     every column resident (<= 131072).  Beyond, the rows are walked from the host (Engine._hals_solve_rowwalk: row update, norm,
-    scaling -- the one-device form of the row-sharded protocol): same result, same sweep count as the oracle; nonzero=True,
-    which has no row-walked form, says so."""
+    scaling -- the one-device form of the row-sharded protocol): same result, same sweep count as the oracle.  nonzero=True
+    (nnls.py:172-177: a row left all zero is refilled with 1e-16 max(V); a zero Gram diagonal raises) walks the rows the same
+    way since round 4, alone and together with normalize, and so does the wall-clock rule's one-sweep probe
+    (deterministic=False)."""
     from nn_fac_amd.update_rules.nnls import hals_nnls_acc
-    from nn_fac_amd.engine import EngineError
+    from nn_fac_amd.utils import errors as err
     rng = np.random.RandomState(17)
     r, n = 5, 140001
     A = rng.rand(40, r)
@@ -725,6 +727,20 @@ def test_hals_normalize_beyond_the_resident_column_limit(built_lib):
         assert cnt == cnto
         assert rel(V, Vo) < 2e-4 and abs(eps - epso) <= 5e-3 * abs(epso)
         np.testing.assert_allclose(np.linalg.norm(np.asarray(V, dtype=np.float64), axis=1), 1.0, rtol=1e-5)
-    with pytest.raises(EngineError):
-        hals_nnls_acc(UtM.astype(np.float32), UtU.astype(np.float32), V0.astype(np.float32), maxiter=3, alpha=math.inf,
-                      nonzero=True)
+    # nonzero=True: row 2's right-hand side is pushed far below zero, so its update leaves the row all zero -> refilled
+    UtM2 = UtM.copy()
+    UtM2[2] = -5.0 - rng.rand(n)
+    for nrm in (False, True):
+        Vo, epso, cnto, _ = orc.hals_nnls_acc(UtM2, UtU, V0, maxiter=4, alpha=math.inf, delta=0.01, normalize=nrm, nonzero=True)
+        V, eps, cnt, _ = hals_nnls_acc(UtM2.astype(np.float32), UtU.astype(np.float32), V0.astype(np.float32), maxiter=4,
+                                       alpha=math.inf, delta=0.01, normalize=nrm, nonzero=True)
+        assert cnt == cnto and rel(V, Vo) < 2e-4 and abs(eps - epso) <= 5e-3 * abs(epso)
+        assert np.all(np.asarray(V)[2] > 0)
+    G0 = UtU.copy()
+    G0[3, 3] = 0.0
+    with pytest.raises(err.ZeroColumnWhenUnautorized):
+        hals_nnls_acc(UtM.astype(np.float32), G0.astype(np.float32), V0.astype(np.float32), maxiter=3, alpha=math.inf, nonzero=True)
+    # the reference's default call (deterministic=False): its one-sweep timing probe runs through the row-walk too
+    V, eps, cnt, rho = hals_nnls_acc(UtM.astype(np.float32), UtU.astype(np.float32), V0.astype(np.float32), maxiter=3, atime=1e-3,
+                                     alpha=0.5, normalize=True)
+    assert 2 <= cnt <= 4

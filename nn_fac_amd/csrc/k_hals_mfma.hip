@@ -115,10 +115,10 @@ struct mfma_sweeper {
     uint64_t lbase;
     unsigned ta, tg, ts;   // this lane's LDS byte addresses in the wave's 2 KB transpose scratch (see below)
     f32x4 af[NBUF][RTQ];
-    LT lt[2];
-    f32x16 xt[2];
+    LT lt[1];          // ONE set each: refilled for the next block right behind the row updates that read it (a second set
+    f32x16 xt[1];      // overflows the scalar registers: 8 v_readlane reloads per k-block in the middle of the MFMA stream)
     f32x4 w, stp;          // the block's residuals / steps, lane = column
-    float d[4], dn[4];     // B operands of this block / of the next one
+    float d2[2][4];        // B operands of the k-blocks, by block parity (the scatter of block kb+1 lands while block kb's are in use)
     float nd;
 
     // Gather and scatter go THROUGH LDS, not through the VALU (tools/probes/permlane_rate.hip: fp32 MFMAs and VALU instructions
@@ -145,10 +145,10 @@ struct mfma_sweeper {
             w = f32x4{accx[0], accx[1], accx[2], accx[3]};
         }
     }
-    __device__ __forceinline__ void issue_scatter() {
+    __device__ __forceinline__ void issue_scatter(int kb) {   // kb: the block whose steps these are
         asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(ta), "v"(stp));
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dn[ct]) : "v"(ts), "i"(1024 + ct * 256));
+        for (int ct = 0; ct < 4; ++ct) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d2[kb & 1][ct]) : "v"(ts), "i"(1024 + ct * 256));
     }
     __device__ __forceinline__ void issue_af(int buf, int q, int kb) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[buf][q]) : "v"(img_addr), "i"((kb * RTQ + q) * 1024));
@@ -164,15 +164,18 @@ struct mfma_sweeper {
         f32x4& a1 = af[NBUF - 1][RTQ - 1];
         if constexpr (REM > 0)
             asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(a0), "+v"(a1), "+s"(lt[0]), "+s"(lt[1]), "+s"(xt[0]), "+s"(xt[1]), "+v"(w), "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]));
+                         : "+v"(a0), "+v"(a1), "+s"(lt[0]), "+s"(xt[0]), "+v"(w), "+v"(d2[0][0]), "+v"(d2[0][1]), "+v"(d2[0][2]), "+v"(d2[0][3]),
+                           "+v"(d2[1][0]), "+v"(d2[1][1]), "+v"(d2[1][2]), "+v"(d2[1][3]));
         else
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+s"(lt[0]), "+s"(lt[1]), "+v"(w), "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(a0), "+v"(a1), "+s"(lt[0]), "+v"(w), "+v"(d2[0][0]), "+v"(d2[0][1]), "+v"(d2[0][2]), "+v"(d2[0][3]), "+v"(d2[1][0]),
+                           "+v"(d2[1][1]), "+v"(d2[1][2]), "+v"(d2[1][3]));
     }
 
     // The VALU work of k-block kb on its residuals w: the four row updates of nnls.py:162-170 in order, the bookkeeping, the
     // leftover rows' push.  Leaves the steps in stp.  l[0..5] = -G'[k0+i][k0+j], j < i.
     __device__ __forceinline__ void update(int kb) {
-        const int lb = kb & 1;
+        const int lb = 0;
         const LT l = lt[lb];
         float s0, s1, s2, s3;
         asm("v_max_f32 %0, %1, -%2" : "=v"(s0) : "v"(w[0]), "v"(v[4 * kb]));
@@ -234,9 +237,7 @@ struct mfma_sweeper {
     __device__ __forceinline__ void blocks(int first, int last) {
 #pragma unroll
         for (int kb = first; kb < last; ++kb) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d[i] = dn[i];
-            asm volatile("s_nop 1" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+            float (&d)[4] = d2[kb & 1];
             const int cb = NBUF == 2 ? (kb & 1) : 0;
             const bool more = kb + 1 < NKB;
             const int nfirst = 4 * piece_tiles(first_piece(kb));   // MFMAs on the first piece
@@ -251,7 +252,8 @@ struct mfma_sweeper {
                     wait_all();
                     if (!(MFMA_DBG & 4)) update(kb + 1);
                     else stp = w;
-                    issue_scatter();
+                    issue_scatter(kb + 1);
+                    if (kb + 2 < NKB) issue_lt(0, kb + 2);   // (its registers have just been read for the last time)
                 }
                 if (NBUF == 1 && m == nfirst - 1 && m != NM - 1) {   // the first piece is released: refill it for the next block
                     if (m < MU) wait_all();   // (else the wait above has already passed)
@@ -265,21 +267,19 @@ struct mfma_sweeper {
                 if (nfirst == NM) issue_af(0, first_piece(kb), kb + 1);   // (one piece only)
                 else issue_af(0, 1 - first_piece(kb), kb + 1);
             }
-            if (kb + 3 < NKB) issue_lt((kb + 1) & 1, kb + 3);
         }
     }
     __device__ __forceinline__ void head() {
         nd = 0.f;
         issue_lt(0, 0);
-        if (NKB > 1) issue_lt(1, 1);
 #pragma unroll
         for (int q = 0; q < RTQ; ++q) issue_af(0, q, 0);
         if (NBUF == 2 && NKB > 1) issue_af(1, 0, 1);
         issue_gather(0);
         wait_all();
         update(0);
-        issue_scatter();
-        if (NKB > 2) issue_lt(0, 2);
+        issue_scatter(0);
+        if (NKB > 1) issue_lt(0, 1);
         wait_all();
         blocks(0, SPB);
         wait_all();

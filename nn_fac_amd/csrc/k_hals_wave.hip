@@ -46,13 +46,16 @@ constexpr int WAVE_COMM = 4;         // communication waves per workgroup
 constexpr int WAVE_MAX_NW = 16 - WAVE_COMM;   // compute waves (= columns) per workgroup (1024 threads in all)
 constexpr int WAVE_SNAP = 16;        // snapshot / slot / verdict rings (sweeps a compute wave may run ahead of the verdicts, + 1)
 constexpr int WAVE_NP = 6;           // granule pairs per lane of a communication wave: nblocks <= 384
-constexpr int WAVE_REFRESH = 8;      // the residual is re-formed from scratch (b' - G'v) every so many sweeps
+#ifndef WAVE_REFRESH_V
+#define WAVE_REFRESH_V 8             // (A/B builds: 4, 2 -- tools/probes/wave_refresh_probe.sh; accuracy / time table in DESIGN.md section 4)
+#endif
+constexpr int WAVE_REFRESH = WAVE_REFRESH_V;   // the residual is re-formed from scratch (b' - G'v) every so many sweeps (a power of two)
 constexpr unsigned WAVE_ERR = 0xffffffffu;
 
 #ifndef WAVE_DBG
 #define WAVE_DBG 0      // timing-only ablations (tools/probes/vside_probe.py): 1 = verdicts without totals (run to the budget), 4 = no row updates
 #endif
-NNF_BUILD_FLAGS(k_hals_wave, "WAVE_DBG=" NNF_STR(WAVE_DBG))
+NNF_BUILD_FLAGS(k_hals_wave, "WAVE_DBG=" NNF_STR(WAVE_DBG) " WAVE_REFRESH_V=" NNF_STR(WAVE_REFRESH_V))
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float wave_dpp_add_f32(float v) {

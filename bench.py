@@ -814,6 +814,24 @@ def main():
         except Exception as exc:      # an extra: it must never cost the line of the configuration that was asked for
             # (deterministic failures -- an unsupported shape, an allocation -- hit every rank at the same call)
             extra = {"E": {"workload": ewhat, "error": f"{type(exc).__name__}: {exc}"[:300]}}
+        # what ONE rank of the 8-GPU run of configs[4] computes per iteration: a 125000 x 4000 rank-100 row block (the same
+        # generator, block 0), here WITHOUT the sharded protocol's exchanges (a one-GPU box has no peer): the compute side of the
+        # per-rank step, measured instead of estimated; profiles/r04_E_block_* holds the same block under the forced sharded
+        # protocol on a 1-rank RCCL group with its kernel breakdown
+        try:
+            if world != 1:
+                raise RuntimeError("measured on one rank only")
+            if cx.cuda:
+                cx.torch.cuda.empty_cache()
+            bcfg = dict(CONFIGS["E"], m=CONFIGS["E"]["m"] // E_BLOCKS)
+            b = bench_nmf(cx, args, bcfg, 10, 3, False, False, False)
+            extra["E_rank_block_of_8"] = {
+                "workload": f"NMF hals {bcfg['m']}x{bcfg['n']} rank {bcfg['r']}: one rank's row block of configs[4] at 8 GPUs, "
+                            f"unsharded loop (no collectives), 10 steps after 3 warm-up",
+                "iterations_per_s": b["value"], "ms_per_step": b["ms_per_step"], "steps": 10, "warmup": 3,
+                "inner_sweeps_per_step_last": b["inner_sweeps_per_step_last"], "final_cost": b["final_cost"]}
+        except Exception as exc:
+            extra["E_rank_block_of_8"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         # configs[2] and configs[3], short legs on the same box in the same run: rate, the dominant kernel's roofline (launches
         # inside the leg's timed loop) and a one-iteration CPU baseline
         for name in ("C", "D"):

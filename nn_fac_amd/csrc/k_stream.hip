@@ -288,6 +288,12 @@ static int launch_xty(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t 
     int64_t target = (MT + (REM > 0) <= 4 ? 3 : 1) * (int64_t)ctx->num_cus / ncb;   // resident workgroups per CU
     if (target < 1) target = 1;
     int64_t nsplit = target;
+    // a workgroup sums its rows in fp32 (MFMA accumulators); the slabs are added in fp64.  Cap the rows per workgroup: at
+    // 1e6 x 4000 rank 100 the plan above is 16 splits of 62500 rows, and an entry of U^T X came out with 9.5e-7 relative rms
+    // and a -2.2e-7 MEAN error (tools/probes/accum_error_probe.py) -- enough to take the Gram-identity cost of a HALS iteration
+    // (which multiplies the mean by ||X||^2) to its 5e-4 bound.  8192 rows: the slabs of the extra splits are ~1 % of the pass.
+    const int64_t ROWS_CAP = 8192;
+    if (nsplit < nnf_cdiv(m, ROWS_CAP)) nsplit = nnf_cdiv(m, ROWS_CAP);
     const int64_t max_split = nnf_cdiv(m, 64);
     if (nsplit > max_split) nsplit = max_split;
     // workspace bound

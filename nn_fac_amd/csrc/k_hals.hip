@@ -236,7 +236,8 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
     const bool want_mfma = !generic && nsweeps > 0 && hals_mfma_default(RP, ncols);
     const bool wave = !generic && MODE == 0 && sweep0 == 0 && !force_lane && !force_quad && !(force_mfma && want_mfma) && nsweeps <= NNF_HALS_MAX_SWEEPS &&
                       nnf_hals_wave_fits(ctx, r, ncols, max_blocks);
-    (void)force_wave;
+    // NNF_HALS_FORCE=wave: a solve this layout could take but does not fit is refused instead of moving to another layout
+    if (force_wave && !generic && MODE == 0 && sweep0 == 0 && nsweeps <= NNF_HALS_MAX_SWEEPS && !wave) return NNF_ERR_UNSUPPORTED;
     const bool quad = !wave && !generic && !force_lane && !(force_mfma && want_mfma) && (ncols <= 32768 || force_quad) && (int64_t)(r + 16) * (ldv > ldm ? ldv : ldm) * 4 < (int64_t)0x7fff0000 &&
                       nnf_hals_quad_fits(ctx, r, ncols, max_blocks);
     if (getenv("NNF_HALS_DEBUG"))

@@ -446,6 +446,10 @@ __global__ __launch_bounds__(1024) void nnf_hals_wave_kernel(hals_args a, int64_
     if (stop == 0u && S >= 1) wait_verdicts(S);           // the budget ran out: every sweep must be judged
     const unsigned last = stop != 0u ? stop : (unsigned)S;    // the sweep whose column is the result
     if (w == 0 && lane == 0) wave_st(&ctl->fin, (1ull << 32) | (unsigned long long)last);     // (communication waves may leave)
+    // A time-out seen by ANY compute wave is left in the call's workspace word, tagged with the call's epoch: workgroup 0 may
+    // still find every granule later (it needs the same late granule, so it ends after this store) and folds the word in.
+    const unsigned err_tag = 0xE0000000u | a.sy.epoch;
+    if (last == WAVE_ERR && lane == 0) __hip_atomic_store(a.sy.counter, err_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (S >= 1) {
         if (last != WAVE_ERR && (int)last != ran) __builtin_amdgcn_s_waitcnt(0);   // (own snapshot stores have landed before they are read back)
 #pragma unroll
@@ -476,7 +480,8 @@ __global__ __launch_bounds__(1024) void nnf_hals_wave_kernel(hals_args a, int64_
             a.status[NNF_HALS_ST_CNT] = (double)(last + 1u);
             a.status[NNF_HALS_ST_EPS0] = eps0;
         }
-        if (last == WAVE_ERR) a.status[NNF_HALS_ST_ERR] = 1.0;
+        if (last == WAVE_ERR || __hip_atomic_load(a.sy.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == err_tag)
+            a.status[NNF_HALS_ST_ERR] = 1.0;
     }
 }
 
@@ -503,10 +508,14 @@ static int wave_launch(const hals_args& a, int64_t ldg, float* snap, int nblocks
         attr = true;
     }
     if (occupancy) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_wave_kernel<RL, RU, CPW>, 64 * (nw + WAVE_COMM), lds) != hipSuccess)
-            nb = 0;
-        *occupancy = nb;
+        static int cached[WAVE_MAX_NW + 1];               // per (RL, RU, CPW) instance and nw: resident workgroups per CU + 1 (0 = not asked yet)
+        if (cached[nw] == 0) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_wave_kernel<RL, RU, CPW>, 64 * (nw + WAVE_COMM), lds) != hipSuccess)
+                nb = 0;
+            cached[nw] = nb + 1;
+        }
+        *occupancy = cached[nw] - 1;
         return NNF_OK;
     }
     hipLaunchKernelGGL((nnf_hals_wave_kernel<RL, RU, CPW>), dim3(nblocks), dim3(64 * (nw + WAVE_COMM)), lds, st, a, ldg, snap);

@@ -277,6 +277,20 @@ def test_hals_zero_diagonal_row_is_left_alone(eng, layout, r, monkeypatch):
     assert int(st[1]) == cnto and rel(got, Vo) < 2e-4
 
 
+def test_hals_forced_wave_layout_is_refused_where_it_does_not_fit(eng, monkeypatch):
+    """NNF_HALS_FORCE=wave pins the wave-per-column kernel: a solve it cannot hold resident is refused, not moved to another
+    layout (so the layout tests above are known to have run the kernel they name)."""
+    from nn_fac_amd.engine import EngineError
+    monkeypatch.setenv("NNF_HALS_FORCE", "wave")
+    rng = np.random.RandomState(2)
+    A = rng.rand(200, 50)
+    UtU, UtM, V = dev(A.T @ A), dev(A.T @ rng.rand(200, 60000)), dev(rng.rand(50, 60000))
+    with pytest.raises(EngineError):
+        eng.hals_solve(UtM, UtU, V, 10, delta=0.01)
+    monkeypatch.delenv("NNF_HALS_FORCE")
+    assert int(eng.hals_solve(UtM, UtU, V, 10, delta=0.01).cpu()[3]) == 0
+
+
 def test_hals_does_not_modify_inputs(eng):
     from nn_fac_amd.update_rules.nnls import hals_nnls_acc
     r = np.random.RandomState(1)
@@ -296,7 +310,7 @@ def test_hals_does_not_modify_inputs(eng):
                                             (50, 100000, "mfma"), (48, 20000, "mfma"), (100, 3000, "mfma"), (77, 40000, "auto"), (93, 33000, "auto")])
 def test_hals_large_vs_oracle(eng, r, ncols, layout, monkeypatch):
     """Resident and strided (ncols > resident threads) persistent solves vs the fp64 oracle; sweep counts equal."""
-    if layout not in ("auto", "wave"):
+    if layout != "auto":
         monkeypatch.setenv("NNF_HALS_FORCE", layout)
     else:
         monkeypatch.delenv("NNF_HALS_FORCE", raising=False)

@@ -692,6 +692,83 @@ static int launch_gram(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, 
     return nnf_launch_reduce_slabs(slabs, (int)nsplit, (int64_t)r * r, r, r, r, G, ldg, st);
 }
 
+// Ranks above NNF_MAX_RANK: the Gram in 64 x 64 blocks.  Workgroup (split ks, block pair (bi, bj)) multiplies the k range of
+// its split of row block bi by the same range of row block bj -- two LDS images instead of one, otherwise the kernel above.
+// Block (bj, bi) is computed by its own workgroup from the same products in the same order, so the result is symmetric bit
+// for bit, as the single-image kernel's is.  Slabs [split][r x r], reduced in split order by the usual launch.
+__global__ __launch_bounds__(256) void nnf_gram_blocks_kernel(const float* __restrict__ A, int r, int64_t K, int64_t lda,
+                                                              float* __restrict__ slabs, int64_t k_per_split, int a_vec_ok, int nb) {
+    constexpr int MT = 4;
+    __shared__ f32x4 ldsA[2][MT * 256], ldsB[2][MT * 256];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jj = lane & 15, g = lane >> 4;
+    const int bi = (int)blockIdx.y / nb, bj = (int)blockIdx.y - bi * nb;
+    const float* Ai = A + (int64_t)64 * bi * lda;
+    const float* Bj = A + (int64_t)64 * bj * lda;
+    const int ri = r - 64 * bi < 64 ? r - 64 * bi : 64, rj = r - 64 * bj < 64 ? r - 64 * bj : 64;
+    const int64_t k_begin = (int64_t)blockIdx.x * k_per_split;
+    const int64_t k_end = (k_begin + k_per_split < K) ? (k_begin + k_per_split) : K;
+    const int nchunk = (int)((k_end - k_begin + 63) >> 6);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 areg[MT], breg[MT];
+    stageA_load<MT>(Ai, lda, ri, k_end, k_begin, a_vec_ok, areg);
+    stageA_load<MT>(Bj, lda, rj, k_end, k_begin, a_vec_ok, breg);
+    stageA_store<MT>(ldsA[0], areg);
+    stageA_store<MT>(ldsB[0], breg);
+    __syncthreads();
+    for (int q = 0; q < nchunk; ++q) {
+        const f32x4* imgA = ldsA[q & 1];
+        const f32x4* imgB = ldsB[q & 1];
+        stageA_load<MT>(Ai, lda, ri, k_end, k_begin + 64 * (int64_t)(q + 1), a_vec_ok, areg);
+        stageA_load<MT>(Bj, lda, rj, k_end, k_begin + 64 * (int64_t)(q + 1), a_vec_ok, breg);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 af = imgA[(w * 4 + t) * 64 + lane];       // wave w owns tile row w of the block
+            f32x4 bf[MT];
+#pragma unroll
+            for (int b = 0; b < MT; ++b) bf[b] = imgB[(b * 4 + t) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int b = 0; b < MT; ++b) acc[b] = MFMA16(af[c], bf[b][c], acc[b]);
+        }
+        stageA_store<MT>(const_cast<f32x4*>(ldsA[(q + 1) & 1]), areg);
+        stageA_store<MT>(const_cast<f32x4*>(ldsB[(q + 1) & 1]), breg);
+        __syncthreads();
+    }
+    float* sl = slabs + (int64_t)blockIdx.x * r * r;
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 64 * bi + 16 * w + 4 * g + reg, col = 64 * bj + 16 * b + jj;
+            if (row < r && col < r) sl[(int64_t)row * r + col] = acc[b][reg];
+        }
+}
+
+static int launch_gram_blocks(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
+                              hipStream_t st) {
+    const int nb = (r + 63) / 64;
+    // splits: about two workgroups per CU over all block pairs, 64-column chunks, as many slabs as the workspace holds
+    int64_t nsplit = nnf_cdiv((int64_t)2 * ctx->num_cus, (int64_t)nb * nb);
+    const int64_t max_split = nnf_cdiv(K, 64);
+    if (nsplit > max_split) nsplit = max_split;
+    const int64_t ws_max = (int64_t)(cur.remaining() / 4) / ((int64_t)r * r);
+    if (ws_max < 1) return NNF_ERR_WORKSPACE;
+    if (nsplit > ws_max) nsplit = ws_max;
+    if (nsplit < 1) nsplit = 1;
+    const int64_t kps = nnf_rup(nnf_cdiv(K, nsplit), 64);
+    nsplit = nnf_cdiv(K, kps);
+    const int a_vec_ok = ((((uintptr_t)A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
+    float* slabs = (float*)cur.take((size_t)nsplit * r * r * 4);
+    if (!slabs) return NNF_ERR_WORKSPACE;
+    hipLaunchKernelGGL(nnf_gram_blocks_kernel, dim3((int)nsplit, nb * nb), dim3(256), 0, st, A, r, K, lda, slabs, kps, a_vec_ok, nb);
+    NNF_CHECK_LAUNCH();
+    return nnf_launch_reduce_slabs(slabs, (int)nsplit, (int64_t)r * r, r, r, r, G, ldg, st);
+}
+
 // =========================================================================================================
 // frob: sum_ij (X[i][j] - sum_k Ut[k][i] V[k][j])^2
 //   workgroup = 128 rows (wave w: rows 32w..32w+31 as two 16-row M tiles), sweeping all columns in 64-wide blocks.
@@ -738,14 +815,17 @@ __global__ __launch_bounds__(256) void nnf_cost_prepv_kernel(const float* __rest
     }
 }
 
-template <int OP, bool VEC, int NV>   // NV = float4 pieces of a V image per thread: 4 up to r = 64, 8 up to r = 128
-__global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+// PIN (ranks above 128, walked in chunks of <= 128): the model of the EARLIER rank chunks, m x n with row stride ldr in Pin, is
+// added to this chunk's product before the element-wise part -- read one block ahead like X (Pin may be R1: a lane reads its
+// own elements of a block before it writes them).
+template <int OP, bool VEC, int NV, bool PIN = false>   // NV = float4 pieces of a V image per thread: 4 up to r = 64, 8 up to r = 128
+__global__ __launch_bounds__(256, PIN ? 2 : 3) void nnf_cost_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                           const float* __restrict__ Ut, int64_t ldu,
                                                           const f32x4* __restrict__ Vf, int r,
                                                           float beta, double* __restrict__ partial,
                                                           const float* __restrict__ Ub, int64_t ldub, int64_t nbu,
                                                           float* __restrict__ R1, float* __restrict__ R2, int64_t ldr,
-                                                          int u_vec_ok, int vdb) {
+                                                          int u_vec_ok, int vdb, const float* Pin = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KS = (r + 3) >> 2;                               // k-steps of 4
     float* ldsU = reinterpret_cast<float*>(smem);              // [wave 4][rt 2][KS][64]
@@ -872,12 +952,27 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
     // kernel with.)  The block past the workgroup's column range is "read" through an out-of-range offset: zeros, no
     // memory traffic (the prefetch used to fetch the next rows' data: 1.24 GB instead of 0.82 GB per launch).
     f32x4 xb[2][4];  // [rt][reg]: row i0w + 16rt + 4g + reg, columns j0+4jj..+3
+    f32x4 pb[PIN ? 2 : 1][PIN ? 4 : 1];   // the same elements of Pin
+    rsrc_t rsp = rs;
+    int ldp4 = 0, voffp = 0;
+    if constexpr (PIN) {
+        rsp = nnf_make_rsrc(Pin + (rows > 0 ? i0w : 0) * ldr, rows > 0 ? (uint32_t)(((rows - 1) * ldr + n) * 4) : 0u);
+        ldp4 = (int)(ldr * 4);
+        voffp = (int)(((int64_t)4 * g * ldr + 4 * jj) * 4);
+    }
     auto xload = [&](int blk) {
         const int vo = (blk < nblk) ? voff : (int)0x7ffffff0;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) xb[rt][reg] = nnf_bload4<VEC>(rs, vo, (16 * rt + reg) * ldx4 + 256 * blk);
+        if constexpr (PIN) {
+            const int vp = (blk < nblk) ? voffp : (int)0x7ffffff0;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) pb[rt][reg] = nnf_bload4<VEC>(rsp, vp, (16 * rt + reg) * ldp4 + 256 * blk);
+        }
     };
     xload(blk0);
     __syncthreads();
@@ -943,7 +1038,15 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
         // residual of this 32 x 64 block; columns past n hold the next row's data -> masked out
         const int64_t jrem = n - (64 * (int64_t)blk + 4 * jj);
         float loc = 0.f;
-        if constexpr (OP == NNF_RATIO_KL || OP == NNF_RATIO_GEN) {
+        if constexpr (PIN) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) acc[rt][cc][reg] += pb[rt][reg][cc];
+        }
+        if constexpr (OP == NNF_RATIO_KL || OP == NNF_RATIO_GEN || OP == NNF_PROD) {
             // large-rank MU (r > 64): the element-wise operands are written out, the two contractions follow as plain
             // X H^T / W^T X launches on them (k_mu.hip).  One float4 per (row piece): columns j0+4jj .. +3.
 #pragma unroll
@@ -956,7 +1059,10 @@ __global__ __launch_bounds__(256, 3) void nnf_cost_kernel(const float* __restric
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {
                         const float p = acc[rt][cc][reg], x = xb[rt][reg][cc];
-                        if constexpr (OP == NNF_RATIO_KL) {
+                        if constexpr (OP == NNF_PROD) {
+                            o1[cc] = p;
+                            o2[cc] = 0.f;
+                        } else if constexpr (OP == NNF_RATIO_KL) {
                             o1[cc] = x * __builtin_amdgcn_rcpf(p);
                             o2[cc] = 0.f;
                         } else {
@@ -1048,7 +1154,18 @@ static inline void split_rank(int r, int& MT, int& REM) {
 int nnf_xty_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
                  int r, int64_t ldu, float* out, int64_t ldo, hipStream_t st) {
     if (!ctx || !X || !Ut || !out || m < 1 || n < 1 || r < 1 || ldx < n || ldu < m || ldo < n) return NNF_ERR_ARG;
-    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    if (r > NNF_MAX_RANK) {
+        // ranks above 128: passes of <= 128 rank rows (the rows of the result are independent of each other); every pass takes
+        // the workspace of the one before it (same stream)
+        for (int k0 = 0; k0 < r; k0 += NNF_MAX_RANK) {
+            const size_t mark = cur.off;
+            const int rc = nnf_xty_impl(ctx, cur, X, m, n, ldx, Ut + (int64_t)k0 * ldu, r - k0 < NNF_MAX_RANK ? r - k0 : NNF_MAX_RANK,
+                                        ldu, out + (int64_t)k0 * ldo, ldo, st);
+            cur.off = mark;
+            if (rc != NNF_OK) return rc;
+        }
+        return NNF_OK;
+    }
     int MT, REM;
     split_rank(r, MT, REM);
     if (!x_vec_ok(X, ldx)) {
@@ -1074,7 +1191,16 @@ int nnf_xht_lds_launch(nnf_ctx* ctx, int MT, int REM, const float* X, int64_t m,
 int nnf_xht_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V,
                  int r, int64_t ldv, float* out, int64_t ldo, hipStream_t st) {
     if (!ctx || !X || !V || !out || m < 1 || n < 1 || r < 1 || ldx < n || ldv < n || ldo < m) return NNF_ERR_ARG;
-    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    if (r > NNF_MAX_RANK) {   // passes of <= 128 rank rows, as in nnf_xty_impl
+        for (int k0 = 0; k0 < r; k0 += NNF_MAX_RANK) {
+            const size_t mark = cur.off;
+            const int rc = nnf_xht_impl(ctx, cur, X, m, n, ldx, V + (int64_t)k0 * ldv, r - k0 < NNF_MAX_RANK ? r - k0 : NNF_MAX_RANK,
+                                        ldv, out + (int64_t)k0 * ldo, ldo, st);
+            cur.off = mark;
+            if (rc != NNF_OK) return rc;
+        }
+        return NNF_OK;
+    }
     int MT, REM;
     split_rank(r, MT, REM);
     // ranks 51, 52: three tiles + four leftover ranks next to the 4-row-tile body do not fit 256 registers (84 bytes of scratch,
@@ -1105,7 +1231,7 @@ extern "C" int nnf_xht_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, i
 int nnf_gram_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
                   hipStream_t st) {
     if (!ctx || !A || !G || r < 1 || K < 1 || lda < K || ldg < r) return NNF_ERR_ARG;
-    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    if (r > NNF_MAX_RANK) return launch_gram_blocks(ctx, cur, A, r, K, lda, G, ldg, st);
     switch ((r + 15) / 16) {
         case 1: return launch_gram<1>(ctx, cur, A, r, K, lda, G, ldg, st);
         case 2: return launch_gram<2>(ctx, cur, A, r, K, lda, G, ldg, st);
@@ -1128,7 +1254,8 @@ template <int OP>
 static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
                        const float* V, int64_t ldv, int r, float beta, double scale, double* out_f64, hipStream_t st,
                        const float* Vb = nullptr, int64_t ldvb = 0, int64_t nb = 1, const float* Ub = nullptr,
-                       int64_t ldub = 0, int64_t nbu = 1, float* R1 = nullptr, float* R2 = nullptr, int64_t ldr = 0) {
+                       int64_t ldub = 0, int64_t nbu = 1, float* R1 = nullptr, float* R2 = nullptr, int64_t ldr = 0,
+                       const float* Pin = nullptr, size_t ws_cap = 0) {
     const int grid = (int)nnf_cdiv(m, 128);
     // column splits: aim at ~8 workgroups per resident slot, keep at least 4 column blocks per workgroup
     const int nblk_all = (int)nnf_cdiv(n, 64);
@@ -1150,6 +1277,7 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
     }
     if (csplit < 1) csplit = 1;
     nnf_ws_cursor cur(ctx);
+    if (ws_cap) cur.cap = ws_cap;          // (the tail of the workspace holds the model of the earlier rank chunks)
     double* partial = (double*)cur.take((size_t)grid * csplit * 8);
     if (!partial) return NNF_ERR_WORKSPACE;
     const int KS = (r + 3) / 4;
@@ -1169,26 +1297,33 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
     auto wg_per_cu = [&](size_t b) { const size_t w = lds_cu / b; return w > 3 ? (size_t)3 : w; };   // (launch bound: 3)
     const int vdb = wg_per_cu(shm1) > wg_per_cu(shm2) ? 0 : 1;
     const size_t shm = vdb ? shm2 : shm1;
-#define NNF_COST_LAUNCH(VV, NN)                                                                                              \
+#define NNF_COST_LAUNCH(VV, NN, PP)                                                                                          \
     do {                                                                                                                     \
         if (shm > 48 * 1024)                                                                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_cost_kernel<OP, VV, NN>),                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_cost_kernel<OP, VV, NN, PP>),                       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                 \
-        hipLaunchKernelGGL((nnf_cost_kernel<OP, VV, NN>), dim3(grid, csplit), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, Vf, r, \
-                           beta, partial, Ub, ldub, nbu, R1, R2, ldr, u_vec_ok, vdb);                                        \
+        hipLaunchKernelGGL((nnf_cost_kernel<OP, VV, NN, PP>), dim3(grid, csplit), dim3(256), shm, st, X, m, n, ldx, Ut, ldu, Vf, r, \
+                           beta, partial, Ub, ldub, nbu, R1, R2, ldr, u_vec_ok, vdb, Pin);                                   \
     } while (0)
     nnf_probe(ctx, NNF_PROBE_COST, 0, st);
-    if (x_vec_ok(X, ldx)) {
-        if (KS <= 16) NNF_COST_LAUNCH(true, 4);
-        else NNF_COST_LAUNCH(true, 8);
+    if (Pin != nullptr) {           // a later rank chunk of a rank above 128 (launch_cost_chunked): one instance per load width
+        if (Ub != nullptr || ldr < n) return NNF_ERR_ARG;
+        if (x_vec_ok(X, ldx) && x_vec_ok(Pin, ldr)) NNF_COST_LAUNCH(true, 8, true);
+        else NNF_COST_LAUNCH(false, 8, true);
+    } else if (OP == NNF_PROD) {
+        if (x_vec_ok(X, ldx)) NNF_COST_LAUNCH(true, 8, false);
+        else NNF_COST_LAUNCH(false, 8, false);
+    } else if (x_vec_ok(X, ldx)) {
+        if (KS <= 16) NNF_COST_LAUNCH(true, 4, false);
+        else NNF_COST_LAUNCH(true, 8, false);
     } else {
-        if (KS <= 16) NNF_COST_LAUNCH(false, 4);
-        else NNF_COST_LAUNCH(false, 8);
+        if (KS <= 16) NNF_COST_LAUNCH(false, 4, false);
+        else NNF_COST_LAUNCH(false, 8, false);
     }
 #undef NNF_COST_LAUNCH
     NNF_CHECK_LAUNCH();
     nnf_probe(ctx, NNF_PROBE_COST, 1, st);
-    if (OP == NNF_RATIO_KL || OP == NNF_RATIO_GEN) return NNF_OK;   // nothing to sum
+    if (OP == NNF_RATIO_KL || OP == NNF_RATIO_GEN || OP == NNF_PROD) return NNF_OK;   // nothing to sum
     hipLaunchKernelGGL(nnf_sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, (int64_t)grid * csplit, scale, out_f64);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
@@ -1197,8 +1332,48 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
 static int cost_args_ok(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
                         const float* V, int64_t ldv, int r, double* out) {
     if (!ctx || !X || !Ut || !V || !out || m < 1 || n < 1 || r < 1 || ldx < n || ldu < m || ldv < n) return NNF_ERR_ARG;
-    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
     if (32 * ldx * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
+    return NNF_OK;
+}
+
+// The cost / ratio pass at any rank.  Up to NNF_MAX_RANK: one launch.  Above: the model U V is built up over rank chunks of
+// <= 128 in an m x n buffer P -- chunk 0 writes its product (NNF_PROD), every later chunk adds its own to what it reads
+// back, and the LAST chunk does so inside the pass that was asked for (cost terms or ratios on X and the whole model).
+// P is the first output of a ratio pass (R1, in place), else the caller's scratch (nnf_ctx_set_scratch) or, if that is
+// absent or too small, the tail of the context workspace; NNF_ERR_WORKSPACE when neither holds 4*m*ldp bytes.
+template <int OP>
+static int launch_cost_any_rank(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
+                                const float* V, int64_t ldv, int r, float beta, double scale, double* out_f64, hipStream_t st,
+                                float* R1 = nullptr, float* R2 = nullptr, int64_t ldr = 0) {
+    if (r <= NNF_MAX_RANK)
+        return launch_cost<OP>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, scale, out_f64, st, nullptr, 0, 1, nullptr, 0, 1, R1, R2, ldr);
+    float* P = R1;
+    int64_t ldp = ldr;
+    size_t cap = 0;
+    if (!P) {
+        ldp = (n + 3) & ~(int64_t)3;
+        const size_t need = (size_t)m * ldp * 4;
+        if (ctx->big && ctx->big_bytes >= need) P = (float*)ctx->big;
+        else {
+            if (need + ((size_t)8 << 20) > ctx->ws_bytes) return NNF_ERR_WORKSPACE;
+            cap = (ctx->ws_bytes - need) & ~(size_t)255;
+            P = (float*)(ctx->ws + cap);
+        }
+    }
+    if (ldp * 4 * 32 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
+    for (int k0 = 0; k0 < r; k0 += NNF_MAX_RANK) {
+        const int rc = r - k0 < NNF_MAX_RANK ? r - k0 : NNF_MAX_RANK;
+        const float* Uc = Ut + (int64_t)k0 * ldu;
+        const float* Vc = V + (int64_t)k0 * ldv;
+        int e;
+        if (k0 + rc < r)
+            e = launch_cost<NNF_PROD>(ctx, X, m, n, ldx, Uc, ldu, Vc, ldv, rc, beta, scale, nullptr, st, nullptr, 0, 1, nullptr, 0, 1, P,
+                                      nullptr, ldp, k0 ? P : nullptr, cap);
+        else
+            e = launch_cost<OP>(ctx, X, m, n, ldx, Uc, ldu, Vc, ldv, rc, beta, scale, out_f64, st, nullptr, 0, 1, nullptr, 0, 1, R1, R2,
+                                ldp, P, cap);
+        if (e != NNF_OK) return e;
+    }
     return NNF_OK;
 }
 
@@ -1206,7 +1381,7 @@ extern "C" int nnf_frob_resid_f32(nnf_ctx* ctx, const float* X, int64_t m, int64
                                   int64_t ldu, const float* V, int64_t ldv, int r, double* out_f64, void* stream) {
     const int rc = cost_args_ok(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, out_f64);
     if (rc != NNF_OK) return rc;
-    return launch_cost<NNF_COST_FROB>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 2.f, 1.0, out_f64, (hipStream_t)stream);
+    return launch_cost_any_rank<NNF_COST_FROB>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 2.f, 1.0, out_f64, (hipStream_t)stream);
 }
 
 extern "C" int nnf_betadiv_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut,
@@ -1217,10 +1392,10 @@ extern "C" int nnf_betadiv_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t 
     if (!(beta >= 0.0)) return NNF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (beta == 2.0)  // 1/2 ||X - UV||^2  (beta_divergence.py:51-52 with beta = 2)
-        return launch_cost<NNF_COST_FROB>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 2.f, 0.5, out_f64, st);
-    if (beta == 1.0) return launch_cost<NNF_COST_KL>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 1.f, 1.0, out_f64, st);
-    if (beta == 0.0) return launch_cost<NNF_COST_IS>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 0.f, 1.0, out_f64, st);
-    return launch_cost<NNF_COST_GEN>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, (float)beta, 1.0, out_f64, st);
+        return launch_cost_any_rank<NNF_COST_FROB>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 2.f, 0.5, out_f64, st);
+    if (beta == 1.0) return launch_cost_any_rank<NNF_COST_KL>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 1.f, 1.0, out_f64, st);
+    if (beta == 0.0) return launch_cost_any_rank<NNF_COST_IS>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 0.f, 1.0, out_f64, st);
+    return launch_cost_any_rank<NNF_COST_GEN>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, (float)beta, 1.0, out_f64, st);
 }
 
 // Element-wise operands of mu_betadivmin (mu.py:84-97) for ranks beyond the fused kernels (64 < r <= 128):
@@ -1234,10 +1409,8 @@ extern "C" int nnf_mu_ratio_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t
     if (!(beta >= 0.0) || !R1 || ldr < n || (beta != 1.0 && !R2)) return NNF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (beta == 1.0)
-        return launch_cost<NNF_RATIO_KL>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 1.f, 1.0, nullptr, st, nullptr, 0, 1, nullptr, 0, 1,
-                                         R1, R2, ldr);
-    return launch_cost<NNF_RATIO_GEN>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, (float)beta, 1.0, nullptr, st, nullptr, 0, 1, nullptr, 0, 1,
-                                      R1, R2, ldr);
+        return launch_cost_any_rank<NNF_RATIO_KL>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, 1.f, 1.0, nullptr, st, R1, R2, ldr);
+    return launch_cost_any_rank<NNF_RATIO_GEN>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, (float)beta, 1.0, nullptr, st, R1, R2, ldr);
 }
 
 // beta-divergence between a dense 3-way tensor and its CP model [[F0, F1, F2]]: the cost kernel on T seen as an

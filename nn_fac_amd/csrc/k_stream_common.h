@@ -178,7 +178,8 @@ static inline bool x_vec_ok(const float* X, int64_t ldx) { return (((uintptr_t)X
 // Inputs must be strictly positive for the divergences, as in the reference.
 // ---------------------------------------------------------------------------------------------------------
 enum { NNF_COST_FROB = 0, NNF_COST_KL = 1, NNF_COST_IS = 2, NNF_COST_GEN = 3,
-       NNF_RATIO_KL = 4, NNF_RATIO_GEN = 5 };   // 4, 5: write X.*P^(beta-2) [and P^(beta-1)] instead of summing a cost
+       NNF_RATIO_KL = 4, NNF_RATIO_GEN = 5,     // 4, 5: write X.*P^(beta-2) [and P^(beta-1)] instead of summing a cost
+       NNF_PROD = 6 };                          // 6: write the model P itself (a rank chunk's share of it, ranks above 128)
 
 // hardware transcendental units (v_log_f32 = log2, v_exp_f32 = exp2, v_rcp_f32): ~1 ulp, a few issue slots each
 __device__ __forceinline__ float nnf_ln(float x) { return 0.69314718056f * __builtin_amdgcn_logf(x); }

@@ -62,6 +62,8 @@ extern "C" int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_by
     c->ring = nullptr;
     c->ring_n = c->ring_pos = 0;
     c->gc_ticket = nullptr;
+    c->big = nullptr;
+    c->big_bytes = 0;
     c->xch = nullptr;
     c->xch_bytes = (size_t)(NNF_HALS_MAX_SWEEPS + 2) * NNF_HALS_MAX_BLOCKS * 16;
     hipError_t e = hipMalloc((void**)&c->ws, c->ws_bytes);
@@ -79,6 +81,16 @@ extern "C" int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_by
         return NNF_ERR_WORKSPACE;
     }
     *out_ctx = c;
+    return NNF_OK;
+}
+
+// Caller-owned device scratch for calls whose temporaries grow with the DATA (the m x n model of nnf_frob_resid_f32 /
+// nnf_betadiv_f32 at a rank above NNF_MAX_RANK: 4*m*ldp bytes, ldp = n rounded up to 4).  Not freed by the library; the
+// caller keeps it alive until the calls that use it have finished on their streams.  (NULL, 0) withdraws it.
+extern "C" int nnf_ctx_set_scratch(nnf_ctx* ctx, void* device_buf, size_t bytes) {
+    if (!ctx || (device_buf == nullptr) != (bytes == 0) || (((uintptr_t)device_buf) & 15) != 0) return NNF_ERR_ARG;
+    ctx->big = (char*)device_buf;
+    ctx->big_bytes = bytes;
     return NNF_OK;
 }
 

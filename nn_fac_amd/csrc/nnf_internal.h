@@ -19,6 +19,8 @@ struct nnf_ctx {
     unsigned* gc_ticket;   // nnf_nmf_gram_cost_f32: finishing ticket (256 zeroed bytes of its own; the kernel returns it to zero)
     hipEvent_t* ring;      // nnf_ctx_set_probe_ring: ring_n (begin, end) pairs, the next launch records pair ring_pos
     int ring_n, ring_pos;
+    char* big;             // nnf_ctx_set_scratch: caller-owned device buffer for the m x n model of a rank above 128 (may be NULL)
+    size_t big_bytes;
 };
 
 // Build-switch registry (nnf_build_flags): every translation unit that has timing-only ablation / A-B macros records the

@@ -303,8 +303,8 @@ def test_hals_does_not_modify_inputs(eng):
 
 @pytest.mark.parametrize("r,ncols,layout", [(50, 100000, "lane"), (100, 20000, "lane"), (30, 500, "lane"), (50, 300000, "lane"),
                                             (30, 500, "quad"), (50, 2000, "quad"), (96, 8000, "quad"), (70, 16000, "quad"), (100, 4000, "quad"), (128, 3000, "quad"),
-                                            (30, 500, "wave"), (50, 2000, "wave"), (100, 4000, "wave"), (128, 3000, "wave"), (64, 8000, "wave"),
-                                            (65, 700, "wave"), (3, 50, "wave"), (1, 9, "wave"), (57, 8192, "wave"),
+                                            (30, 500, "wave"), (50, 2000, "wave"), (100, 4000, "wave"), (128, 3000, "wave"), (64, 8000, "auto"), (64, 4000, "wave"),
+                                            (65, 700, "wave"), (3, 50, "wave"), (1, 9, "wave"), (57, 8192, "auto"), (57, 4500, "wave"),
                                             (100, 20000, "auto"), (120, 9000, "lane"), (64, 70000, "lane"), (56, 40000, "lane"), (34, 40000, "lane"),
                                             (100, 125000, "auto"), (96, 50000, "mfma"), (80, 40000, "auto"), (64, 70000, "auto"), (52, 40000, "mfma"),
                                             (50, 100000, "mfma"), (48, 20000, "mfma"), (100, 3000, "mfma"), (77, 40000, "auto"), (93, 33000, "auto")])

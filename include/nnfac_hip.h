@@ -33,10 +33,15 @@ extern "C" {
 #define NNF_OK 0
 #define NNF_ERR_ARG (-1)         /* bad size / null pointer / bad flag combination            */
 #define NNF_ERR_LAUNCH (-2)      /* HIP runtime error on launch (hipGetLastError)              */
-#define NNF_ERR_UNSUPPORTED (-3) /* shape outside the built kernels (r > 128, ...)             */
+#define NNF_ERR_UNSUPPORTED (-3) /* shape outside the built kernels (tensor rank > 128, ...)      */
 #define NNF_ERR_WORKSPACE (-4)   /* context workspace too small for this call                  */
 #define NNF_ERR_DEVICE (-5)      /* wrong / unavailable device                                 */
 
+/* One launch per product / cost pass and the register- or LDS-resident sweep kernels up to this rank.  The MATRIX entry
+ * points (nnf_gram / xty / xht / frob_resid / betadiv / mu_ratio / nmf_gram_cost / hals_solve / hals_sweeps / hals_row_*) go
+ * on above it, as the reference does (nn_fac/nmf.py:175-178: any rank <= min(shape); nnls.py:158 loops range(r)): the
+ * contractions and cost passes walk the rank in chunks of 128, the sweeps run in the generic kernel on columns in global
+ * memory.  The tensor entry points (MTTKRP, core contractions, the fused MU kernels) return NNF_ERR_UNSUPPORTED above it. */
 #define NNF_MAX_RANK 128
 
 /* hals flags */
@@ -66,6 +71,11 @@ const char* nnf_status_string(int status);
 int nnf_ctx_create(nnf_ctx** out_ctx, int device, size_t workspace_bytes);
 int nnf_ctx_destroy(nnf_ctx* ctx);
 size_t nnf_ctx_workspace_bytes(const nnf_ctx* ctx);
+/* Caller-owned device scratch for temporaries that grow with the DATA: nnf_frob_resid_f32 / nnf_betadiv_f32 at a rank above
+ * NNF_MAX_RANK build the m x n model over rank chunks in 4*m*ldp bytes, ldp = n rounded up to 4 (taken from here, else from
+ * the tail of the context workspace, else NNF_ERR_WORKSPACE).  16-byte aligned; not freed by the library; must stay alive
+ * until the calls using it have finished on their streams.  (NULL, 0) withdraws it. */
+int nnf_ctx_set_scratch(nnf_ctx* ctx, void* device_buf, size_t bytes);
 
 /* Measurement hook: two caller-owned hipEvent_t (passed as void*; NULL, NULL removes them) that nnf_xty_f32 records on its
  * launch stream immediately before and after its main kernel, so that a benchmark can time the dominant kernel alone --

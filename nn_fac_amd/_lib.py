@@ -33,6 +33,7 @@ SIGNATURES = {
     "nnf_gram_f32": (_i32, [_p, _p, _i32, _i64, _i64, _p, _i64, _p]),
     "nnf_xht_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32, _i64, _p, _i64, _p]),
     "nnf_xty_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i32, _i64, _p, _i64, _p]),
+    "nnf_ctx_set_scratch": (_i32, [_p, _p, C.c_size_t]),
     "nnf_frob_resid_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _p]),
     "nnf_nmf_gram_cost_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _i64, _p, _p, _p]),
     "nnf_nmf_gram_cost_cal_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _i64, _p, _f64, _f64, _p, _p]),

@@ -37,8 +37,9 @@ __global__ void nnf_hals_prep_kernel(const float* __restrict__ UtU, int64_t ldg,
         dinv[2 * k] = (d != 0.f) ? (float)(1.0 / (double)d) : 0.f;   // pair (1/diag, nz): nz = 0 = leave the row alone
         dinv[2 * k + 1] = (d != 0.f) ? 1.f : 0.f;
     }
-    {   // all-live flag: no zero on the diagonal of the r x r Gram (r <= 128 <= blockDim)
-        const int dead = (threadIdx.x < r) && (UtU[(int64_t)threadIdx.x * ldg + threadIdx.x] == 0.f);
+    {   // all-live flag: no zero on the diagonal of the r x r Gram
+        int dead = 0;
+        for (int i = threadIdx.x; i < r; i += blockDim.x) dead |= (UtU[(int64_t)i * ldg + i] == 0.f) ? 1 : 0;
         const int any_dead = __syncthreads_or(dead);
         if (threadIdx.x == 0) dinv[2 * RP] = any_dead ? 0.f : 1.f;
     }
@@ -58,16 +59,20 @@ __global__ void nnf_hals_prep_kernel(const float* __restrict__ UtU, int64_t ldg,
 // (vl[k*128 + tid]); each row update may need a grid reduction (row sum of squares, row non-zero count, max V).
 // Requires all workgroups resident (grid sized by the host) -- columns beyond the resident set are strided.
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE>
+// GCOL (ranks above NNF_MAX_RANK, where r x 128 columns no longer fit the LDS): a thread's column is the column of V itself
+// in global memory -- read and written in place, coalesced across the threads of a wave, served by L1/L2 (a workgroup's
+// r x 128 block of V is 100 KB at rank 200); no load / store phase.  Same arithmetic in the same order as the LDS form.
+template <int MODE, bool GCOL>
 __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __restrict__ UtM, int64_t ldm,
                                                                const float* __restrict__ Gp, const float* __restrict__ dinv,
                                                                int RP, float* __restrict__ V, int64_t ldv, int r,
                                                                int64_t ncols, int max_sweeps, double delta, float sp,
                                                                unsigned flags, hals_sync sy, double* __restrict__ status,
-                                                               double* __restrict__ sweep_partials, int sweep0) {
+                                                               double* __restrict__ sweep_partials, int sweep0,
+                                                               float* __restrict__ snapshots, int64_t snap_stride, int snap_first) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* vl = reinterpret_cast<float*>(smem);                       // [r][128]
-    double* red = reinterpret_cast<double*>(smem + (size_t)r * 128 * 4 + 16);
+    float* vl = reinterpret_cast<float*>(smem);                       // [r][128]  (GCOL: unused)
+    double* red = reinterpret_cast<double*>(smem + (GCOL ? (size_t)0 : (size_t)r * 128 * 4) + 16);
     __shared__ unsigned lds_flag;
     const int nblocks = gridDim.x;
     const int64_t gthreads = (int64_t)nblocks * 128;
@@ -80,29 +85,31 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
     int done = 0, err = 0;
     bool ok = true;
     if (MODE == 0 && sweep0 > 0 && !hals_take_over(status, sweep0, delta, eps0, eps)) return;
-    float* mycol = vl + threadIdx.x;
     const int64_t col0 = active ? gtid : 0;
-    for (int k = 0; k < r; ++k) mycol[k * 128] = active ? V[(int64_t)k * ldv + col0] : 0.f;
+    float* mycol = GCOL ? V + col0 : vl + threadIdx.x;               // element k of the column: mycol[k * cs]
+    const int64_t cs = GCOL ? ldv : 128;
+    if constexpr (!GCOL)
+        for (int k = 0; k < r; ++k) mycol[k * 128] = active ? V[(int64_t)k * ldv + col0] : 0.f;
     for (int s = 1; s <= max_sweeps && ok; ++s) {
         double nd = 0.0;
         for (int k = 0; k < r; ++k) {
             const float di = dinv[2 * k];
             if (di != 0.f) {
                 float dot = 0.f;
-                for (int i = 0; i < r; ++i) dot = fmaf(Gp[k * RP + i], mycol[i * 128], dot);
-                const float vk = mycol[k * 128];
+                for (int i = 0; i < r; ++i) dot = fmaf(Gp[k * RP + i], mycol[i * cs], dot);
+                const float vk = mycol[k * cs];
                 float step = fmaxf((UtM[(int64_t)k * ldm + col0] - dot - sp) * di, -vk);
                 if (!active) step = 0.f;
-                mycol[k * 128] = vk + step;
+                if (!GCOL || active) mycol[k * cs] = vk + step;
                 nd += (double)step * (double)step;
             } else if (flags & NNF_HALS_NONZERO) {
                 err = 2;   // nnls.py:176-177
             }
             if (rowsync) {
-                const float vk = mycol[k * 128];
+                const float vk = mycol[k * cs];
                 double vmax = 0.0;
                 if (flags & NNF_HALS_NONZERO)
-                    for (int i = 0; i < r; ++i) vmax = fmax(vmax, (double)mycol[i * 128]);
+                    for (int i = 0; i < r; ++i) vmax = fmax(vmax, (double)mycol[i * cs]);
                 double mine[3] = {active ? (double)vk * (double)vk : 0.0, (active && vk != 0.f) ? 1.0 : 0.0,
                                   active ? vmax : -1.0e300};
                 double tot[3];
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
                 ok = grid_exchange<3>(sy, ++epoch, nblocks, pub, tot, red, &lds_flag);
                 if (!ok) break;
                 if ((flags & NNF_HALS_NONZERO) && di != 0.f && tot[1] == 0.0 && active)
-                    mycol[k * 128] = (float)(1e-16 * tot[2]);            // nnls.py:173-174
+                    mycol[k * cs] = (float)(1e-16 * tot[2]);            // nnls.py:173-174
                 if (flags & NNF_HALS_NORMALIZE) {
                     // the norm is taken after the NONZERO refill (nnls.py:179-185)
                     double nsq = tot[0];
@@ -129,8 +136,8 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
                         nsq = f * f * (double)ncols;
                     }
                     if (active) {
-                        if (nsq != 0.0) mycol[k * 128] = (float)((double)mycol[k * 128] / sqrt(nsq));
-                        else mycol[k * 128] = (float)(1.0 / sqrt((double)ncols));
+                        if (nsq != 0.0) mycol[k * cs] = (float)((double)mycol[k * cs] / sqrt(nsq));
+                        else mycol[k * cs] = (float)(1.0 / sqrt((double)ncols));
                     }
                 }
             }
@@ -140,6 +147,10 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
         const double bs = nnf_block_sum_f64(nd, red);
         if (MODE == 1) {
             if (threadIdx.x == 0) sweep_partials[(size_t)(s - 1) * nblocks + blockIdx.x] = bs;
+            if (snapshots != nullptr && s > snap_first && active) {   // block s - 1 - snap_first: V after sweep s
+                float* sn = snapshots + (int64_t)(s - 1 - snap_first) * snap_stride + col0;
+                for (int k = 0; k < r; ++k) sn[(int64_t)k * ncols] = mycol[k * cs];
+            }
         } else {
             double mine[1] = {bs}, tot[1];
             ok = grid_exchange<1>(sy, ++epoch, nblocks, mine, tot, red, &lds_flag);
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
             if (!(eps >= delta * eps0)) break;
         }
     }
-    if (active)
+    if (!GCOL && active)
         for (int k = 0; k < r; ++k) V[(int64_t)k * ldv + col0] = mycol[k * 128];
     if (blockIdx.x == 0 && threadIdx.x == 0 && status) {
         if (MODE == 0 && max_sweeps >= 1) {
@@ -184,7 +195,7 @@ static int pick_rp(int r) {
     static const int opts[] = {8, 16, 24, 32, 40, 48, 50, 52, 56, 64, 80, 96, 100, 104, 112, 128};   // 100: config E's rank
     for (int o : opts)
         if (r <= o) return o;
-    return -1;
+    return (r + 7) & ~7;      // above NNF_MAX_RANK: the generic kernel only (its padded Gram has one row per 8)
 }
 
 // workgroups of 256 columns the register-resident lane kernel of padded rank RP keeps on the chip
@@ -219,14 +230,16 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
         return NNF_ERR_ARG;
     if (MODE == 0 && !status) return NNF_ERR_ARG;
     if (MODE == 1 && !nodelta_out && nsweeps > 0) return NNF_ERR_ARG;
-    if (r > NNF_MAX_RANK || nsweeps > NNF_HALS_MAX_SWEEPS) return NNF_ERR_UNSUPPORTED;   // (longer solves: chained by the caller)
+    if (nsweeps > NNF_HALS_MAX_SWEEPS) return NNF_ERR_UNSUPPORTED;   // (longer solves: chained by the caller)
+    const bool big_rank = r > NNF_MAX_RANK;   // the generic kernel on columns in global memory (no snapshots, no residual state)
+
     if (flags & ~(NNF_HALS_SPARSITY | NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) return NNF_ERR_ARG;
     const int RP = pick_rp(r);
     const float sp = (flags & NNF_HALS_SPARSITY) ? sparsity : 0.f;
     const int max_blocks = NNF_HALS_MAX_BLOCKS;
     nnf_ws_cursor cur(ctx);
     const int RS = 32 * ((RP + 31) / 32);
-    const bool generic = (flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) != 0;
+    const bool generic = big_rank || (flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) != 0;
     // few columns: four lanes per column (k_hals_quad.hip); many: one lane per column (k_hals_fast.hip)
     // NNF_HALS_FORCE=lane|quad pins the column layout (tests exercise both kernels on the same fixtures)
     const char* force = getenv("NNF_HALS_FORCE");
@@ -321,20 +334,35 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
         if (nsweeps == 0) return NNF_OK;
     } else if (generic) {
         // one column per thread, all workgroups resident (row-level grid reductions)
-        const size_t shm = (size_t)r * 128 * 4 + 16 + 3 * 2 * 8 + 64;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_generic_kernel<MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        const size_t shm = (big_rank ? (size_t)0 : (size_t)r * 128 * 4) + 16 + 3 * 2 * 8 + 64;
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_generic_kernel<MODE>, 128, shm) != hipSuccess ||
-            nb < 1)
-            return NNF_ERR_LAUNCH;
+        hipError_t he;
+        if (big_rank) {
+            he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_generic_kernel<MODE, true>, 128, shm);
+        } else {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_generic_kernel<MODE, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_generic_kernel<MODE, false>, 128, shm);
+        }
+        if (he != hipSuccess || nb < 1) return NNF_ERR_LAUNCH;
         int bpc = nb >= 3 ? nb - 1 : nb;
         if (bpc > 4) bpc = 4;
         const int64_t grid = nnf_cdiv(ncols, 128);
-        if (grid > (int64_t)bpc * ctx->num_cus || grid > max_blocks) return NNF_ERR_UNSUPPORTED;
+        // blind sweeps without row-level reductions exchange nothing: no residency needed (any number of columns)
+        const bool exchanges = MODE == 0 || (flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) != 0;
+        if ((exchanges && grid > (int64_t)bpc * ctx->num_cus) || grid > (exchanges ? (int64_t)max_blocks : (int64_t)0x7fffffff))
+            return NNF_ERR_UNSUPPORTED;
+        if (!exchanges && MODE == 1 && grid > max_blocks) {   // the per-sweep partial sums: one double per workgroup and sweep
+            sweep_partials = (double*)cur.take((size_t)(nsweeps > 0 ? nsweeps : 1) * (size_t)grid * 8);
+            if (!sweep_partials) return NNF_ERR_WORKSPACE;
+        }
         nblocks = (int)grid;
-        hipLaunchKernelGGL((nnf_hals_generic_kernel<MODE>), dim3(nblocks), dim3(128), shm, st, UtM, ldm, Gp, dinv, RS, V,
-                           ldv, r, ncols, nsweeps, delta, sp, flags, sy, status, sweep_partials, sweep0);
+        if (big_rank)
+            hipLaunchKernelGGL((nnf_hals_generic_kernel<MODE, true>), dim3(nblocks), dim3(128), shm, st, UtM, ldm, Gp, dinv, RS, V,
+                               ldv, r, ncols, nsweeps, delta, sp, flags, sy, status, sweep_partials, sweep0, snapshots, snap_stride, snap_first);
+        else
+            hipLaunchKernelGGL((nnf_hals_generic_kernel<MODE, false>), dim3(nblocks), dim3(128), shm, st, UtM, ldm, Gp, dinv, RS, V,
+                               ldv, r, ncols, nsweeps, delta, sp, flags, sy, status, sweep_partials, sweep0, snapshots, snap_stride, snap_first);
         NNF_CHECK_LAUNCH();
     } else {
         if ((((int64_t)(r - 1) * ldv + ncols) * 4) >= (int64_t)0x7fff0000 || (((int64_t)(r - 1) * ldm + ncols) * 4) >= (int64_t)0x7fff0000)
@@ -477,7 +505,10 @@ __global__ __launch_bounds__(256) void nnf_hals_stop_restore_kernel(const double
 extern "C" int nnf_hals_resident_columns(nnf_ctx* ctx, int r, int64_t* columns_out) {
     if (!ctx || r < 1 || !columns_out) return NNF_ERR_ARG;
     const int RP = pick_rp(r);
-    if (RP < 0) return NNF_ERR_UNSUPPORTED;
+    if (r > NNF_MAX_RANK) {   // the generic kernel: four 128-column workgroups per CU
+        *columns_out = (int64_t)4 * ctx->num_cus * 128;
+        return NNF_OK;
+    }
     hals_args a{};
     a.ncols = -1;
     int nblocks = 0, rc;

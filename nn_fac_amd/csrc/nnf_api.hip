@@ -205,16 +205,19 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
                                                             int64_t ldg, int r, int64_t n,
                                                             double* __restrict__ partial, unsigned* __restrict__ ticket,
                                                             const double* __restrict__ normx2, double* __restrict__ out,
-                                                            double sigma_a, double bias_a) {
+                                                            double sigma_a, double bias_a, int g_global) {
     extern __shared__ float gc_sh[];
-    float* g = gc_sh;                    // r x r
-    float* vc = gc_sh + (size_t)r * r;   // 16 columns x r
+    // the Gram: staged in LDS (r x r), or -- ranks above NNF_MAX_RANK, where it no longer fits -- read where it lies (L2)
+    const float* g = g_global ? G : gc_sh;
+    const int64_t gs = g_global ? ldg : r;
+    float* vc = gc_sh + (g_global ? (size_t)0 : (size_t)r * r);   // 16 columns x r
     __shared__ double red[4];
     __shared__ unsigned last;
-    for (int e = threadIdx.x; e < r * r; e += 256) {      // G2: the Gram is a Hadamard product (NTF: ntf.py:442-445)
-        const int64_t o = (int64_t)(e / r) * ldg + (e % r);
-        g[e] = G2 ? G[o] * G2[o] : G[o];
-    }
+    if (!g_global)
+        for (int e = threadIdx.x; e < r * r; e += 256) {      // G2: the Gram is a Hadamard product (NTF: ntf.py:442-445)
+            const int64_t o = (int64_t)(e / r) * ldg + (e % r);
+            gc_sh[e] = G2 ? G[o] * G2[o] : G[o];
+        }
     const int tc = threadIdx.x >> 4, t = threadIdx.x & 15;
     const int64_t j = (int64_t)blockIdx.x * 16 + tc;
     for (int a = t; a < r; a += 16) vc[tc * r + a] = (j < n) ? V[(int64_t)a * ldv + j] : 0.f;
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
     if (j < n) {
         const float* vj = vc + tc * r;
         for (int a = t; a < r; a += 16) {
-            const float* ga = g + (size_t)a * r;
+            const float* ga = g + (size_t)a * gs;
             double ta = 0.0;
             for (int b = 0; b < r; ++b) ta = __builtin_fma((double)ga[b], (double)vj[b], ta);
             const double va = (double)vj[a], p = va * (double)UtM[(int64_t)a * ldm + j];
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) tot[i] = nnf_block_sum_f64(s[i], red);
     float gm = 0.f;
-    for (int e = threadIdx.x; e < r * r; e += 256) gm = fmaxf(gm, fabsf(g[e]));
+    for (int e = threadIdx.x; e < r * r; e += 256) gm = fmaxf(gm, fabsf(g[(size_t)(e / r) * gs + (e % r)]));
     gm = fmaxf(gm, __shfl_xor(gm, 1, 64));
     gm = fmaxf(gm, __shfl_xor(gm, 2, 64));
     gm = fmaxf(gm, __shfl_xor(gm, 4, 64));
@@ -298,7 +301,8 @@ extern "C" int nnf_nmf_gram_cost_cal_f32(nnf_ctx* ctx, const float* V, int64_t l
                                          double bias_a, double* out_f64, void* stream) {
     if (!ctx || !V || !UtM || !UtU || !normx2_f64 || !out_f64 || r < 1 || n < 1 || ldv < n || ldm < n || ldg < r) return NNF_ERR_ARG;
     if (!(sigma_a >= 0.0) || !(bias_a >= 0.0)) return NNF_ERR_ARG;
-    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    const int g_global = r > NNF_MAX_RANK ? 1 : 0;
+    if (g_global && UtU_b != nullptr) return NNF_ERR_UNSUPPORTED;   // (Hadamard Grams belong to NTF: ranks <= 128)
     hipStream_t st = (hipStream_t)stream;
     const int64_t nwg = nnf_cdiv(n, 16);
     if (nwg > (int64_t)1 << 24) return NNF_ERR_UNSUPPORTED;
@@ -308,14 +312,15 @@ extern "C" int nnf_nmf_gram_cost_cal_f32(nnf_ctx* ctx, const float* V, int64_t l
     // the ticket: 256 bytes of the context's own, zero at creation, returned to zero by the kernel itself (stream-ordered)
     unsigned* ticket = ctx->gc_ticket;
     if (!ticket) return NNF_ERR_WORKSPACE;
-    const size_t shm = ((size_t)r * r + (size_t)16 * r) * 4;
+    const size_t shm = ((g_global ? (size_t)0 : (size_t)r * r) + (size_t)16 * r) * 4;
+    if (shm > 96 * 1024) return NNF_ERR_UNSUPPORTED;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_gram_cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
     hipLaunchKernelGGL(nnf_gram_cost_kernel, dim3((int)nwg), dim3(256), shm, st, V, ldv, UtM, ldm, UtU, UtU_b, ldg, r, n, partial,
-                       ticket, normx2_f64, out_f64, sigma_a, bias_a);
+                       ticket, normx2_f64, out_f64, sigma_a, bias_a, g_global);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
 }

@@ -18,18 +18,20 @@ ST_EPS, ST_CNT, ST_EPS0, ST_ERR, ST_WORDS = 0, 1, 2, 3, 8
 _engines = {}
 _lock = threading.Lock()
 
-MAX_RANK = 128      # NNF_MAX_RANK of include/nnfac_hip.h: the sweep / Gram / cross / cost / MTTKRP kernels hold a rank-long
-#                     column or operand tile per lane or per LDS image
+MAX_RANK = 128      # NNF_MAX_RANK of include/nnfac_hip.h: up to here one launch per product / cost pass and the register- or
+#                     LDS-resident sweep kernels; above, matrix factorisations go on in rank chunks (see check_rank)
 
 
 def check_rank(r, where):
-    """The reference accepts any rank up to min(shape) (nn_fac/nmf.py:175-178; nnls.py:156-170 loops `range(r)`); the
-    kernels here are built for rank <= 128.  Said at the boundary, before anything is uploaded or launched, instead of an
-    NNF_ERR_UNSUPPORTED status from deep inside an iteration."""
+    """The reference accepts any rank up to min(shape) (nn_fac/nmf.py:175-178; nnls.py:156-170 loops `range(r)`).  The MATRIX
+    path (nmf, hals_nnls_acc, mu_betadivmin) follows it: above 128 the contractions and cost passes walk the rank in chunks of
+    128 and the sweeps run in the generic kernel ("Ranks above 128") -- callers of that path do not call
+    this.  The TENSOR kernels (MTTKRP, Tucker core contractions, the fused CP passes) are built for rank <= 128: said at the
+    boundary, before anything is uploaded or launched, instead of an NNF_ERR_UNSUPPORTED status from deep inside an iteration."""
     r = int(r)
     if r > MAX_RANK:
-        raise EngineError(f"{where}: rank {r} is above the {MAX_RANK} the MI355X kernels of nn_fac_amd are built for "
-                          f"(register-resident sweep columns, LDS operand tiles); factorise with rank <= {MAX_RANK}")
+        raise EngineError(f"{where}: rank {r} is above the {MAX_RANK} the tensor kernels (MTTKRP, core contractions) of "
+                          f"nn_fac_amd are built for; matrix factorisations (nmf, hals_nnls_acc, mu_betadivmin) take any rank")
 
 
 def _ptr(t):
@@ -130,9 +132,22 @@ class Engine:
         if Ut.shape[1] != m or V.shape != (r, n):
             raise EngineError("frob_resid: shape mismatch")
         o = out if out is not None else torch.empty(1, dtype=torch.float64, device=X.device)
+        self._model_scratch(m, n, r)
         _lib.check(self.lib.nnf_frob_resid_f32(self.ctx, _ptr(X), m, n, _ld(X), _ptr(Ut), _ld(Ut), _ptr(V),
                                                _ld(V), r, _ptr(o), self._stream()), "nnf_frob_resid_f32")
         return o
+
+    def _model_scratch(self, m, n, r):
+        """Ranks above 128: the cost passes build the model U V over rank chunks in an m x n float32 buffer (nnf_ctx_set_scratch);
+        kept between calls, grown when a larger one is asked for."""
+        if r <= MAX_RANK:
+            return
+        need = int(m) * ((int(n) + 3) // 4 * 4) * 4
+        cur = getattr(self, "_scratch", None)
+        if cur is None or cur.numel() < need:
+            torch.cuda.current_stream(self.device).synchronize()      # (earlier calls may still read the old buffer)
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.nnf_ctx_set_scratch(self.ctx, _ptr(self._scratch), need), "nnf_ctx_set_scratch")
 
     def gram_cost(self, V, UtM, UtU, normx2, out, UtU_b=None, rounding=None):
         """||X - U V||^2 through the Gram identity (nnf_nmf_gram_cost_cal_f32): `normx2` a 1-element float64 device tensor holding
@@ -229,7 +244,8 @@ class Engine:
             raise EngineError("hals_solve: shape mismatch")
         st = status if status is not None else torch.empty(ST_WORDS, dtype=torch.float64, device=V.device)
         flags = self._hals_flags(sparsity, normalize, nonzero)
-        if (normalize or nonzero) and ncols > self.ROWSYNC_MAX_COLUMNS and int(max_sweeps) > 0:
+        if (normalize or nonzero or r > MAX_RANK) and ncols > self.ROWSYNC_MAX_COLUMNS and int(max_sweeps) > 0:
+            # (ranks above 128 run in the generic kernel too: one column per resident thread for a persistent solve)
             return self._hals_solve_rowwalk(UtM, UtU, V, max_sweeps, delta, sparsity, st, normalize=normalize, nonzero=nonzero)
         self._check_rowsync_columns(normalize or nonzero, ncols)
         total, first = int(max_sweeps), min(int(max_sweeps), self.HALS_MAX_SWEEPS_PER_LAUNCH)
@@ -355,7 +371,7 @@ class Engine:
     MU_FUSED_MAX_RANK = 64   # the fused two-MFMA kernels are built for r <= 64 (beta = 2 has no limit: Gram form)
 
     def _mu_large_rank(self, X, Ut, V, beta, side):
-        """64 < r <= 128, beta != 2: one pass writes the element-wise operands R1 = X.*(UV)^(beta-2), R2 = (UV)^(beta-1)
+        """r > 64 (beta != 2) or r > 128 (any beta; the model then builds up over rank chunks inside R1): one pass writes the element-wise operands R1 = X.*(UV)^(beta-2), R2 = (UV)^(beta-1)
         (m x n device scratch each), then the numerator / denominator are plain X H^T ('left') or W^T X ('right') products.
         Returns (num, den or None, den_vec or None) like mu_right_accum."""
         m, n = X.shape
@@ -390,7 +406,7 @@ class Engine:
                                                         r, _ptr(O), _ld(O), _ptr(cost_out), self._stream()),
                        "nnf_mu_left_kl_cost_f32")
             return O
-        if r > self.MU_FUSED_MAX_RANK and float(beta) != 2.0:
+        if (r > self.MU_FUSED_MAX_RANK and float(beta) != 2.0) or r > MAX_RANK:
             num, den, dvec = self._mu_large_rank(X, Ut, V, beta, "left")
             return self.mu_apply(Ut, num, den, dvec, beta, out=out)
         O = out if out is not None else torch.empty_like(Ut)
@@ -403,7 +419,7 @@ class Engine:
         _chk2d(X, "mu X"), _chk2d(Ut, "mu Ut"), _chk2d(V, "mu V")
         m, n = X.shape
         r = Ut.shape[0]
-        if r > self.MU_FUSED_MAX_RANK and float(beta) != 2.0:
+        if (r > self.MU_FUSED_MAX_RANK and float(beta) != 2.0) or r > MAX_RANK:
             num, den, dvec = self._mu_large_rank(X, Ut, V, beta, "right")
             return self.mu_apply(V, num, den, dvec, beta, out=out)
         O = out if out is not None else torch.empty_like(V)
@@ -418,7 +434,7 @@ class Engine:
         _chk2d(X, "mu X"), _chk2d(Ut, "mu Ut"), _chk2d(V, "mu V")
         m, n = X.shape
         r = Ut.shape[0]
-        if r > self.MU_FUSED_MAX_RANK and float(beta) != 2.0:
+        if (r > self.MU_FUSED_MAX_RANK and float(beta) != 2.0) or r > MAX_RANK:
             return self._mu_large_rank(X, Ut, V, beta, "right")
         num = torch.empty((r, n), dtype=torch.float32, device=X.device)
         den = torch.empty((r, n), dtype=torch.float32, device=X.device) if float(beta) != 1.0 else None
@@ -584,6 +600,7 @@ class Engine:
         m, n = X.shape
         r = Ut.shape[0]
         o = out if out is not None else torch.empty(1, dtype=torch.float64, device=X.device)
+        self._model_scratch(m, n, r)
         _lib.check(self.lib.nnf_betadiv_f32(self.ctx, _ptr(X), m, n, _ld(X), _ptr(Ut), _ld(Ut), _ptr(V),
                                             _ld(V), r, float(beta), _ptr(o), self._stream()), "nnf_betadiv_f32")
         return o

@@ -40,7 +40,6 @@ def nmf(data, rank, init="random", U_0=None, V_0=None, n_iter_max=100, tol=1e-8,
         rank = min_data
         warnings.warn(f"The rank is too high for the input matrix. It was set to {min_data} instead.")
 
-    _engine.check_rank(rank, "nmf")
     if deterministic:
         np.random.seed(seed)
 
@@ -65,7 +64,6 @@ def compute_nmf(data, rank, U_in, V_in, n_iter_max=100, tol=1e-8,
     row-sharded problem (contiguous blocks, nn_fac_amd.dist.shard_rows), `V_in` is replicated; the Gram / cross terms, the
     stopping scalars and the cost are all-reduced over the group (RCCL over xGMI) and every rank returns its
     block of U, the whole V and the global costs (start values: nn_fac_amd.dist.sharded_random_init)."""
-    _engine.check_rank(V_in.shape[0], "compute_nmf")
     dev = device_of(data, U_in, V_in)
     eng = _engine.get_engine(dev)
     X = to_dev(data, dev)
@@ -129,7 +127,6 @@ def compute_nmf(data, rank, U_in, V_in, n_iter_max=100, tol=1e-8,
 def one_nmf_step(data, rank, U_in, V_in, norm_data, update_rule, beta,
                  sparsity_coefficients, fixed_modes, normalize, deterministic):
     """One pass of updates on U then V, then the cost (nmf.py:387-458).  Returns (U, V, cost)."""
-    _engine.check_rank(V_in.shape[0], "one_nmf_step")
     dev = device_of(data, U_in, V_in)
     eng = _engine.get_engine(dev)
     X = to_dev(data, dev)

@@ -17,7 +17,6 @@ def mu_betadivmin(U, V, M, beta):
     """U <- max(U * ((K^(beta-2) .* M) V^T / (K^(beta-1) V^T))^gamma(beta), 1e-12), K = U V   (mu.py:79-97)."""
     if beta < 0:
         raise err.InvalidArgumentValue("Invalid value for beta: negative one.") from None
-    _engine.check_rank(V.shape[0], "mu_betadivmin")
     dev = device_of(U, V, M)
     eng = _engine.get_engine(dev)
     X = to_dev(M, dev)
@@ -34,7 +33,6 @@ def switch_alternate_mu(data, U, V, beta, matrix):
     elif matrix in ["V", "H"]:
         if beta < 0:
             raise err.InvalidArgumentValue("Invalid value for beta: negative one.") from None
-        _engine.check_rank(V.shape[0], "switch_alternate_mu")
         dev = device_of(U, V, data)
         eng = _engine.get_engine(dev)
         out = eng.mu_right(to_dev(data, dev), to_dev_t(U, dev), to_dev(V, dev), beta)

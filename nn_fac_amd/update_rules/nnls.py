@@ -51,7 +51,6 @@ def hals_nnls_acc(UtM, UtU, in_V, maxiter=500, atime=None, alpha=0.5, delta=0.01
         raise err.ArgumentException(f"Argument UtU is an array of {np.shape(UtU)} dimensions when it should be a matrix.")
     if _ndim(in_V) != 2:
         raise err.ArgumentException(f"Argument in_V is an array of {np.shape(in_V)} dimensions when it should be a matrix.")
-    _engine.check_rank(max(np.shape(UtM)[0], np.shape(in_V)[0] if _size(in_V) else 0), "hals_nnls_acc")
 
     dev = device_of(UtM, UtU, in_V)
     eng = _engine.get_engine(dev)
@@ -122,7 +121,6 @@ def hals_coupling_nnls_acc(UtM, UtU, in_V, Vtarget, mu, maxiter=500, atime=None,
     in the shifted Gram, which is how the kernels recognise a frozen row.  Same return tuple ``(V, eps, cnt, rho)``;
     ``nonzero`` with a zero diagonal raises the reference's plain ValueError (nnls.py:331-332).  The reference does
     not validate its arguments here (no ArgumentException checks); shapes are checked only as far as the device needs."""
-    _engine.check_rank(np.shape(in_V)[0], "hals_coupling_nnls_acc")
     dev = device_of(UtM, UtU, in_V)
     eng = _engine.get_engine(dev)
     M = to_dev(UtM, dev)

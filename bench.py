@@ -500,6 +500,12 @@ def nmf_kernel_rooflines(cx, run, m, n, r, rule, beta, loop_times=None, steps=20
         out.append(roof("nnf_xht_kernel (X H^T)", "mfma", flops, ms, MFMA_F32_PEAK_TFLOPS, "TFLOP/s",
                         algorithmic_flops=flops, algorithmic_bytes=xbytes, hbm_gbs=xbytes / ms / 1e6))
         with_inloop(out[-1], run.inloop(eng, "xht", 1, steps)[0], flops, MFMA_F32_PEAK_TFLOPS, "TFLOP/s", where_more)
+        if ws.direct_cost:
+            # the run has left the Gram-identity cost (flagged, or NNF_COST=direct): the streaming cost kernel of iteration i then
+            # runs on the side stream BESIDE this kernel of iteration i+1 -- both launches stretch, their sum is what shrinks
+            out[-1]["note"] = ("in these iterations the streaming cost kernel (the identity's error estimate exceeded its bound late "
+                               "in the run) runs beside this kernel on the side stream: the in-loop duration is that of two "
+                               "kernels sharing the chip; `standalone` is this kernel alone")
         c = torch.zeros(1, dtype=torch.float64, device=X.device)
         ms = eng.time_kernel("cost", lambda: eng.frob_resid(X, Ut, V, out=c))
         out.append(roof("nnf_cost_kernel<FROB> (||X - UV||^2 fused with the product)", "mfma", flops, ms,

@@ -11,7 +11,8 @@ O=$R/gpurun_out/prof_$CFG
 mkdir -p $O
 cd $R && timeout -k 10 500 python bench.py --config $CFG --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
-ARGS="--config $CFG --steps 10 --warmup 2 --no-cpu --no-fixed --no-extra --no-kernels"
+# (the loop of the bench line itself: same --steps / --warmup; the legs that follow the timed region are switched off)
+ARGS="--config $CFG --steps 20 --warmup 3 --no-cpu --no-fixed --no-extra --no-kernels"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $ARGS > $O/stats.log 2>&1 || exit 1
 if [ "$WHAT" = "all" ]; then
 ARGS="--config $CFG --steps 3 --warmup 1 --no-cpu --no-fixed --no-extra --no-kernels"

@@ -40,7 +40,11 @@ for cfg in configs:
     if not os.path.isdir(O):
         print("missing", O)
         continue
-    shutil.copy(os.path.join(O, "stats_summary.txt"), os.path.join(P, f"{tag}_{cfg}_kernel_stats.txt"))
+    # (regenerated here from the raw CSVs: the newest pass only, with the per-grid split of tools/prof_summary.py)
+    import subprocess
+    with open(os.path.join(P, f"{tag}_{cfg}_kernel_stats.txt"), "w") as fh:
+        fh.write(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), os.path.join(O, "stats")],
+                                capture_output=True, text=True).stdout)
     ks = sorted(glob.glob(os.path.join(O, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if ks:
         shutil.copy(ks[-1], os.path.join(P, f"{tag}_{cfg}_kernel_stats.csv"))
@@ -50,12 +54,20 @@ for cfg in configs:
         with open(os.path.join(P, f"{tag}_{cfg}_bench_line.json"), "w") as fh:
             fh.write(line[-1])
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    grids = {}
     for d in ("fetch", "write", "sq"):
         # (gpurun merges into gpurun_out/: files of earlier calls stay -- only the newest pass of each kind counts)
         for f in sorted(glob.glob(os.path.join(O, d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
-            for r in csv.DictReader(open(f)):
+            rows = list(csv.DictReader(open(f)))
+            # a kernel launched with several grids (W^T X on the matrix and on the row blocks of the once-per-run rounding
+            # calibration; sweeps on full and last column blocks): only the launches of its LARGEST grid count
+            for r in rows:
                 for k in MAIN.get(cfg, []):
                     if k in r["Kernel_Name"]:
+                        grids[k] = max(grids.get(k, 0), int(r["Grid_Size"]))
+            for r in rows:
+                for k in MAIN.get(cfg, []):
+                    if k in r["Kernel_Name"] and int(r["Grid_Size"]) == grids[k]:
                         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
     for k, cs in acc.items():
@@ -64,7 +76,7 @@ for cfg in configs:
         fetch = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
         write = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
         e = {"fetch_size_kib_raw": fetch, "write_size_kib": write, "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
-             "launches": len(cs["FETCH_SIZE"])}
+             "launches": len(cs["FETCH_SIZE"]), "grid_threads": grids.get(k)}
         if cs.get("SQ_VALU_MFMA_BUSY_CYCLES") and cs.get("SQ_BUSY_CYCLES"):
             # SQ_VALU_MFMA_BUSY_CYCLES sums over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines (~ kernel duration each)
             e["mfma_busy_frac"] = (sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(cs["SQ_VALU_MFMA_BUSY_CYCLES"])) / \

@@ -121,6 +121,10 @@ int nnf_allreduce_f64(nnf_comm* comm, double* buf, int64_t count, void* stream);
 /* G[r x r] = A[r x K] * A^T.   Replaces VVt = np.dot(V, V.T) (nmf.py:407), UtU = np.dot(U.T, U) (nmf.py:432),
  * and each factor Gram in ntf.py:442-445.  Split-K partials are summed in fp64 in a fixed order. */
 int nnf_gram_f32(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg, void* stream);
+/* The same Gram and, next to it, the sums BEFORE they are rounded to fp32 (G64: r x r doubles, contiguous) -- the split-K
+ * partials are added in fp64 anyway.  For nnf_nmf_gram_cost_g64_f32: fp32 storage of U^T U alone (3.4e-8 relative rms per
+ * entry) bounds the Gram-identity cost at ~1e-4 of a late-run cost at 10^6 x 4000 rank 100. */
+int nnf_gram_f64_f32(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg, double* G64, void* stream);
 
 /* out[r x m] = V[r x n] * X[m x n]^T.   Replaces VMt = np.dot(V, data.T) (nmf.py:408), the "X H^T" product. */
 int nnf_xht_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r, int64_t ldv,
@@ -160,6 +164,12 @@ int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float
 int nnf_nmf_gram_cost_cal_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
                               const float* UtU_b, int64_t ldg, int r, int64_t n, const double* normx2_f64, double sigma_a,
                               double bias_a, double* out_f64, void* stream);
+/* The same with the quadratic form taken on UtU64 (nnf_gram_f64_f32; UtU, the fp32 Gram the solve used, still provides max|UtU|)
+ * and sigma_g = the caller's figure for the relative rms error of a UtU64 entry (what the fp32 accumulation inside a split
+ * leaves) in place of the 4e-8 of fp32 storage in sigma_B = sigma_g max|UtU| ||V||_F^2.  No Hadamard form (NMF loop only). */
+int nnf_nmf_gram_cost_g64_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
+                              const double* UtU64, int64_t ldg, int r, int64_t n, const double* normx2_f64, double sigma_a,
+                              double bias_a, double sigma_g, double* out_f64, void* stream);
 
 /* hals_nnls_acc (nnls.py:147-198) on device: V (r x ncols, in/out) is swept in place until
  *   eps >= delta*eps0 fails, or sweeps == max_sweeps                         (nnls.py:156)

@@ -37,6 +37,8 @@ SIGNATURES = {
     "nnf_frob_resid_f32": (_i32, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _p]),
     "nnf_nmf_gram_cost_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _i64, _p, _p, _p]),
     "nnf_nmf_gram_cost_cal_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _i64, _p, _f64, _f64, _p, _p]),
+    "nnf_nmf_gram_cost_g64_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _i64, _p, _f64, _f64, _f64, _p, _p]),
+    "nnf_gram_f64_f32": (_i32, [_p, _p, _i32, _i64, _i64, _p, _i64, _p, _p]),
     "nnf_hals_solve_f32": (_i32, [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _f64, _f32, _u32, _p, _p]),
     "nnf_hals_solve_cross_f32": (_i32, [_p, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _f64, _f32, _u32, _p,
                                         _p]),

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 3 : 1)) void nnf_xty_ke
 // out[row][col] = sum_s slabs[s][row][col]  (fp64 accumulate, slab order fixed -> bitwise reproducible)
 __global__ __launch_bounds__(256) void nnf_reduce_slabs_kernel(const float* __restrict__ slabs, int nslab,
                                                                int64_t slab_stride, int rows, int64_t cols, int64_t lds,
-                                                               float* __restrict__ out, int64_t ldo) {
+                                                               float* __restrict__ out, int64_t ldo, double* __restrict__ out64) {
     const int64_t total = (int64_t)rows * cols;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = e / cols, col = e - row * cols;
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void nnf_reduce_slabs_kernel(const float* __re
             for (int u = 0; u < 8; ++u) s += (k + u < nslab) ? (double)v[u] : 0.0;
         }
         out[row * ldo + col] = (float)s;
+        if (out64) out64[e] = s;          // (the Gram before it is rounded to fp32: nnf_gram_f64_f32)
     }
 }
 
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void nnf_reduce_slabs4_kernel(const float* __r
 template <int P>
 __global__ __launch_bounds__(256) void nnf_reduce_slabs_par_kernel(const float* __restrict__ slabs, int nslab,
                                                                    int64_t slab_stride, int rows, int64_t cols, int64_t lds,
-                                                                   float* __restrict__ out, int64_t ldo) {
+                                                                   float* __restrict__ out, int64_t ldo, double* __restrict__ out64) {
     constexpr int EPB = 256 / P;                 // elements per workgroup
     __shared__ double part_sum[P][EPB];
     const int el = threadIdx.x % EPB, part = threadIdx.x / EPB;
@@ -233,13 +234,14 @@ __global__ __launch_bounds__(256) void nnf_reduce_slabs_par_kernel(const float* 
             for (int q = 1; q < P; ++q) t += part_sum[q][el];
             const int64_t row = e / cols, col = e - row * cols;
             out[row * ldo + col] = (float)t;
+            if (out64) out64[e] = t;
         }
         __syncthreads();
     }
 }
 
 int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, int rows, int64_t cols, int64_t lds,
-                            float* out, int64_t ldo, hipStream_t st) {
+                            float* out, int64_t ldo, hipStream_t st, double* out64) {
     {   // enough threads to fill the chip: P parts per element when the output is small
         const int64_t total = (int64_t)rows * cols;
         int P = 1;
@@ -250,7 +252,7 @@ int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, 
             if (grid > 4096) grid = 4096;
 #define NNF_RSP(PP)                                                                                                          \
     hipLaunchKernelGGL(nnf_reduce_slabs_par_kernel<PP>, dim3((int)grid), dim3(256), 0, st, slabs, nslab, slab_stride, rows, cols, \
-                       lds, out, ldo)
+                       lds, out, ldo, out64)
             if (P == 2) NNF_RSP(2);
             else if (P == 4) NNF_RSP(4);
             else if (P == 8) NNF_RSP(8);
@@ -261,7 +263,7 @@ int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, 
         }
     }
     // (four columns per thread only when that still leaves enough threads to fill the chip: 20 vs 16 us at r x n = 1e5)
-    if ((lds & 3) == 0 && (slab_stride & 3) == 0 && (((uintptr_t)slabs) & 15) == 0 && (int64_t)rows * cols >= ((int64_t)1 << 21)) {
+    if (out64 == nullptr && (lds & 3) == 0 && (slab_stride & 3) == 0 && (((uintptr_t)slabs) & 15) == 0 && (int64_t)rows * cols >= ((int64_t)1 << 21)) {
         const int64_t total4 = (int64_t)rows * ((cols + 3) >> 2);
         int grid4 = (int)((total4 + 255) / 256);
         if (grid4 > 2048) grid4 = 2048;
@@ -275,7 +277,7 @@ int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, 
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(nnf_reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, slabs, nslab, slab_stride, rows, cols, lds,
-                       out, ldo);
+                       out, ldo, out64);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
 }
@@ -291,8 +293,12 @@ static int launch_xty(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t 
     // a workgroup sums its rows in fp32 (MFMA accumulators); the slabs are added in fp64.  Cap the rows per workgroup: at
     // 1e6 x 4000 rank 100 the plan above is 16 splits of 62500 rows, and an entry of U^T X came out with 9.5e-7 relative rms
     // and a -2.2e-7 MEAN error (tools/probes/accum_error_probe.py) -- enough to take the Gram-identity cost of a HALS iteration
-    // (which multiplies the mean by ||X||^2) to its 5e-4 bound.  8192 rows: the slabs of the extra splits are ~1 % of the pass.
-    const int64_t ROWS_CAP = 8192;
+    // (which multiplies the mean by ||X||^2) to its 5e-4 bound.  The mean falls with the SQUARE of the chain length (62500 ->
+    // 8192 rows: -2.2e-7 -> -3.7e-9, rms 9.5e-7 -> 1.2e-7), and at 8192 rows it was still what sent a 10^6 x 4000 rank-100 run
+    // back to the streaming cost kernel after ~20 iterations (tools/probes/identity_terms_probe.py: bias term 3.3e4 of a 5.9e4
+    // bound, actual error 1.4e4).  2048 rows: 489 slabs of 1.6 MB there (+10 % traffic on an MFMA-bound pass; fewer if the
+    // context workspace is smaller -- the Python engine creates its main context with 1 GiB).
+    const int64_t ROWS_CAP = 2048;
     if (nsplit < nnf_cdiv(m, ROWS_CAP)) nsplit = nnf_cdiv(m, ROWS_CAP);
     const int64_t max_split = nnf_cdiv(m, 64);
     if (nsplit > max_split) nsplit = max_split;
@@ -658,12 +664,26 @@ static int launch_gram_small(const float* A, int r, int64_t K, int64_t lda, floa
     return NNF_OK;
 }
 
+// G64[a][b] = (double)G[a][b]: the fp64 copy of a Gram that was formed without slabs (K <= 1024: one workgroup)
+__global__ void nnf_gram_widen_kernel(const float* __restrict__ G, int64_t ldg, int r, double* __restrict__ G64) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < r * r) G64[e] = (double)G[(int64_t)(e / r) * ldg + (e % r)];
+}
+static int launch_gram_widen(const float* G, int64_t ldg, int r, double* G64, hipStream_t st) {
+    if (!G64) return NNF_OK;
+    hipLaunchKernelGGL(nnf_gram_widen_kernel, dim3((r * r + 255) / 256), dim3(256), 0, st, G, ldg, r, G64);
+    NNF_CHECK_LAUNCH();
+    return NNF_OK;
+}
+
 template <int MT>
 static int launch_gram(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
-                       hipStream_t st) {
+                       hipStream_t st, double* G64) {
     if constexpr (MT <= 4) {
-        if (K <= 1024 && (K & 3) == 0 && ldg == r && ((((uintptr_t)A) & 15) == 0) && (lda & 3) == 0)
-            return launch_gram_small<MT>(A, r, K, lda, G, st);
+        if (K <= 1024 && (K & 3) == 0 && ldg == r && ((((uintptr_t)A) & 15) == 0) && (lda & 3) == 0) {
+            const int rc = launch_gram_small<MT>(A, r, K, lda, G, st);
+            return rc != NNF_OK ? rc : launch_gram_widen(G, ldg, r, G64, st);
+        }
     }
     // one split per CU (the slab reduction spreads every output element over up to 16 threads, so its cost grows slowly
     // with the split count): 64 splits left a 50 x 100000 Gram at 22 us and a 100 x 125000 one at 127 us
@@ -677,19 +697,25 @@ static int launch_gram(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, 
     // short factors (the I_mode x R factors of NTF / NTD, K <= 1024): one workgroup, no split, written straight into G -- the
     // whole Gram is a few microseconds of work and the slab reduction would be a second launch of the same length
     if (K <= 1024 && ldg == r) nsplit = 1;
+    // the fp64 copy is wanted for its accuracy: keep the fp32 chain inside a split short (<= 512 columns; 40 KB of slab each)
+    if (G64 != nullptr && nsplit > 1 && nsplit < nnf_cdiv(K, 512)) {
+        nsplit = nnf_cdiv(K, 512);
+        const int64_t ws_max = (int64_t)(cur.remaining() / 4) / ((int64_t)r * r);
+        if (nsplit > ws_max) nsplit = ws_max > 0 ? ws_max : 1;
+    }
     const int64_t kps = nnf_rup(nnf_cdiv(K, nsplit), 64);
     nsplit = nnf_cdiv(K, kps);
     const int a_vec_ok = ((((uintptr_t)A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     if (nsplit == 1 && ldg == r) {
         hipLaunchKernelGGL((nnf_gram_kernel<MT>), dim3(1), dim3(256), 0, st, A, r, K, lda, G, kps, a_vec_ok);
         NNF_CHECK_LAUNCH();
-        return NNF_OK;
+        return launch_gram_widen(G, ldg, r, G64, st);
     }
     float* slabs = (float*)cur.take((size_t)nsplit * r * r * 4);
     if (!slabs) return NNF_ERR_WORKSPACE;
     hipLaunchKernelGGL((nnf_gram_kernel<MT>), dim3((int)nsplit), dim3(256), 0, st, A, r, K, lda, slabs, kps, a_vec_ok);
     NNF_CHECK_LAUNCH();
-    return nnf_launch_reduce_slabs(slabs, (int)nsplit, (int64_t)r * r, r, r, r, G, ldg, st);
+    return nnf_launch_reduce_slabs(slabs, (int)nsplit, (int64_t)r * r, r, r, r, G, ldg, st, G64);
 }
 
 // Ranks above NNF_MAX_RANK: the Gram in 64 x 64 blocks.  Workgroup (split ks, block pair (bi, bj)) multiplies the k range of
@@ -749,7 +775,7 @@ __global__ __launch_bounds__(256) void nnf_gram_blocks_kernel(const float* __res
 }
 
 static int launch_gram_blocks(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
-                              hipStream_t st) {
+                              hipStream_t st, double* G64) {
     const int nb = (r + 63) / 64;
     // splits: about two workgroups per CU over all block pairs, 64-column chunks, as many slabs as the workspace holds
     int64_t nsplit = nnf_cdiv((int64_t)2 * ctx->num_cus, (int64_t)nb * nb);
@@ -757,6 +783,7 @@ static int launch_gram_blocks(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, 
     if (nsplit > max_split) nsplit = max_split;
     const int64_t ws_max = (int64_t)(cur.remaining() / 4) / ((int64_t)r * r);
     if (ws_max < 1) return NNF_ERR_WORKSPACE;
+    if (G64 != nullptr && nsplit < nnf_cdiv(K, 512)) nsplit = nnf_cdiv(K, 512);   // (short fp32 chains for the fp64 copy, as in launch_gram)
     if (nsplit > ws_max) nsplit = ws_max;
     if (nsplit < 1) nsplit = 1;
     const int64_t kps = nnf_rup(nnf_cdiv(K, nsplit), 64);
@@ -766,7 +793,7 @@ static int launch_gram_blocks(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, 
     if (!slabs) return NNF_ERR_WORKSPACE;
     hipLaunchKernelGGL(nnf_gram_blocks_kernel, dim3((int)nsplit, nb * nb), dim3(256), 0, st, A, r, K, lda, slabs, kps, a_vec_ok, nb);
     NNF_CHECK_LAUNCH();
-    return nnf_launch_reduce_slabs(slabs, (int)nsplit, (int64_t)r * r, r, r, r, G, ldg, st);
+    return nnf_launch_reduce_slabs(slabs, (int)nsplit, (int64_t)r * r, r, r, r, G, ldg, st, G64);
 }
 
 // =========================================================================================================
@@ -1229,25 +1256,34 @@ extern "C" int nnf_xht_f32(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, i
 }
 
 int nnf_gram_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
-                  hipStream_t st) {
+                  hipStream_t st, double* G64) {
     if (!ctx || !A || !G || r < 1 || K < 1 || lda < K || ldg < r) return NNF_ERR_ARG;
-    if (r > NNF_MAX_RANK) return launch_gram_blocks(ctx, cur, A, r, K, lda, G, ldg, st);
+    if (r > NNF_MAX_RANK) return launch_gram_blocks(ctx, cur, A, r, K, lda, G, ldg, st, G64);
     switch ((r + 15) / 16) {
-        case 1: return launch_gram<1>(ctx, cur, A, r, K, lda, G, ldg, st);
-        case 2: return launch_gram<2>(ctx, cur, A, r, K, lda, G, ldg, st);
-        case 3: return launch_gram<3>(ctx, cur, A, r, K, lda, G, ldg, st);
-        case 4: return launch_gram<4>(ctx, cur, A, r, K, lda, G, ldg, st);
-        case 5: return launch_gram<5>(ctx, cur, A, r, K, lda, G, ldg, st);
-        case 6: return launch_gram<6>(ctx, cur, A, r, K, lda, G, ldg, st);
-        case 7: return launch_gram<7>(ctx, cur, A, r, K, lda, G, ldg, st);
-        default: return launch_gram<8>(ctx, cur, A, r, K, lda, G, ldg, st);
+        case 1: return launch_gram<1>(ctx, cur, A, r, K, lda, G, ldg, st, G64);
+        case 2: return launch_gram<2>(ctx, cur, A, r, K, lda, G, ldg, st, G64);
+        case 3: return launch_gram<3>(ctx, cur, A, r, K, lda, G, ldg, st, G64);
+        case 4: return launch_gram<4>(ctx, cur, A, r, K, lda, G, ldg, st, G64);
+        case 5: return launch_gram<5>(ctx, cur, A, r, K, lda, G, ldg, st, G64);
+        case 6: return launch_gram<6>(ctx, cur, A, r, K, lda, G, ldg, st, G64);
+        case 7: return launch_gram<7>(ctx, cur, A, r, K, lda, G, ldg, st, G64);
+        default: return launch_gram<8>(ctx, cur, A, r, K, lda, G, ldg, st, G64);
     }
 }
 extern "C" int nnf_gram_f32(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
                             void* stream) {
     if (!ctx) return NNF_ERR_ARG;
     nnf_ws_cursor cur(ctx);
-    return nnf_gram_impl(ctx, cur, A, r, K, lda, G, ldg, (hipStream_t)stream);
+    return nnf_gram_impl(ctx, cur, A, r, K, lda, G, ldg, (hipStream_t)stream, nullptr);
+}
+// The same Gram, and next to it the sums BEFORE they are rounded to fp32 (G64: r x r doubles, contiguous): the split-K slabs are
+// added in fp64 anyway, so the copy costs a second store.  For the Gram-identity cost (nnf_nmf_gram_cost_g64_f32): fp32 storage of
+// U^T U alone (relative rms 3.4e-8 per entry) bounds that cost's accuracy at ~1e-4 of a late-run cost at 10^6 x 4000 rank 100.
+extern "C" int nnf_gram_f64_f32(nnf_ctx* ctx, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
+                                double* G64, void* stream) {
+    if (!ctx || !G64) return NNF_ERR_ARG;
+    nnf_ws_cursor cur(ctx);
+    return nnf_gram_impl(ctx, cur, A, r, K, lda, G, ldg, (hipStream_t)stream, G64);
 }
 
 template <int OP>

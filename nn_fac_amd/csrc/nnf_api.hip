@@ -200,23 +200,28 @@ extern "C" int nnf_hadamard_f32(nnf_ctx* ctx, const float* A, const float* B, fl
 //   A = sum v_a UtM[a][j],  A2 = sum (v_a UtM[a][j])^2,  B = sum v_a t_a,  V2 = sum v_a^2      (all fp64)
 // block sums in a fixed order -> partial[wg][4]; the LAST workgroup to finish (a ticket) adds the partials in index order
 // -- the same bits whichever workgroup that is -- and writes {cost, flag, estimate}.  One launch.
+template <typename GT>
 __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restrict__ V, int64_t ldv, const float* __restrict__ UtM,
                                                             int64_t ldm, const float* __restrict__ G, const float* __restrict__ G2,
-                                                            int64_t ldg, int r, int64_t n,
+                                                            const double* __restrict__ G64, int64_t ldg, int r, int64_t n,
                                                             double* __restrict__ partial, unsigned* __restrict__ ticket,
                                                             const double* __restrict__ normx2, double* __restrict__ out,
-                                                            double sigma_a, double bias_a, int g_global) {
-    extern __shared__ float gc_sh[];
-    // the Gram: staged in LDS (r x r), or -- ranks above NNF_MAX_RANK, where it no longer fits -- read where it lies (L2)
-    const float* g = g_global ? G : gc_sh;
-    const int64_t gs = g_global ? ldg : r;
-    float* vc = gc_sh + (g_global ? (size_t)0 : (size_t)r * r);   // 16 columns x r
+                                                            double sigma_a, double bias_a, int g_global, double sigma_g) {
+    extern __shared__ __attribute__((aligned(16))) float gc_sh[];
+    // the Gram: staged in LDS (r x r; GT = double when the caller has the sums before their rounding to fp32, G64), or -- ranks
+    // above NNF_MAX_RANK, where it no longer fits -- read where it lies (L2)
+    GT* gsh = reinterpret_cast<GT*>(gc_sh);
+    const GT* gsrc = reinterpret_cast<const GT*>(std::is_same<GT, double>::value ? (const void*)G64 : (const void*)G);
+    const GT* g = g_global ? gsrc : gsh;
+    const int64_t gs = g_global ? (std::is_same<GT, double>::value ? (int64_t)r : ldg) : r;
+    float* vc = gc_sh + (g_global ? (size_t)0 : (size_t)r * r * (sizeof(GT) / 4));   // 16 columns x r
     __shared__ double red[4];
     __shared__ unsigned last;
     if (!g_global)
         for (int e = threadIdx.x; e < r * r; e += 256) {      // G2: the Gram is a Hadamard product (NTF: ntf.py:442-445)
             const int64_t o = (int64_t)(e / r) * ldg + (e % r);
-            gc_sh[e] = G2 ? G[o] * G2[o] : G[o];
+            if constexpr (std::is_same<GT, double>::value) gsh[e] = G64[e];
+            else gsh[e] = G2 ? G[o] * G2[o] : G[o];
         }
     const int tc = threadIdx.x >> 4, t = threadIdx.x & 15;
     const int64_t j = (int64_t)blockIdx.x * 16 + tc;
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
     if (j < n) {
         const float* vj = vc + tc * r;
         for (int a = t; a < r; a += 16) {
-            const float* ga = g + (size_t)a * gs;
+            const GT* ga = g + (size_t)a * gs;
             double ta = 0.0;
             for (int b = 0; b < r; ++b) ta = __builtin_fma((double)ga[b], (double)vj[b], ta);
             const double va = (double)vj[a], p = va * (double)UtM[(int64_t)a * ldm + j];
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) tot[i] = nnf_block_sum_f64(s[i], red);
     float gm = 0.f;
-    for (int e = threadIdx.x; e < r * r; e += 256) gm = fmaxf(gm, fabsf(g[(size_t)(e / r) * gs + (e % r)]));
+    for (int e = threadIdx.x; e < r * r; e += 256) gm = fmaxf(gm, fabsf((float)g[(size_t)(e / r) * gs + (e % r)]));
     gm = fmaxf(gm, __shfl_xor(gm, 1, 64));
     gm = fmaxf(gm, __shfl_xor(gm, 2, 64));
     gm = fmaxf(gm, __shfl_xor(gm, 4, 64));
@@ -280,7 +285,8 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
         // the cross-product kernel sums in fp32 (tools/probes/accum_error_probe.py: 5.7e-8 at 100000 x 2000 rank 50, 9.5e-7 at
         // 1e6 x 4000 rank 100, there with a MEAN of -2.2e-7) -- and bias_a its figure for the relative mean: a bias does not
         // average down over the entries, it enters with the whole inner product.
-        const double sa = 2.0 * sigma_a * sqrt(tot[1]), sb = 4e-8 * (double)gm * tot[3];
+        // sigma_g: relative rms rounding of a Gram entry as handed over -- 4e-8 for fp32 storage, the caller's figure for G64
+        const double sa = 2.0 * sigma_a * sqrt(tot[1]), sb = sigma_g * (double)gm * tot[3];
         const double est = 4.0 * sqrt(sa * sa + sb * sb) + 2.0 * 2.0 * bias_a * fabs(tot[0]);
         out[0] = cost;
         out[1] = (est <= 5e-4 * cost) ? 0.0 : 1.0;      // (a NaN or a non-positive cost lands on 1)
@@ -288,19 +294,12 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call (stream-ordered)
     }
 }
-extern "C" int nnf_nmf_gram_cost_cal_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
-                                         const float* UtU_b, int64_t ldg, int r, int64_t n, const double* normx2_f64, double sigma_a,
-                                         double bias_a, double* out_f64, void* stream);
-extern "C" int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
-                                     const float* UtU_b, int64_t ldg, int r, int64_t n, const double* normx2_f64, double* out_f64,
-                                     void* stream) {
-    return nnf_nmf_gram_cost_cal_f32(ctx, V, ldv, UtM, ldm, UtU, UtU_b, ldg, r, n, normx2_f64, 6e-8, 0.0, out_f64, stream);
-}
-extern "C" int nnf_nmf_gram_cost_cal_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
-                                         const float* UtU_b, int64_t ldg, int r, int64_t n, const double* normx2_f64, double sigma_a,
-                                         double bias_a, double* out_f64, void* stream) {
+static int gram_cost_launch(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
+                            const float* UtU_b, const double* UtU64, int64_t ldg, int r, int64_t n, const double* normx2_f64,
+                            double sigma_a, double bias_a, double sigma_g, double* out_f64, void* stream) {
     if (!ctx || !V || !UtM || !UtU || !normx2_f64 || !out_f64 || r < 1 || n < 1 || ldv < n || ldm < n || ldg < r) return NNF_ERR_ARG;
-    if (!(sigma_a >= 0.0) || !(bias_a >= 0.0)) return NNF_ERR_ARG;
+    if (!(sigma_a >= 0.0) || !(bias_a >= 0.0) || !(sigma_g >= 0.0)) return NNF_ERR_ARG;
+    if (UtU64 != nullptr && UtU_b != nullptr) return NNF_ERR_ARG;
     const int g_global = r > NNF_MAX_RANK ? 1 : 0;
     if (g_global && UtU_b != nullptr) return NNF_ERR_UNSUPPORTED;   // (Hadamard Grams belong to NTF: ranks <= 128)
     hipStream_t st = (hipStream_t)stream;
@@ -312,15 +311,46 @@ extern "C" int nnf_nmf_gram_cost_cal_f32(nnf_ctx* ctx, const float* V, int64_t l
     // the ticket: 256 bytes of the context's own, zero at creation, returned to zero by the kernel itself (stream-ordered)
     unsigned* ticket = ctx->gc_ticket;
     if (!ticket) return NNF_ERR_WORKSPACE;
-    const size_t shm = ((g_global ? (size_t)0 : (size_t)r * r) + (size_t)16 * r) * 4;
-    if (shm > 96 * 1024) return NNF_ERR_UNSUPPORTED;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_gram_cost_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr = true;
+    const size_t shm = ((g_global ? (size_t)0 : (size_t)r * r * (UtU64 ? 2 : 1)) + (size_t)16 * r) * 4;
+    if (shm > 150 * 1024) return NNF_ERR_UNSUPPORTED;
+    if (UtU64) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_gram_cost_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      150 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL(nnf_gram_cost_kernel<double>, dim3((int)nwg), dim3(256), shm, st, V, ldv, UtM, ldm, UtU, UtU_b, UtU64, ldg, r, n,
+                           partial, ticket, normx2_f64, out_f64, sigma_a, bias_a, g_global, sigma_g);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_gram_cost_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      96 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL(nnf_gram_cost_kernel<float>, dim3((int)nwg), dim3(256), shm, st, V, ldv, UtM, ldm, UtU, UtU_b, UtU64, ldg, r, n,
+                           partial, ticket, normx2_f64, out_f64, sigma_a, bias_a, g_global, sigma_g);
     }
-    hipLaunchKernelGGL(nnf_gram_cost_kernel, dim3((int)nwg), dim3(256), shm, st, V, ldv, UtM, ldm, UtU, UtU_b, ldg, r, n, partial,
-                       ticket, normx2_f64, out_f64, sigma_a, bias_a, g_global);
     NNF_CHECK_LAUNCH();
     return NNF_OK;
+}
+extern "C" int nnf_nmf_gram_cost_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
+                                     const float* UtU_b, int64_t ldg, int r, int64_t n, const double* normx2_f64, double* out_f64,
+                                     void* stream) {
+    return gram_cost_launch(ctx, V, ldv, UtM, ldm, UtU, UtU_b, nullptr, ldg, r, n, normx2_f64, 6e-8, 0.0, 4e-8, out_f64, stream);
+}
+extern "C" int nnf_nmf_gram_cost_cal_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
+                                         const float* UtU_b, int64_t ldg, int r, int64_t n, const double* normx2_f64, double sigma_a,
+                                         double bias_a, double* out_f64, void* stream) {
+    return gram_cost_launch(ctx, V, ldv, UtM, ldm, UtU, UtU_b, nullptr, ldg, r, n, normx2_f64, sigma_a, bias_a, 4e-8, out_f64, stream);
+}
+// The quadratic form on the Gram BEFORE its rounding to fp32 (UtU64: r x r doubles from nnf_gram_f64_f32; UtU, the fp32 Gram the
+// solve used, still gives max|UtU| of the estimate): sigma_g = the caller's figure for the relative rms error of a UtU64 entry
+// (what the fp32 accumulation inside a split leaves: Engine.cross_rounding measures it), in place of the 4e-8 of fp32 storage.
+extern "C" int nnf_nmf_gram_cost_g64_f32(nnf_ctx* ctx, const float* V, int64_t ldv, const float* UtM, int64_t ldm, const float* UtU,
+                                         const double* UtU64, int64_t ldg, int r, int64_t n, const double* normx2_f64, double sigma_a,
+                                         double bias_a, double sigma_g, double* out_f64, void* stream) {
+    if (!UtU64) return NNF_ERR_ARG;
+    return gram_cost_launch(ctx, V, ldv, UtM, ldm, UtU, nullptr, UtU64, ldg, r, n, normx2_f64, sigma_a, bias_a, sigma_g, out_f64, stream);
 }

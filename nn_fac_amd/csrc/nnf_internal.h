@@ -130,7 +130,7 @@ __device__ __forceinline__ void nnf_xcd_map(int bid, int members, int& group, in
 
 // kernels / launchers implemented in the .hip files
 int nnf_launch_reduce_slabs(const float* slabs, int nslab, int64_t slab_stride, int rows, int64_t cols, int64_t lds,
-                            float* out, int64_t ldo, hipStream_t st);
+                            float* out, int64_t ldo, hipStream_t st, double* out64 = nullptr);   // out64: the sums before rounding (rows x cols, contiguous)
 
 // out[z] = A (p x q) B[z] (q x cols), z < batch: a rank-sized left operand staged in LDS (k_mu.hip)
 int nnf_small_gemm_launch(const float* A, int64_t lda, int p, int q, const float* B, int64_t ldb, int64_t cols, float* out,
@@ -144,4 +144,4 @@ int nnf_xty_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, in
 int nnf_xht_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V,
                  int r, int64_t ldv, float* out, int64_t ldo, hipStream_t st);
 int nnf_gram_impl(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, int64_t K, int64_t lda, float* G, int64_t ldg,
-                  hipStream_t st);
+                  hipStream_t st, double* G64 = nullptr);

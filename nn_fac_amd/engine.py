@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, streams); every arithmetic statement of
 libnnfac_hip.so.  Factors are kept "transposed" on the device (Ut: r x m, V: r x n), the layout hals_nnls_acc works on.
 """
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -91,11 +92,18 @@ class Engine:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- contractions -------------------------------------------------------------------------------
-    def gram(self, A, out=None):
-        """A (r x K) -> A A^T (r x r)."""
+    def gram(self, A, out=None, out64=None):
+        """A (r x K) -> A A^T (r x r).  out64 (optional, contiguous r x r float64 device tensor): also receives the sums before
+        they are rounded to fp32 (nnf_gram_f64_f32), for gram_cost(..., UtU64=...)."""
         _chk2d(A, "gram A")
         r, K = A.shape
         G = out if out is not None else torch.empty((r, r), dtype=torch.float32, device=A.device)
+        if out64 is not None:
+            if out64.dtype != torch.float64 or not out64.is_contiguous() or out64.numel() < r * r or out64.device != A.device:
+                raise EngineError("gram: out64 must be a contiguous float64 device tensor of r*r elements")
+            _lib.check(self.lib.nnf_gram_f64_f32(self.ctx, _ptr(A), r, K, _ld(A), _ptr(G), _ld(G), _ptr(out64), self._stream()),
+                       "nnf_gram_f64_f32")
+            return G
         _lib.check(self.lib.nnf_gram_f32(self.ctx, _ptr(A), r, K, _ld(A), _ptr(G), _ld(G), self._stream()),
                    "nnf_gram_f32")
         return G
@@ -149,7 +157,7 @@ class Engine:
             self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.nnf_ctx_set_scratch(self.ctx, _ptr(self._scratch), need), "nnf_ctx_set_scratch")
 
-    def gram_cost(self, V, UtM, UtU, normx2, out, UtU_b=None, rounding=None):
+    def gram_cost(self, V, UtM, UtU, normx2, out, UtU_b=None, rounding=None, UtU64=None):
         """||X - U V||^2 through the Gram identity (nnf_nmf_gram_cost_cal_f32): `normx2` a 1-element float64 device tensor holding
         ||X||^2, `out` >= 3 float64 on the device: {cost, 1 if the fp32 operands do not carry it to 5e-4, error estimate}.
         rounding = (relative rms, |relative mean|) of the rounding error of a UtM entry (default: 6e-8, 0)."""
@@ -161,6 +169,13 @@ class Engine:
         if UtU_b is not None and (UtU_b.shape != UtU.shape or _ld(UtU_b) != _ld(UtU)):
             raise EngineError("gram_cost: the two Grams of a Hadamard pair must share shape and leading dimension")
         sa, ba = (6e-8, 0.0) if rounding is None else (float(rounding[0]), float(rounding[1]))
+        if UtU64 is not None and UtU_b is None:
+            # the quadratic form on the Gram before its rounding to fp32; rounding[2] = relative rms error of a UtU64 entry
+            sg = float(rounding[2]) if rounding is not None and len(rounding) > 2 else 1e-8
+            _lib.check(self.lib.nnf_nmf_gram_cost_g64_f32(self.ctx, _ptr(V), _ld(V), _ptr(UtM), _ld(UtM), _ptr(UtU), _ptr(UtU64),
+                                                          _ld(UtU), r, n, _ptr(normx2), sa, ba, sg, _ptr(out), self._stream()),
+                       "nnf_nmf_gram_cost_g64_f32")
+            return out
         _lib.check(self.lib.nnf_nmf_gram_cost_cal_f32(self.ctx, _ptr(V), _ld(V), _ptr(UtM), _ld(UtM), _ptr(UtU),
                                                       _ptr(UtU_b) if UtU_b is not None else None, _ld(UtU), r, n,
                                                       _ptr(normx2), sa, ba, _ptr(out), self._stream()), "nnf_nmf_gram_cost_cal_f32")
@@ -182,6 +197,23 @@ class Engine:
         rel = (full - acc) / acc.clamp_min(1e-300)
         rel = torch.where(acc > 0, rel, torch.zeros_like(rel))
         return float(rel.pow(2).mean().sqrt()), abs(float(rel.mean()))
+
+    def gram_rounding(self, Ut, blocks=16):
+        """Relative rms error of an entry of the fp64 Gram of nnf_gram_f64_f32 at THIS shape (the fp32 accumulation inside a
+        split of the Gram kernel): the Gram in one piece against the sum of the Grams of `blocks` column blocks, whose chains
+        are `blocks` times shorter.  r x r work, once per run."""
+        r, m = Ut.shape
+        full = torch.empty((r, r), dtype=torch.float64, device=Ut.device)
+        self.gram(Ut, out64=full)
+        acc, part = torch.zeros_like(full), torch.empty_like(full)
+        step = -(-m // int(blocks))
+        step = -(-step // 256) * 256
+        for lo in range(0, m, step):
+            self.gram(Ut[:, lo:min(m, lo + step)], out64=part)
+            acc += part
+        rel = (full - acc) / acc.abs().clamp_min(1e-300)
+        rel = torch.where(acc != 0, rel, torch.zeros_like(rel))
+        return float(rel.pow(2).mean().sqrt())
 
     def dot(self, A, B):
         _chk2d(A, "dot A"), _chk2d(B, "dot B")
@@ -701,7 +733,11 @@ def get_engine(device=None):
     with _lock:
         e = _engines.get(dev.index)
         if e is None:
-            e = Engine(dev)
+            # 1 GiB of scratch for the main context (NNF_WORKSPACE_MB overrides): the split-K slabs of W^T X at 10^6 x 4000 rank
+            # 100 are 780 MB when a workgroup sums at most 2048 rows in fp32 (k_stream.hip: launch_xty) -- with the C default of
+            # 256 MiB the plan falls back to longer chains.  Side contexts keep the default.
+            mb = int(os.environ.get("NNF_WORKSPACE_MB", "1024"))
+            e = Engine(dev, workspace_bytes=mb << 20)
             _engines[dev.index] = e
         return e
 

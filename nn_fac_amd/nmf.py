@@ -161,6 +161,10 @@ class _StepBuffers:
         self.UtM = self.v_terms[:r * n].view(r, n)
         self.G2 = self.v_terms[r * n:].view(r, r)
         self.G = torch.empty((r, r), **f32)
+        # U^T U before its rounding to fp32 (nnf_gram_f64_f32), for the Gram-identity cost: single-process GPU runs only (the
+        # row-sharded step all-reduces the fp32 Gram)
+        self.G64 = torch.empty((r, r), dtype=torch.float64, device=X.device) if X.is_cuda else None
+        self.g64_ok = False
         # one block read back per iteration: HALS status of the first / second solve at [0:8] / [8:16], cost at [16].
         # A ring of PIPELINE_DEPTH + 1 blocks with pinned host mirrors: run_steps enqueues iteration i+1 before it reads
         # the block of iteration i, so the device never waits for the host between iterations.
@@ -302,7 +306,9 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
         # below the figures the estimate was calibrated with; row-sharded: the largest over the ranks, so that every rank's
         # (replicated) cost kernel flags the same iterates
         sa, ba = eng.cross_rounding(X, Ut)
-        cal = torch.tensor([max(1.5 * sa, 6e-8), 1.5 * ba], dtype=torch.float64, device=X.device)
+        # (and what the Gram kernel's fp32 accumulation inside a split leaves in the fp64 copy of U^T U the cost is taken on)
+        sg = eng.gram_rounding(Ut) if ws.G64 is not None else 0.0
+        cal = torch.tensor([max(1.5 * sa, 6e-8), 1.5 * ba, max(1.5 * sg, 2e-9)], dtype=torch.float64, device=X.device)
         _dist.allreduce_max_(cal, group)
         ws.cross_rounding = tuple(float(v) for v in cal.cpu())
     overlap = (cuda and update_rule == "hals" and 1 not in fixed_modes and isinstance(eng, _engine.Engine) and not ident
@@ -409,7 +415,8 @@ def run_steps(eng, ws, X, rank, Ut, V, n_iter, update_rule, beta, sparsity_coeff
         ws.sync_next = False
         if ident:
             # words 19..21 of the block: {cost, 1 = not reliable, error estimate}; the V update's operands are still in place
-            eng.gram_cost(V, ws.UtM, ws.G2, ws.normx2, ws.block[19:22], rounding=ws.cross_rounding)
+            eng.gram_cost(V, ws.UtM, ws.G2, ws.normx2, ws.block[19:22], rounding=ws.cross_rounding,
+                          UtU64=ws.G64 if ws.g64_ok else None)
             _add_sparsity_terms(Ut, V, sparsity_coefficients, ws.block[19:20], group)
             _dist.allreduce_errs_(ws.block, group)
             ws.host[ws.slot].copy_(ws.block, non_blocking=True)
@@ -648,7 +655,11 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             if not deterministic:
                 _sync(dev)
                 t0 = time.time()
-            eng.gram(Ut, out=ws.G2)                     # UtU  (nmf.py:432) -- in line: see _gram_on_side
+            ws.g64_ok = (not sharded and getattr(ws, "G64", None) is not None and isinstance(eng, _engine.Engine))
+            if ws.g64_ok:
+                eng.gram(Ut, out=ws.G2, out64=ws.G64)   # UtU  (nmf.py:432) -- in line: see _gram_on_side; + its fp64 sums
+            else:
+                eng.gram(Ut, out=ws.G2)
             eng.xty(X, Ut, out=ws.UtM)                  # UtM  (nmf.py:433)
             if sharded:                                 # sum over the row blocks: r x n and r x r over xGMI, one collective
                 if getattr(ws, "v_terms", None) is not None:

@@ -50,6 +50,48 @@ def test_gram_xty_xht_frob(eng, m, n, r):
     assert abs(got - want) <= 1e-5 * want
 
 
+@pytest.mark.parametrize("r,K", [(50, 100000), (100, 40000), (12, 700), (64, 1024), (33, 513), (200, 30000), (1, 5)])
+def test_gram_with_its_fp64_sums(eng, r, K):
+    """nnf_gram_f64_f32: the fp32 Gram is unchanged (bitwise the plain entry's) and the fp64 copy is the same sums before their
+    rounding -- closer to the exact Gram than fp32 storage allows (3.4e-8 relative rms) wherever split-K slabs exist."""
+    rng = np.random.RandomState(r * 7 + K)
+    A = rng.rand(r, K).astype(np.float32)
+    Ad = dev(A)
+    G64 = torch.empty((r, r), dtype=torch.float64, device="cuda")
+    G = eng.gram(Ad, out64=G64).cpu().numpy()
+    assert np.array_equal(G, eng.gram(Ad).cpu().numpy())
+    g64 = G64.cpu().numpy()
+    assert np.array_equal(g64.astype(np.float32), G)
+    exact = A.astype(np.float64) @ A.astype(np.float64).T
+    e64 = np.sqrt(np.mean(((g64 - exact) / exact) ** 2))
+    assert e64 < 6e-7                     # (K <= 1024: one workgroup, one fp32 chain per entry, no slabs)
+    if K > 1024:
+        assert e64 < 2e-8, e64            # (accumulation inside a split of at most 512 columns only)
+
+
+def test_gram_identity_cost_on_the_fp64_gram(eng):
+    """nnf_nmf_gram_cost_g64_f32 against the fp64 residual on a late-run-like iterate (cost / ||X||^2 ~ 1e-3 at 20000 x 600 rank
+    40): same cost as the fp32-Gram form within both estimates, a smaller estimate, and an error inside its own estimate."""
+    rng = np.random.RandomState(3)
+    m, n, r = 20000, 600, 40
+    U, V = rng.rand(m, r), rng.rand(r, n)
+    X = (U @ V * (1 + 0.03 * rng.randn(m, n))).astype(np.float32)
+    Xd, Utd, Vd = dev(X), dev(U.T), dev(V)
+    UtM = eng.xty(Xd, Utd)
+    G64 = torch.empty((r, r), dtype=torch.float64, device="cuda")
+    UtU = eng.gram(Utd, out64=G64)
+    nx2 = eng.dot(Xd, Xd)
+    o32 = torch.zeros(3, dtype=torch.float64, device="cuda")
+    o64 = torch.zeros(3, dtype=torch.float64, device="cuda")
+    eng.gram_cost(Vd, UtM, UtU, nx2, o32, rounding=(6e-8, 0.0))
+    eng.gram_cost(Vd, UtM, UtU, nx2, o64, rounding=(6e-8, 0.0, 5e-9), UtU64=G64)
+    want = np.sum((X.astype(np.float64) - Utd.cpu().numpy().astype(np.float64).T @ Vd.cpu().numpy().astype(np.float64)) ** 2)
+    c32, f32_, e32 = o32.cpu().tolist()
+    c64, f64_, e64 = o64.cpu().tolist()
+    assert e64 < e32 and abs(c64 - want) <= e64 and abs(c32 - want) <= e32
+    assert abs(c64 - want) <= 2e-5 * want and f64_ == 0.0
+
+
 @pytest.mark.parametrize("K", [4, 60, 124, 128, 132, 500, 512, 772, 1000, 1024, 1028, 501])
 @pytest.mark.parametrize("r", [1, 7, 16, 17, 30, 33, 48, 50, 64, 65])
 def test_gram_of_short_factors(eng, K, r):

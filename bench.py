@@ -268,6 +268,11 @@ class Ctx:
         # all-reduces and host decisions without any peer: what the protocol itself costs a rank on a one-GPU box
         self.force_sharded = self.pg and os.environ.get("NNF_BENCH_FORCE_SHARDED") == "1"
         self.group = dist.group.WORLD if (self.world > 1 or self.force_sharded) else None
+        if self.force_sharded:
+            # (the product's own switch -- NNF_FORCE_SHARDED, read when nn_fac_amd.dist is imported -- set here, so that the one
+            #  variable of this script is enough: without it a one-rank group runs the UNSHARDED step)
+            from nn_fac_amd import dist as _nd
+            _nd.FORCE_SHARDED = True
         if factory is None:
             from nn_fac_amd.engine import get_engine
             self.eng = get_engine(self.device)

@@ -697,8 +697,10 @@ static int launch_gram(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, int r, 
     // short factors (the I_mode x R factors of NTF / NTD, K <= 1024): one workgroup, no split, written straight into G -- the
     // whole Gram is a few microseconds of work and the slab reduction would be a second launch of the same length
     if (K <= 1024 && ldg == r) nsplit = 1;
-    // the fp64 copy is wanted for its accuracy: keep the fp32 chain inside a split short (<= 512 columns; 40 KB of slab each)
-    if (G64 != nullptr && nsplit > 1 && nsplit < nnf_cdiv(K, 512)) {
+    // keep the fp32 chain inside a split short (<= 512 columns; r*r*4 bytes of slab each): what the chains leave is all the error
+    // the fp64 copy of the sums has (nnf_gram_f64_f32).  The same plan with and without the copy: the fp32 Gram does not depend
+    // on which entry point formed it.
+    if (nsplit > 1 && nsplit < nnf_cdiv(K, 512)) {
         nsplit = nnf_cdiv(K, 512);
         const int64_t ws_max = (int64_t)(cur.remaining() / 4) / ((int64_t)r * r);
         if (nsplit > ws_max) nsplit = ws_max > 0 ? ws_max : 1;
@@ -783,7 +785,7 @@ static int launch_gram_blocks(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* A, 
     if (nsplit > max_split) nsplit = max_split;
     const int64_t ws_max = (int64_t)(cur.remaining() / 4) / ((int64_t)r * r);
     if (ws_max < 1) return NNF_ERR_WORKSPACE;
-    if (G64 != nullptr && nsplit < nnf_cdiv(K, 512)) nsplit = nnf_cdiv(K, 512);   // (short fp32 chains for the fp64 copy, as in launch_gram)
+    if (nsplit < nnf_cdiv(K, 512)) nsplit = nnf_cdiv(K, 512);   // (short fp32 chains, as in launch_gram)
     if (nsplit > ws_max) nsplit = ws_max;
     if (nsplit < 1) nsplit = 1;
     const int64_t kps = nnf_rup(nnf_cdiv(K, nsplit), 64);

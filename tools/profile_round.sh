@@ -5,5 +5,5 @@ export NNF_BENCH_INIT_PG=1 NNF_BENCH_FORCE_SHARDED=1 MASTER_ADDR=127.0.0.1 MASTE
 O=gpurun_out/prof_Eblock; mkdir -p $O
 timeout -k 10 400 python bench.py --config E --shape 125000,4000,100 --steps 20 --warmup 3 --no-cpu > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.json
 R=$PWD; cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats -- python3 $R/bench.py --config E --shape 125000,4000,100 --steps 10 --warmup 2 --no-cpu --no-fixed --no-extra --no-kernels > $R/$O/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats -- python3 $R/bench.py --config E --shape 125000,4000,100 --steps 20 --warmup 3 --no-cpu --no-fixed --no-extra --no-kernels > $R/$O/stats.log 2>&1
 cd $R; python tools/prof_summary.py $O/stats > $O/stats_summary.txt; head -14 $O/stats_summary.txt

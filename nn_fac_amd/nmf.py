@@ -161,8 +161,8 @@ class _StepBuffers:
         self.UtM = self.v_terms[:r * n].view(r, n)
         self.G2 = self.v_terms[r * n:].view(r, r)
         self.G = torch.empty((r, r), **f32)
-        # U^T U before its rounding to fp32 (nnf_gram_f64_f32), for the Gram-identity cost: single-process GPU runs only (the
-        # row-sharded step all-reduces the fp32 Gram)
+        # U^T U before its rounding to fp32 (nnf_gram_f64_f32), for the Gram-identity cost (row-sharded: summed over the ranks by
+        # a collective of its own, r x r doubles)
         self.G64 = torch.empty((r, r), dtype=torch.float64, device=X.device) if X.is_cuda else None
         self.g64_ok = False
         # one block read back per iteration: HALS status of the first / second solve at [0:8] / [8:16], cost at [16].
@@ -655,7 +655,7 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
             if not deterministic:
                 _sync(dev)
                 t0 = time.time()
-            ws.g64_ok = (not sharded and getattr(ws, "G64", None) is not None and isinstance(eng, _engine.Engine))
+            ws.g64_ok = getattr(ws, "G64", None) is not None and isinstance(eng, _engine.Engine)
             if ws.g64_ok:
                 eng.gram(Ut, out=ws.G2, out64=ws.G64)   # UtU  (nmf.py:432) -- in line: see _gram_on_side; + its fp64 sums
             else:
@@ -667,6 +667,8 @@ def _one_nmf_step_dev(eng, ws, X, rank, Ut_in, V_in, update_rule, beta, sparsity
                 else:
                     _dist.allreduce_(ws.G2, group)
                     _dist.allreduce_(ws.UtM, group)
+                if ws.g64_ok:                           # the fp64 sums of the Gram for the identity cost: r x r doubles
+                    _dist.allreduce_(ws.G64, group)
             if not deterministic:
                 _sync(dev)
                 timer = time.time() - t0

@@ -37,11 +37,12 @@ extern "C" {
 #define NNF_ERR_WORKSPACE (-4)   /* context workspace too small for this call                  */
 #define NNF_ERR_DEVICE (-5)      /* wrong / unavailable device                                 */
 
-/* One launch per product / cost pass and the register- or LDS-resident sweep kernels up to this rank.  The MATRIX entry
- * points (nnf_gram / xty / xht / frob_resid / betadiv / mu_ratio / nmf_gram_cost / hals_solve / hals_sweeps / hals_row_*) go
- * on above it, as the reference does (nn_fac/nmf.py:175-178: any rank <= min(shape); nnls.py:158 loops range(r)): the
- * contractions and cost passes walk the rank in chunks of 128, the sweeps run in the generic kernel on columns in global
- * memory.  The tensor entry points (MTTKRP, core contractions, the fused MU kernels) return NNF_ERR_UNSUPPORTED above it. */
+/* One launch per product / cost pass and the register- or LDS-resident sweep kernels up to this rank.  The matrix and CP entry
+ * points (nnf_gram / xty / xht / frob_resid / betadiv / mu_ratio / nmf_gram_cost / hals_solve / hals_sweeps / hals_row_* /
+ * mttkrp3 / mttkrp3_from_partial / cp3_betadiv / ttm3 along the first and last axis) go on above it, as the reference does
+ * (nn_fac/nmf.py:175-178: any rank <= min(shape); nnls.py:158 loops range(r)): the contractions and cost passes walk the rank
+ * in chunks of 128, the sweeps run in the generic kernel on columns in global memory.  The fused MU kernels, nnf_ttm3_f32
+ * along the middle axis and the Tucker core update return NNF_ERR_UNSUPPORTED above it. */
 #define NNF_MAX_RANK 128
 
 /* hals flags */

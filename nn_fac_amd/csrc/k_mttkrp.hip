@@ -469,7 +469,17 @@ extern "C" int nnf_mttkrp3_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t 
     if (!ctx || !T || !Ft0 || !Ft1 || !Ft2 || !out || I < 1 || J < 1 || K < 1 || R < 1 || ld0 < I || ld1 < J || ld2 < K)
         return NNF_ERR_ARG;
     if (mode < 0 || mode > 2) return NNF_ERR_ARG;
-    if (R > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    if (R > NNF_MAX_RANK) {
+        // ranks above 128: the rank rows of the result are independent of each other -- passes of <= 128 rows of the three
+        // transposed factors (the tensor is read once per pass)
+        for (int k0 = 0; k0 < R; k0 += NNF_MAX_RANK) {
+            const int rc = nnf_mttkrp3_f32(ctx, T, I, J, K, Ft0 + (int64_t)k0 * ld0, ld0, Ft1 + (int64_t)k0 * ld1, ld1,
+                                           Ft2 + (int64_t)k0 * ld2, ld2, R - k0 < NNF_MAX_RANK ? R - k0 : NNF_MAX_RANK, mode,
+                                           out + (int64_t)k0 * ldo, ldo, stream);
+            if (rc != NNF_OK) return rc;
+        }
+        return NNF_OK;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (mode == 0) {
         if (ldo < I) return NNF_ERR_ARG;
@@ -556,7 +566,15 @@ extern "C" int nnf_mttkrp3_from_partial_f32(nnf_ctx* ctx, const float* Y, int64_
                                             int R, int axis, float* out, int64_t ldo, void* stream) {
     if (!ctx || !Y || !Ft || !out || A < 1 || B < 1 || R < 1 || (axis != 1 && axis != 2)) return NNF_ERR_ARG;
     if (ldf < (axis == 1 ? A : B) || ldo < (axis == 1 ? B : A)) return NNF_ERR_ARG;
-    if (R > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
+    if (R > NNF_MAX_RANK) {   // R independent matrix-vector products: passes of <= 128 of them
+        for (int k0 = 0; k0 < R; k0 += NNF_MAX_RANK) {
+            const int rc = nnf_mttkrp3_from_partial_f32(ctx, Y + (int64_t)k0 * A * B, A, B, Ft + (int64_t)k0 * ldf, ldf,
+                                                        R - k0 < NNF_MAX_RANK ? R - k0 : NNF_MAX_RANK, axis, out + (int64_t)k0 * ldo,
+                                                        ldo, stream);
+            if (rc != NNF_OK) return rc;
+        }
+        return NNF_OK;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (axis == 2) {
         int64_t grid = nnf_cdiv((int64_t)R * A, 4);

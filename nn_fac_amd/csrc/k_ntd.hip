@@ -47,9 +47,10 @@ __global__ __launch_bounds__(256) void nnf_ttm_mid_kernel(const float* __restric
 extern "C" int nnf_ttm3_f32(nnf_ctx* ctx, const float* T, int64_t I, int64_t J, int64_t K, const float* Ft, int64_t ldf, int r,
                             int mode, float* out, void* stream) {
     if (!ctx || !T || !Ft || !out || I < 1 || J < 1 || K < 1 || r < 1 || mode < 0 || mode > 2) return NNF_ERR_ARG;
-    if (r > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
     const int64_t dim = mode == 0 ? I : (mode == 1 ? J : K);
     if (ldf < dim) return NNF_ERR_ARG;
+    // (ranks above 128: modes 0 and 2 are the W^T X / X H^T kernels, which walk the rank in passes; the middle axis stays <= 128)
+    if (r > NNF_MAX_RANK && mode == 1) return NNF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     nnf_ws_cursor cur(ctx);
     if (mode == 0) return nnf_xty_impl(ctx, cur, T, I, J * K, J * K, Ft, r, ldf, out, J * K, st);

@@ -1345,7 +1345,7 @@ static int launch_cost(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64
     } while (0)
     nnf_probe(ctx, NNF_PROBE_COST, 0, st);
     if (Pin != nullptr) {           // a later rank chunk of a rank above 128 (launch_cost_chunked): one instance per load width
-        if (Ub != nullptr || ldr < n) return NNF_ERR_ARG;
+        if (ldr < n) return NNF_ERR_ARG;
         if (x_vec_ok(X, ldx) && x_vec_ok(Pin, ldr)) NNF_COST_LAUNCH(true, 8, true);
         else NNF_COST_LAUNCH(false, 8, true);
     } else if (OP == NNF_PROD) {
@@ -1382,9 +1382,10 @@ static int cost_args_ok(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int6
 template <int OP>
 static int launch_cost_any_rank(nnf_ctx* ctx, const float* X, int64_t m, int64_t n, int64_t ldx, const float* Ut, int64_t ldu,
                                 const float* V, int64_t ldv, int r, float beta, double scale, double* out_f64, hipStream_t st,
-                                float* R1 = nullptr, float* R2 = nullptr, int64_t ldr = 0) {
+                                float* R1 = nullptr, float* R2 = nullptr, int64_t ldr = 0, const float* Ub = nullptr, int64_t ldub = 0,
+                                int64_t nbu = 1) {
     if (r <= NNF_MAX_RANK)
-        return launch_cost<OP>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, scale, out_f64, st, nullptr, 0, 1, nullptr, 0, 1, R1, R2, ldr);
+        return launch_cost<OP>(ctx, X, m, n, ldx, Ut, ldu, V, ldv, r, beta, scale, out_f64, st, nullptr, 0, 1, Ub, ldub, nbu, R1, R2, ldr);
     float* P = R1;
     int64_t ldp = ldr;
     size_t cap = 0;
@@ -1403,12 +1404,13 @@ static int launch_cost_any_rank(nnf_ctx* ctx, const float* X, int64_t m, int64_t
         const int rc = r - k0 < NNF_MAX_RANK ? r - k0 : NNF_MAX_RANK;
         const float* Uc = Ut + (int64_t)k0 * ldu;
         const float* Vc = V + (int64_t)k0 * ldv;
+        const float* Ubc = Ub ? Ub + (int64_t)k0 * ldub : nullptr;      // (CP cost: the second factor of the Khatri-Rao rows)
         int e;
         if (k0 + rc < r)
-            e = launch_cost<NNF_PROD>(ctx, X, m, n, ldx, Uc, ldu, Vc, ldv, rc, beta, scale, nullptr, st, nullptr, 0, 1, nullptr, 0, 1, P,
+            e = launch_cost<NNF_PROD>(ctx, X, m, n, ldx, Uc, ldu, Vc, ldv, rc, beta, scale, nullptr, st, nullptr, 0, 1, Ubc, ldub, nbu, P,
                                       nullptr, ldp, k0 ? P : nullptr, cap);
         else
-            e = launch_cost<OP>(ctx, X, m, n, ldx, Uc, ldu, Vc, ldv, rc, beta, scale, out_f64, st, nullptr, 0, 1, nullptr, 0, 1, R1, R2,
+            e = launch_cost<OP>(ctx, X, m, n, ldx, Uc, ldu, Vc, ldv, rc, beta, scale, out_f64, st, nullptr, 0, 1, Ubc, ldub, nbu, R1, R2,
                                 ldp, P, cap);
         if (e != NNF_OK) return e;
     }
@@ -1460,13 +1462,13 @@ extern "C" int nnf_cp3_betadiv_f32(nnf_ctx* ctx, const float* T, int64_t I, int6
     if (!ctx || !T || !Ft0 || !Ft1 || !Ft2 || !out_f64 || I < 1 || J < 1 || K < 1 || R < 1 || ld0 < I || ld1 < J ||
         ld2 < K || !(beta >= 0.0))
         return NNF_ERR_ARG;
-    if (R > NNF_MAX_RANK) return NNF_ERR_UNSUPPORTED;
     // T seen as an (I*J) x K matrix: row (i,j) of the left operand is F0[i,:].*F1[j,:] (generated while it is staged),
     // the right operand is F2^T as is.  I*J rows give the kernel its parallelism (one workgroup per 128 rows).
+    // (ranks above 128: the model is built up over rank chunks in a tensor-sized buffer, launch_cost_any_rank)
     const int64_t m = I * J;
     if (32 * K * 4 + 4 * (K + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-#define CP3(OP, B, SC) launch_cost<OP>(ctx, T, m, K, K, Ft0, ld0, Ft2, ld2, R, B, SC, out_f64, st, nullptr, 0, 1, Ft1, ld1, J)
+#define CP3(OP, B, SC) launch_cost_any_rank<OP>(ctx, T, m, K, K, Ft0, ld0, Ft2, ld2, R, B, SC, out_f64, st, nullptr, nullptr, 0, Ft1, ld1, J)
     if (beta == 2.0) return CP3(NNF_COST_FROB, 2.f, 0.5);
     if (beta == 1.0) return CP3(NNF_COST_KL, 1.f, 1.0);
     if (beta == 0.0) return CP3(NNF_COST_IS, 0.f, 1.0);

@@ -233,6 +233,10 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
         for (int a = t; a < r; a += 16) {
             const GT* ga = g + (size_t)a * gs;
             double ta = 0.0;
+            if (g_global && G2 != nullptr) {       // Hadamard Gram read in place (NTF at a rank above 128)
+                const float* gb = G2 + (size_t)a * ldg;
+                for (int b = 0; b < r; ++b) ta = __builtin_fma((double)((float)ga[b] * gb[b]), (double)vj[b], ta);
+            } else
             for (int b = 0; b < r; ++b) ta = __builtin_fma((double)ga[b], (double)vj[b], ta);
             const double va = (double)vj[a], p = va * (double)UtM[(int64_t)a * ldm + j];
             pA += p;
@@ -266,7 +270,11 @@ __global__ __launch_bounds__(256) void nnf_gram_cost_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) tot[i] = nnf_block_sum_f64(s[i], red);
     float gm = 0.f;
-    for (int e = threadIdx.x; e < r * r; e += 256) gm = fmaxf(gm, fabsf((float)g[(size_t)(e / r) * gs + (e % r)]));
+    for (int e = threadIdx.x; e < r * r; e += 256) {
+        float ge = (float)g[(size_t)(e / r) * gs + (e % r)];
+        if (g_global && G2 != nullptr) ge *= G2[(size_t)(e / r) * ldg + (e % r)];
+        gm = fmaxf(gm, fabsf(ge));
+    }
     gm = fmaxf(gm, __shfl_xor(gm, 1, 64));
     gm = fmaxf(gm, __shfl_xor(gm, 2, 64));
     gm = fmaxf(gm, __shfl_xor(gm, 4, 64));
@@ -301,7 +309,6 @@ static int gram_cost_launch(nnf_ctx* ctx, const float* V, int64_t ldv, const flo
     if (!(sigma_a >= 0.0) || !(bias_a >= 0.0) || !(sigma_g >= 0.0)) return NNF_ERR_ARG;
     if (UtU64 != nullptr && UtU_b != nullptr) return NNF_ERR_ARG;
     const int g_global = r > NNF_MAX_RANK ? 1 : 0;
-    if (g_global && UtU_b != nullptr) return NNF_ERR_UNSUPPORTED;   // (Hadamard Grams belong to NTF: ranks <= 128)
     hipStream_t st = (hipStream_t)stream;
     const int64_t nwg = nnf_cdiv(n, 16);
     if (nwg > (int64_t)1 << 24) return NNF_ERR_UNSUPPORTED;

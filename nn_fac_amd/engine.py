@@ -24,15 +24,16 @@ MAX_RANK = 128      # NNF_MAX_RANK of include/nnfac_hip.h: up to here one launch
 
 
 def check_rank(r, where):
-    """The reference accepts any rank up to min(shape) (nn_fac/nmf.py:175-178; nnls.py:156-170 loops `range(r)`).  The MATRIX
-    path (nmf, hals_nnls_acc, mu_betadivmin) follows it: above 128 the contractions and cost passes walk the rank in chunks of
-    128 and the sweeps run in the generic kernel ("Ranks above 128") -- callers of that path do not call
-    this.  The TENSOR kernels (MTTKRP, Tucker core contractions, the fused CP passes) are built for rank <= 128: said at the
-    boundary, before anything is uploaded or launched, instead of an NNF_ERR_UNSUPPORTED status from deep inside an iteration."""
+    """The reference accepts any rank up to min(shape) (nn_fac/nmf.py:175-178; nnls.py:156-170 loops `range(r)`).  The matrix
+    path (nmf, hals_nnls_acc, mu_betadivmin) and NTF (ntf, compute_ntf, one_ntf_step) follow it: above 128 the contractions,
+    MTTKRPs and cost passes walk the rank in chunks of 128 and the sweeps run in the generic kernel ("Ranks
+    above 128") -- callers on those paths do not call this.  The TUCKER kernels (core contractions along the middle axis, the
+    projected-gradient core update) are built for ranks <= 128: said at the boundary, before anything is uploaded or launched,
+    instead of an NNF_ERR_UNSUPPORTED status from deep inside an iteration."""
     r = int(r)
     if r > MAX_RANK:
-        raise EngineError(f"{where}: rank {r} is above the {MAX_RANK} the tensor kernels (MTTKRP, core contractions) of "
-                          f"nn_fac_amd are built for; matrix factorisations (nmf, hals_nnls_acc, mu_betadivmin) take any rank")
+        raise EngineError(f"{where}: rank {r} is above the {MAX_RANK} the Tucker kernels (core contractions, core update) of "
+                          f"nn_fac_amd are built for; nmf, ntf, hals_nnls_acc and mu_betadivmin take any rank")
 
 
 def _ptr(t):
@@ -674,6 +675,7 @@ class Engine:
         I, J, K = T.shape
         R = Ft[0].shape[0]
         o = out if out is not None else torch.empty(1, dtype=torch.float64, device=T.device)
+        self._model_scratch(I * J, K, R)
         _lib.check(self.lib.nnf_cp3_betadiv_f32(self.ctx, _ptr(T), I, J, K, _ptr(Ft[0]), _ld(Ft[0]), _ptr(Ft[1]),
                                                 _ld(Ft[1]), _ptr(Ft[2]), _ld(Ft[2]), R, float(beta), _ptr(o),
                                                 self._stream()), "nnf_cp3_betadiv_f32")

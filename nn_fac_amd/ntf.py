@@ -40,7 +40,6 @@ def ntf(tensor, rank, init="random", factors_0=[], n_iter_max=100, tol=1e-8,
         sparsity_coefficients=[], fixed_modes=[], normalize=[],
         verbose=False, return_costs=False):
     """Nonnegative PARAFAC of `tensor` (reference docstring: ntf.py:23-179)."""
-    _engine.check_rank(rank, "ntf")
     factors = []
     nb_modes = len(tensor.shape)
     if init.lower() == "custom":
@@ -465,7 +464,6 @@ def compute_ntf(tensor_in, rank, factors_in, n_iter_max=100, tol=1e-8,
                 sparsity_coefficients=[], fixed_modes=[], normalize=[],
                 verbose=False, return_costs=False, alpha=0.5, delta=0.01, sweep_log=None):
     """Outer loop of ntf.py:288-344.  Returns the list of factors (dim x R each) [, costs, toc]."""
-    _engine.check_rank(rank, "compute_ntf")
     dev = device_of(tensor_in, *factors_in)
     eng = _engine.get_engine(dev)
     T = to_dev(tensor_in, dev)
@@ -523,7 +521,6 @@ def one_ntf_step(unfolded_tensors, rank, in_factors, norm_tensor, update_rule, b
                  alpha=0.5, delta=0.01):
     """One pass over the modes (ntf.py:422-477).  `unfolded_tensors` is the reference's list of unfoldings; the tensor is
     rebuilt from the mode-0 unfolding (a plain reshape).  Returns (factors, cost)."""
-    _engine.check_rank(rank, "one_ntf_step")
     dev = device_of(*unfolded_tensors, *in_factors)
     eng = _engine.get_engine(dev)
     dims = [int(u.shape[0]) for u in unfolded_tensors]

@@ -54,17 +54,16 @@ def test_built_library_carries_the_default_build_switches(built_lib):
         assert got.get(unit) == flags, (unit, got.get(unit))
 
 
-def test_tensor_rank_above_the_kernels_limit_is_refused_at_the_boundary():
-    """The reference takes any rank up to min(shape) (nn_fac/nmf.py:175-178).  The matrix path follows it (rank chunks, generic
-    sweep kernel: tests/test_gpu_bigrank.py); the TENSOR kernels (MTTKRP, core contractions) stop at 128 and every drop-in
-    entry on that path says so before anything is uploaded or launched (also without a GPU), not as a bare status code."""
+def test_tucker_rank_above_the_kernels_limit_is_refused_at_the_boundary():
+    """The reference takes any rank up to min(shape) (nn_fac/nmf.py:175-178).  The matrix path and NTF follow it (rank chunks,
+    generic sweep kernel: tests/test_gpu_bigrank.py); the TUCKER kernels (core contractions, core update) stop at 128 and every
+    drop-in entry on that path says so before anything is uploaded or launched (also without a GPU), not as a bare status code."""
     from nn_fac_amd.utils.errors import EngineError
     from nn_fac_amd.update_rules.mu import mu_tensorial
-    from nn_fac_amd.ntf import ntf
     from nn_fac_amd.ntd import ntd
     rng = np.random.RandomState(0)
     r = 129
-    calls = [lambda: ntf(rng.rand(130, 131, 132), r, n_iter_max=1), lambda: ntd(rng.rand(130, 131, 132), [r, 4, 4], n_iter_max=1),
+    calls = [lambda: ntd(rng.rand(130, 131, 132), [r, 4, 4], n_iter_max=1),
              lambda: mu_tensorial(rng.rand(r, 4, 4), [rng.rand(130, r), rng.rand(131, 4), rng.rand(132, 4)], rng.rand(130, 131, 132), 1)]
     for f in calls:
         with pytest.raises(EngineError, match="rank 129 is above the 128"):

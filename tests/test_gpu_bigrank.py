@@ -157,3 +157,45 @@ def test_nmf_driver_at_rank_130_random_init(built_lib):
     assert all(b <= a * (1 + 1e-4) for a, b in zip(costs, costs[1:]))
     want = np.linalg.norm(X.astype(np.float64) - U.astype(np.float64) @ V.astype(np.float64)) ** 2      # nmf.py:452, no sparsity
     assert abs(costs[-1] - want) <= 1e-3 * want
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_mttkrp_and_cp_cost_above_rank_128(eng, mode):
+    rng = np.random.RandomState(11 + mode)
+    I, J, K, R = 60, 70, 90, 150
+    T = rng.rand(I, J, K).astype(np.float32) + 0.05
+    F = [(rng.rand(d, R) / np.sqrt(R)).astype(np.float32) for d in (I, J, K)]
+    Ft = [dev(f.T) for f in F]
+    Td = torch.from_numpy(T).cuda()
+    F64 = [f.astype(np.float64) for f in F]
+    want = orc.unfold(T.astype(np.float64), mode) @ orc.khatri_rao(F64, skip_matrix=mode)
+    assert rel(eng.mttkrp3(Td, Ft, mode).cpu().numpy().T, want) < 1e-5
+    if mode == 0:
+        model = (F64[0] @ orc.khatri_rao(F64, skip_matrix=0).T).reshape(T.shape)
+        for beta in (2, 1, 0.5):
+            w = orc.beta_divergence(T.astype(np.float64), model, beta)
+            g = float(eng.cp3_betadiv(Td, Ft, beta))
+            assert abs(g - w) <= 2e-5 * abs(w), (beta, g, w)
+        Y = eng.ttm3(Td, Ft[2], 2)                      # R x I x J
+        assert rel(Y.cpu().numpy(), np.einsum("ijk,kr->rij", T.astype(np.float64), F64[2])) < 1e-5
+        for axis, other in ((2, 1), (1, 0)):
+            got = eng.mttkrp3_from_partial(Y, Ft[other], axis).cpu().numpy()
+            y = Y.cpu().numpy().astype(np.float64)
+            ref = np.einsum("rab,rb->ra", y, F64[1].T) if axis == 2 else np.einsum("rab,ra->rb", y, F64[0].T)
+            assert rel(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("rule,beta", [("hals", 2), ("mu", 1), ("mu", 2)])
+def test_ntf_at_rank_140_vs_oracle(built_lib, rule, beta):
+    """NTF above rank 128 (the reference puts no limit on the CP rank): MTTKRPs and cost passes in rank chunks, sweeps in the
+    generic kernel; against the fp64 oracle on a 150 x 141 x 160 tensor."""
+    from nn_fac_amd.ntf import compute_ntf
+    shape, R = (150, 141, 160), 140
+    T, F0 = orc.synth_ntf(shape, R, seed=5, dtype=np.float32)
+    kw = dict(n_iter_max=3, tol=0, update_rule=rule, beta=beta, alpha=math.inf, sparsity_coefficients=[None] * 3,
+              normalize=[False] * 3, return_costs=True)
+    F, costs, _ = compute_ntf(T, R, [f.copy() for f in F0], **kw)
+    Fo, co, _ = orc.compute_ntf(T.astype(np.float64), R, [f.astype(np.float64) for f in F0], **kw)
+    for a, b in zip(F, Fo):
+        assert rel(a, b) < 1e-3
+    np.testing.assert_allclose(costs, co, rtol=2e-3)

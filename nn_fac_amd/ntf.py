@@ -188,7 +188,10 @@ def _ntf_cost(eng, st, Ft, update_rule, beta, sparsity_coefficients, cost, fuse_
     sharded = _dist.is_sharded(st.group)
     if ident is not None:
         mode, rhs_t, Ga, Gb = ident
-        eng.gram_cost(Ft[mode], rhs_t, Ga, st.norm2, cost[0:3], UtU_b=Gb)
+        # rounding of an MTTKRP entry, measured at 500^3 rank 30 and 300 x 200 x 1000 rank 64 (tools/probes/mttkrp_rounding_probe.py,
+        # profiles/r04_mttkrp_rounding.txt): 3.5e-8 ... 5.1e-8 relative rms, |mean| <= 7.5e-10 -- its split-K chains are short
+        # (a workgroup sums a few hundred slices); the estimate assumes 6e-8 and a mean of 1e-9
+        eng.gram_cost(Ft[mode], rhs_t, Ga, st.norm2, cost[0:3], UtU_b=Gb, rounding=(6e-8, 1e-9))
     elif update_rule == "hals" and fuse_next and hasattr(eng, "cp3_partial_cost") \
             and Ft[0].shape[0] <= getattr(eng, "CP3_FUSED_MAX_RANK", 0):
         st.cost_and_partial(Ft, cost[0:1])           # ||T - model||^2

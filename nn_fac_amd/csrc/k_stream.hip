@@ -460,7 +460,7 @@ __device__ __forceinline__ void nnf_xht_body(const float* __restrict__ X, int64_
 // (8 row tiles against 6.1 on average).  The first n_hi workgroups take NTH tiles per wave, the others NTH-1, chosen
 // on the host so that one full round of resident workgroups covers the matrix (7 tiles on the busiest SIMD).
 template <int MT, int REM, bool VEC, int NTH>
-__global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 2 : 1)) void nnf_xht_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+__global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 || NTH <= 2 ? 2 : 1)) void nnf_xht_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                          const float* __restrict__ V, int64_t ldv, int r,
                                                          float* __restrict__ out, int64_t ldo, int a_vec_ok, int n_hi) {
     constexpr int MTA = MT + (REM > 0 ? 1 : 0);
@@ -482,7 +482,18 @@ static int launch_xht(nnf_ctx* ctx, nnf_ws_cursor&, const float* X, int64_t m, i
     const int64_t T = nnf_cdiv(m, 16), waves = 4 * slots;
     int nth = 4;
     int64_t n_hi, grid;
-    if (T > 4 * waves) {            // several rounds: 256-row workgroups
+    // six and more rank tiles (ranks 96 ... 128), many rounds: TWO row tiles per wave keep a wave at 248 registers, so that two
+    // workgroups share a CU -- the four-tile form needs 404 (256 + 148 accumulation registers) and runs one wave per SIMD.
+    // Measured (tools/probes/xht_nt2_probe.py, four -> two tiles): rank 100, 10^6 x 4000 7.16 -> 6.56 ms (0.71 -> 0.775 of the MFMA
+    // peak), 500000 rows 3.58 -> 3.47, 250000 1.79 -> 1.73; rank 96 x 600000 2.17 -> 2.05; ranks 112 / 128 x 10^6 -4 % / -2 %;
+    // below ~230000 rows (125000: 0.97 -> 1.00) and at five rank tiles (rank 80: 2.75 -> 2.79) the four-tile form stays ahead.
+    // NNF_XHT_NT2=0 / 1 forces either form (A/B on one box).
+    static const int nt2 = [] { const char* e = getenv("NNF_XHT_NT2"); return e ? atoi(e) : -1; }();
+    const bool two_tiles = MT + (REM > 0) > 4 && T > 4 * waves && (nt2 >= 0 ? nt2 != 0 : (MT + (REM > 0) >= 6 && T > 14 * waves));
+    if (two_tiles) {
+        nth = 2;
+        n_hi = grid = nnf_cdiv(m, 128);
+    } else if (T > 4 * waves) {            // several rounds: 256-row workgroups
         n_hi = grid = nnf_cdiv(m, 256);
     } else if (T > 2 * waves) {     // one round: (4,3) or (3,2) tiles per wave
         nth = T > 3 * waves ? 4 : 3;
@@ -498,7 +509,11 @@ static int launch_xht(nnf_ctx* ctx, nnf_ws_cursor&, const float* X, int64_t m, i
     if (nth == 4)
         hipLaunchKernelGGL((nnf_xht_kernel<MT, REM, VEC, 4>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
                            a_vec_ok, (int)n_hi);
-    else
+    else if (nth == 2) {
+        if constexpr (MT + (REM > 0) > 4)
+            hipLaunchKernelGGL((nnf_xht_kernel<MT, REM, VEC, 2>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
+                               a_vec_ok, (int)n_hi);
+    } else
         hipLaunchKernelGGL((nnf_xht_kernel<MT, REM, VEC, 3>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
                            a_vec_ok, (int)n_hi);
     NNF_CHECK_LAUNCH();

@@ -24,7 +24,16 @@
 #ifndef XHT_ABL
 #define XHT_ABL 0   // timing-only ablations of nnf_xht_kernel (tools/xht_ablate.sh); 0 = the product
 #endif
-NNF_BUILD_FLAGS(k_stream, "XHT_ABL=" NNF_STR(XHT_ABL))
+#ifndef XTY_BIG_WG
+#define XTY_BIG_WG 2   // resident workgroups per CU the W^T X kernel of five or six rank tiles is compiled for (A/B: tools/abl_build.sh)
+#endif
+// W^T X, workgroups per CU by rank tiles: up to four tiles three (<= 168 registers); five and six tiles (ranks 65 ... 100) TWO --
+// the kernel fits 256 registers there (rank 100: 4 spilled outside the loop) where it took 348 for one wave per SIMD: 6.54 -> 6.34 ms
+// at 10^6 x 4000 rank 100, 0.98 -> 0.96 at 125000 rows (tools/probes/xty_occ_probe.py); seven and eight tiles spill 57-89
+// registers at 256 and stay at one.
+template <int MT, int REM>
+constexpr int nnf_xty_wg_per_cu() { return MT + (REM > 0) <= 4 ? 3 : (MT <= 6 ? XTY_BIG_WG : 1); }
+NNF_BUILD_FLAGS(k_stream, "XHT_ABL=" NNF_STR(XHT_ABL) " XTY_BIG_WG=" NNF_STR(XTY_BIG_WG))
 
 // =========================================================================================================
 // xty: slab[ks][rk][j] = sum_{i in split ks} Ut[rk][i] * X[i][j]
@@ -35,7 +44,7 @@ NNF_BUILD_FLAGS(k_stream, "XHT_ABL=" NNF_STR(XHT_ABL))
 // is otherwise idle here (fp32 MFMA and fp32 VALU have the same peak on gfx950, so padding r=50 to 64 would burn 22 % of
 // the MFMA time on zeros).  The leftover rows' operand is the (MT+1)-th tile of the same LDS image, read as a broadcast.
 template <int MT, int REM, bool VEC>
-__global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 ? 3 : 1)) void nnf_xty_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
+__global__ __launch_bounds__(256, (nnf_xty_wg_per_cu<MT, REM>())) void nnf_xty_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                          const float* __restrict__ Ut, int64_t ldu, int r,
                                                          float* __restrict__ slabs, int64_t ldp, int ncb, int nsplit,
                                                          int64_t rows_per_split, int a_vec_ok) {
@@ -287,7 +296,7 @@ static int launch_xty(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t 
                       int64_t ldu, float* out, int64_t ldo, hipStream_t st) {
     const int ncb = (int)nnf_cdiv(n, 256);
     const int64_t ldp = nnf_rup(n, 4);
-    int64_t target = (MT + (REM > 0) <= 4 ? 3 : 1) * (int64_t)ctx->num_cus / ncb;   // resident workgroups per CU
+    int64_t target = nnf_xty_wg_per_cu<MT, REM>() * (int64_t)ctx->num_cus / ncb;   // resident workgroups per CU
     if (target < 1) target = 1;
     int64_t nsplit = target;
     // a workgroup sums its rows in fp32 (MFMA accumulators); the slabs are added in fp64.  Cap the rows per workgroup: at

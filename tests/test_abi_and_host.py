@@ -46,7 +46,7 @@ def test_built_library_carries_the_default_build_switches(built_lib):
     hals = "HALS_LATE_ISSUE=1 HALS_MID_AT(R)=((R) - 1) HALS_DBG=0"
     quad = "QUAD_MID_SEL=1 HALS_LATE_ISSUE=1"
     mu = "MU_WG_PER_CU=2 MU_STEP_FENCE()=__builtin_amdgcn_sched_barrier(0)"
-    want = {"k_stream": "XHT_ABL=0", "k_mttkrp": "SEG_ABL=0 MTTKRP_ABL=0", "k_hals_wave": "WAVE_DBG=0 WAVE_REFRESH_V=8",
+    want = {"k_stream": "XHT_ABL=0 XTY_BIG_WG=2", "k_mttkrp": "SEG_ABL=0 MTTKRP_ABL=0", "k_hals_wave": "WAVE_DBG=0 WAVE_REFRESH_V=8",
             "k_hals_mfma": "MFMA_NREF_V=32 MFMA_EARLY=1 MFMA_DBG=0",
             **{f"k_hals_fast{i}": hals for i in range(4)}, **{f"k_hals_quad{i}": quad for i in range(4)},
             **{f"k_mu{i}": mu for i in range(3)}}

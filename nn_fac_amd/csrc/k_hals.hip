@@ -62,7 +62,10 @@ __global__ void nnf_hals_prep_kernel(const float* __restrict__ UtU, int64_t ldg,
 // GCOL (ranks above NNF_MAX_RANK, where r x 128 columns no longer fit the LDS): a thread's column is the column of V itself
 // in global memory -- read and written in place, coalesced across the threads of a wave, served by L1/L2 (a workgroup's
 // r x 128 block of V is 100 KB at rank 200); no load / store phase.  Same arithmetic in the same order as the LDS form.
-template <int MODE, bool GCOL>
+// BIG (ranks above NNF_MAX_RANK): the row's dot product in eight independent partial sums over batches of eight entries -- the
+// loads of a batch go out together (a plain `dot = fmaf(G[i], v[i], dot)` waits for one LDS / memory round trip per entry: 43 ns
+// per entry at rank 200, 1.7 ms per sweep).  Up to NNF_MAX_RANK the sum keeps the reference's order (nnls.py:162: np.dot).
+template <int MODE, bool GCOL, bool BIG = GCOL>
 __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __restrict__ UtM, int64_t ldm,
                                                                const float* __restrict__ Gp, const float* __restrict__ dinv,
                                                                int RP, float* __restrict__ V, int64_t ldv, int r,
@@ -96,6 +99,20 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
             const float di = dinv[2 * k];
             if (di != 0.f) {
                 float dot = 0.f;
+                if constexpr (BIG) {
+                    const float* gk = Gp + (size_t)k * RP;
+                    float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    int i = 0;
+                    for (; i + 8 <= r; i += 8) {
+                        float gv[8], vv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { gv[u] = gk[i + u]; vv[u] = mycol[(int64_t)(i + u) * cs]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) d[u] = fmaf(gv[u], vv[u], d[u]);
+                    }
+                    for (; i < r; ++i) d[i & 7] = fmaf(gk[i], mycol[(int64_t)i * cs], d[i & 7]);
+                    dot = ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+                } else
                 for (int i = 0; i < r; ++i) dot = fmaf(Gp[k * RP + i], mycol[i * cs], dot);
                 const float vk = mycol[k * cs];
                 float step = fmaxf((UtM[(int64_t)k * ldm + col0] - dot - sp) * di, -vk);
@@ -334,22 +351,32 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
         if (nsweeps == 0) return NNF_OK;
     } else if (generic) {
         // one column per thread, all workgroups resident (row-level grid reductions)
-        const size_t shm = (big_rank ? (size_t)0 : (size_t)r * 128 * 4) + 16 + 3 * 2 * 8 + 64;
-        int nb = 0;
-        hipError_t he;
-        if (big_rank) {
-            he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_generic_kernel<MODE, true>, 128, shm);
-        } else {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_generic_kernel<MODE, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_generic_kernel<MODE, false>, 128, shm);
-        }
-        if (he != hipSuccess || nb < 1) return NNF_ERR_LAUNCH;
-        int bpc = nb >= 3 ? nb - 1 : nb;
-        if (bpc > 4) bpc = 4;
         const int64_t grid = nnf_cdiv(ncols, 128);
         // blind sweeps without row-level reductions exchange nothing: no residency needed (any number of columns)
         const bool exchanges = MODE == 0 || (flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) != 0;
+        // the column in LDS (r x 128 floats per workgroup) while that fits and -- when the workgroups exchange -- all of them are
+        // resident with it; else (ranks above ~300, or more columns than one LDS-bound workgroup per CU holds) the column stays
+        // in global memory (GCOL).  Measured at rank 200 (tools/probes/bigrank_sweep_probe.py): LDS 3-5x faster per sweep.
+        static const int force_gcol = [] { const char* e = getenv("NNF_HALS_GCOL"); return e ? atoi(e) : 0; }();   // A/B knob
+        const size_t shm_lds = (size_t)r * 128 * 4 + 16 + 3 * 2 * 8 + 64, shm_g = 16 + 3 * 2 * 8 + 64;
+        bool gcol = big_rank && (force_gcol || shm_lds > (size_t)150 * 1024);
+        int nb = 0;
+        hipError_t he = hipSuccess;
+        if (!gcol && big_rank) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_generic_kernel<MODE, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_lds);
+            he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_generic_kernel<MODE, false, true>, 128, shm_lds);
+        } else if (!gcol) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_generic_kernel<MODE, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_lds);
+            he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_generic_kernel<MODE, false>, 128, shm_lds);
+            if (big_rank && (he != hipSuccess || nb < 1 || (exchanges && grid > (int64_t)(nb >= 3 ? nb - 1 : nb) * ctx->num_cus))) gcol = true;
+        }
+        if (gcol) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_generic_kernel<MODE, true>, 128, shm_g);
+        if (he != hipSuccess || nb < 1) return NNF_ERR_LAUNCH;
+        const size_t shm = gcol ? shm_g : shm_lds;
+        int bpc = nb >= 3 ? nb - 1 : nb;
+        if (bpc > 4) bpc = 4;
         if ((exchanges && grid > (int64_t)bpc * ctx->num_cus) || grid > (exchanges ? (int64_t)max_blocks : (int64_t)0x7fffffff))
             return NNF_ERR_UNSUPPORTED;
         if (!exchanges && MODE == 1 && grid > max_blocks) {   // the per-sweep partial sums: one double per workgroup and sweep
@@ -357,8 +384,12 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
             if (!sweep_partials) return NNF_ERR_WORKSPACE;
         }
         nblocks = (int)grid;
-        if (big_rank)
+        if (getenv("NNF_HALS_DEBUG")) fprintf(stderr, "[nnf hals] generic: %s, %d workgroups, %d per CU\n", gcol ? "columns in global memory" : "columns in LDS", nblocks, bpc);
+        if (gcol)
             hipLaunchKernelGGL((nnf_hals_generic_kernel<MODE, true>), dim3(nblocks), dim3(128), shm, st, UtM, ldm, Gp, dinv, RS, V,
+                               ldv, r, ncols, nsweeps, delta, sp, flags, sy, status, sweep_partials, sweep0, snapshots, snap_stride, snap_first);
+        else if (big_rank)
+            hipLaunchKernelGGL((nnf_hals_generic_kernel<MODE, false, true>), dim3(nblocks), dim3(128), shm, st, UtM, ldm, Gp, dinv, RS, V,
                                ldv, r, ncols, nsweeps, delta, sp, flags, sy, status, sweep_partials, sweep0, snapshots, snap_stride, snap_first);
         else
             hipLaunchKernelGGL((nnf_hals_generic_kernel<MODE, false>), dim3(nblocks), dim3(128), shm, st, UtM, ldm, Gp, dinv, RS, V,

@@ -73,26 +73,35 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
                                                                unsigned flags, hals_sync sy, double* __restrict__ status,
                                                                double* __restrict__ sweep_partials, int sweep0,
                                                                float* __restrict__ snapshots, int64_t snap_stride, int snap_first) {
+    // LPC lanes per column.  BIG with the column in LDS: FOUR (lane q of a quad takes the entries i = q (mod 4) of a row's dot
+    // product, two shuffles add the quarters -- the same bits in all four lanes -- every lane forms the step, lane 0 keeps it):
+    // a thread's dependent chain is r*r/4 entries instead of r*r, and a workgroup's 32 columns are r x 32 floats of LDS, so
+    // that several workgroups share a CU.  The lanes of a column sit in one wave, whose LDS operations execute in order.
+    constexpr int LPC = (BIG && !GCOL) ? 4 : 1;
+    constexpr int CW = 128 / LPC;                                     // columns per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* vl = reinterpret_cast<float*>(smem);                       // [r][128]  (GCOL: unused)
-    double* red = reinterpret_cast<double*>(smem + (GCOL ? (size_t)0 : (size_t)r * 128 * 4) + 16);
+    float* vl = reinterpret_cast<float*>(smem);                       // [r][CW]  (GCOL: unused)
+    double* red = reinterpret_cast<double*>(smem + (GCOL ? (size_t)0 : (size_t)r * CW * 4) + 16);
     __shared__ unsigned lds_flag;
     const int nblocks = gridDim.x;
-    const int64_t gthreads = (int64_t)nblocks * 128;
-    const int64_t gtid = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    const int q = threadIdx.x % LPC;                                  // this lane's share of a column (0: the lane that keeps it)
+    const int64_t gcolumn = (int64_t)blockIdx.x * CW + threadIdx.x / LPC;
     const bool rowsync = (flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) != 0;
-    // with row-level grid reductions every thread must take part in every exchange: one column per thread only
-    const bool active = gtid < ncols;
+    // with row-level grid reductions every thread must take part in every exchange: one column per thread (quad) only
+    const bool active = gcolumn < ncols;
+    const bool owner = active && q == 0;
     unsigned epoch = 0;
     double eps0 = 0.0, eps = 1.0;
     int done = 0, err = 0;
     bool ok = true;
     if (MODE == 0 && sweep0 > 0 && !hals_take_over(status, sweep0, delta, eps0, eps)) return;
-    const int64_t col0 = active ? gtid : 0;
-    float* mycol = GCOL ? V + col0 : vl + threadIdx.x;               // element k of the column: mycol[k * cs]
-    const int64_t cs = GCOL ? ldv : 128;
-    if constexpr (!GCOL)
-        for (int k = 0; k < r; ++k) mycol[k * 128] = active ? V[(int64_t)k * ldv + col0] : 0.f;
+    const int64_t col0 = active ? gcolumn : 0;
+    float* mycol = GCOL ? V + col0 : vl + threadIdx.x / LPC;         // element k of the column: mycol[k * cs]
+    const int64_t cs = GCOL ? ldv : CW;
+    if constexpr (!GCOL) {
+        for (int k = q; k < r; k += LPC) mycol[k * CW] = active ? V[(int64_t)k * ldv + col0] : 0.f;
+        if constexpr (LPC > 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
     for (int s = 1; s <= max_sweeps && ok; ++s) {
         double nd = 0.0;
         for (int k = 0; k < r; ++k) {
@@ -102,32 +111,48 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
                 if constexpr (BIG) {
                     const float* gk = Gp + (size_t)k * RP;
                     float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    int i = 0;
-                    for (; i + 8 <= r; i += 8) {
+                    int i = q;
+                    for (; i + 7 * LPC < r; i += 8 * LPC) {                    // eight entries of this lane: i, i + LPC, ...
                         float gv[8], vv[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { gv[u] = gk[i + u]; vv[u] = mycol[(int64_t)(i + u) * cs]; }
+                        for (int u = 0; u < 8; ++u) { gv[u] = gk[i + u * LPC]; vv[u] = mycol[(int64_t)(i + u * LPC) * cs]; }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) d[u] = fmaf(gv[u], vv[u], d[u]);
                     }
-                    for (; i < r; ++i) d[i & 7] = fmaf(gk[i], mycol[(int64_t)i * cs], d[i & 7]);
+                    for (int u = 0; i < r; i += LPC, ++u) d[u & 7] = fmaf(gk[i], mycol[(int64_t)i * cs], d[u & 7]);
                     dot = ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+                    if constexpr (LPC > 1) {
+                        dot += __shfl_xor(dot, 1, 64);
+                        dot += __shfl_xor(dot, 2, 64);
+                    }
                 } else
                 for (int i = 0; i < r; ++i) dot = fmaf(Gp[k * RP + i], mycol[i * cs], dot);
                 const float vk = mycol[k * cs];
                 float step = fmaxf((UtM[(int64_t)k * ldm + col0] - dot - sp) * di, -vk);
                 if (!active) step = 0.f;
-                if (!GCOL || active) mycol[k * cs] = vk + step;
-                nd += (double)step * (double)step;
+                if constexpr (LPC > 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (every lane of the quad has read v[k])
+                    if (q == 0) mycol[k * cs] = vk + step;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if (q == 0) nd += (double)step * (double)step;
+                } else {
+                    if (!GCOL || active) mycol[k * cs] = vk + step;
+                    nd += (double)step * (double)step;
+                }
             } else if (flags & NNF_HALS_NONZERO) {
                 err = 2;   // nnls.py:176-177
             }
             if (rowsync) {
                 const float vk = mycol[k * cs];
                 double vmax = 0.0;
-                if (flags & NNF_HALS_NONZERO)
-                    for (int i = 0; i < r; ++i) vmax = fmax(vmax, (double)mycol[i * cs]);
-                double mine[3] = {active ? (double)vk * (double)vk : 0.0, (active && vk != 0.f) ? 1.0 : 0.0,
+                if (flags & NNF_HALS_NONZERO) {
+                    for (int i = q; i < r; i += LPC) vmax = fmax(vmax, (double)mycol[i * cs]);
+                    if constexpr (LPC > 1) {
+                        vmax = fmax(vmax, __shfl_xor(vmax, 1, 64));
+                        vmax = fmax(vmax, __shfl_xor(vmax, 2, 64));
+                    }
+                }
+                double mine[3] = {owner ? (double)vk * (double)vk : 0.0, (owner && vk != 0.f) ? 1.0 : 0.0,
                                   active ? vmax : -1.0e300};
                 double tot[3];
                 const double b0 = nnf_block_sum_f64(mine[0], red);
@@ -143,8 +168,9 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
                 if (threadIdx.x != 0) { pub[0] = 0; pub[1] = 0; }
                 ok = grid_exchange<3>(sy, ++epoch, nblocks, pub, tot, red, &lds_flag);
                 if (!ok) break;
-                if ((flags & NNF_HALS_NONZERO) && di != 0.f && tot[1] == 0.0 && active)
+                if ((flags & NNF_HALS_NONZERO) && di != 0.f && tot[1] == 0.0 && owner)
                     mycol[k * cs] = (float)(1e-16 * tot[2]);            // nnls.py:173-174
+                if constexpr (LPC > 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (flags & NNF_HALS_NORMALIZE) {
                     // the norm is taken after the NONZERO refill (nnls.py:179-185)
                     double nsq = tot[0];
@@ -152,10 +178,11 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
                         const double f = 1e-16 * tot[2];
                         nsq = f * f * (double)ncols;
                     }
-                    if (active) {
+                    if (owner) {
                         if (nsq != 0.0) mycol[k * cs] = (float)((double)mycol[k * cs] / sqrt(nsq));
                         else mycol[k * cs] = (float)(1.0 / sqrt((double)ncols));
                     }
+                    if constexpr (LPC > 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 }
             }
         }
@@ -166,7 +193,7 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
             if (threadIdx.x == 0) sweep_partials[(size_t)(s - 1) * nblocks + blockIdx.x] = bs;
             if (snapshots != nullptr && s > snap_first && active) {   // block s - 1 - snap_first: V after sweep s
                 float* sn = snapshots + (int64_t)(s - 1 - snap_first) * snap_stride + col0;
-                for (int k = 0; k < r; ++k) sn[(int64_t)k * ncols] = mycol[k * cs];
+                for (int k = q; k < r; k += LPC) sn[(int64_t)k * ncols] = mycol[k * cs];
             }
         } else {
             double mine[1] = {bs}, tot[1];
@@ -178,7 +205,7 @@ __global__ __launch_bounds__(128) void nnf_hals_generic_kernel(const float* __re
         }
     }
     if (!GCOL && active)
-        for (int k = 0; k < r; ++k) V[(int64_t)k * ldv + col0] = mycol[k * 128];
+        for (int k = q; k < r; k += LPC) V[(int64_t)k * ldv + col0] = mycol[k * CW];
     if (blockIdx.x == 0 && threadIdx.x == 0 && status) {
         if (MODE == 0 && max_sweeps >= 1) {
             status[NNF_HALS_ST_EPS] = eps;
@@ -351,15 +378,16 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
         if (nsweeps == 0) return NNF_OK;
     } else if (generic) {
         // one column per thread, all workgroups resident (row-level grid reductions)
-        const int64_t grid = nnf_cdiv(ncols, 128);
         // blind sweeps without row-level reductions exchange nothing: no residency needed (any number of columns)
         const bool exchanges = MODE == 0 || (flags & (NNF_HALS_NORMALIZE | NNF_HALS_NONZERO)) != 0;
         // the column in LDS (r x 128 floats per workgroup) while that fits and -- when the workgroups exchange -- all of them are
         // resident with it; else (ranks above ~300, or more columns than one LDS-bound workgroup per CU holds) the column stays
         // in global memory (GCOL).  Measured at rank 200 (tools/probes/bigrank_sweep_probe.py): LDS 3-5x faster per sweep.
         static const int force_gcol = [] { const char* e = getenv("NNF_HALS_GCOL"); return e ? atoi(e) : 0; }();   // A/B knob
-        const size_t shm_lds = (size_t)r * 128 * 4 + 16 + 3 * 2 * 8 + 64, shm_g = 16 + 3 * 2 * 8 + 64;
+        const int cw_lds = big_rank ? 32 : 128;            // columns per workgroup with the column in LDS (four lanes per column above rank 128)
+        const size_t shm_lds = (size_t)r * cw_lds * 4 + 16 + 3 * 2 * 8 + 64, shm_g = 16 + 3 * 2 * 8 + 64;
         bool gcol = big_rank && (force_gcol || shm_lds > (size_t)150 * 1024);
+        int64_t grid = nnf_cdiv(ncols, cw_lds);
         int nb = 0;
         hipError_t he = hipSuccess;
         if (!gcol && big_rank) {
@@ -370,13 +398,17 @@ static int hals_entry(nnf_ctx* ctx, const float* UtM, int64_t ldm, const float* 
             hipFuncSetAttribute(reinterpret_cast<const void*>(&nnf_hals_generic_kernel<MODE, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_lds);
             he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_generic_kernel<MODE, false>, 128, shm_lds);
-            if (big_rank && (he != hipSuccess || nb < 1 || (exchanges && grid > (int64_t)(nb >= 3 ? nb - 1 : nb) * ctx->num_cus))) gcol = true;
+            if (big_rank && (he != hipSuccess || nb < 1 ||
+                             (exchanges && (grid > max_blocks || grid > (int64_t)(nb >= 3 ? nb - 1 : nb) * ctx->num_cus)))) gcol = true;
         }
-        if (gcol) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_generic_kernel<MODE, true>, 128, shm_g);
+        if (gcol) {
+            grid = nnf_cdiv(ncols, 128);
+            he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nnf_hals_generic_kernel<MODE, true>, 128, shm_g);
+        }
         if (he != hipSuccess || nb < 1) return NNF_ERR_LAUNCH;
         const size_t shm = gcol ? shm_g : shm_lds;
         int bpc = nb >= 3 ? nb - 1 : nb;
-        if (bpc > 4) bpc = 4;
+        if (bpc > 4 && !(big_rank && !gcol)) bpc = 4;
         if ((exchanges && grid > (int64_t)bpc * ctx->num_cus) || grid > (exchanges ? (int64_t)max_blocks : (int64_t)0x7fffffff))
             return NNF_ERR_UNSUPPORTED;
         if (!exchanges && MODE == 1 && grid > max_blocks) {   // the per-sweep partial sums: one double per workgroup and sweep

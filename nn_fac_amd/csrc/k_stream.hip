@@ -27,12 +27,13 @@
 #ifndef XTY_BIG_WG
 #define XTY_BIG_WG 2   // resident workgroups per CU the W^T X kernel of five or six rank tiles is compiled for (A/B: tools/abl_build.sh)
 #endif
-// W^T X, workgroups per CU by rank tiles: up to four tiles three (<= 168 registers); five and six tiles (ranks 65 ... 100) TWO --
-// the kernel fits 256 registers there (rank 100: 4 spilled outside the loop) where it took 348 for one wave per SIMD: 6.54 -> 6.34 ms
-// at 10^6 x 4000 rank 100, 0.98 -> 0.96 at 125000 rows (tools/probes/xty_occ_probe.py); seven and eight tiles spill 57-89
-// registers at 256 and stay at one.
+// W^T X, workgroups per CU by rank tiles: up to four tiles three (<= 168 registers); five and six tiles (ranks 65 ... 98) TWO --
+// the kernel fits 256 registers there without a spill where the compiler took up to 348 for one wave per SIMD.  Six tiles + four
+// leftover ranks (rank 100) and seven / eight tiles stay at one: at 256 registers rank 100 spills 4 and -- worse -- waits for a
+// staging load inside the chunk loop (a full drain of the X prefetch ring per trip, tools/check_loop_drains.py), for 6.54 -> 6.34 ms
+// at 10^6 x 4000 (tools/probes/xty_occ_probe.py): not taken.
 template <int MT, int REM>
-constexpr int nnf_xty_wg_per_cu() { return MT + (REM > 0) <= 4 ? 3 : (MT <= 6 ? XTY_BIG_WG : 1); }
+constexpr int nnf_xty_wg_per_cu() { return MT + (REM > 0) <= 4 ? 3 : ((MT <= 6 && !(MT == 6 && REM == 4)) ? XTY_BIG_WG : 1); }
 NNF_BUILD_FLAGS(k_stream, "XHT_ABL=" NNF_STR(XHT_ABL) " XTY_BIG_WG=" NNF_STR(XTY_BIG_WG))
 
 // =========================================================================================================
@@ -345,7 +346,10 @@ static int launch_xty(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t 
 template <int MT, int REM, bool VEC, int NT>
 __device__ __forceinline__ void nnf_xht_body(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                              const float* __restrict__ V, int64_t ldv, int r, float* __restrict__ out,
-                                             int64_t ldo, int a_vec_ok, int64_t row0, f32x4 (*ldsA)[(MT + (REM > 0 ? 1 : 0)) * 256]) {
+                                             int64_t ldo, int a_vec_ok, int64_t row0, f32x4 (*ldsA)[(MT + (REM > 0 ? 1 : 0)) * 256],
+                                             int q0 = 0, int q1 = -1, int64_t oshift = 0) {
+    // [q0, q1): the 64-column chunks this call contracts (default: all of them; a sub-range = a k-split share, see the kernel);
+    // row i of the result goes to column i - oshift of `out` (a share's slab starts at the first k-split row)
     constexpr int MTA = MT + (REM > 0 ? 1 : 0);
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ii = lane & 15, g = lane >> 4;
@@ -356,7 +360,7 @@ __device__ __forceinline__ void nnf_xht_body(const float* __restrict__ X, int64_
     const rsrc_t rs = nnf_make_rsrc(X + (rows > 0 ? i0w : 0) * ldx, bytes);
     const int voff = (int)(((int64_t)ii * ldx + 4 * g) * 4);
     const int ldx4 = (int)(ldx * 4);
-    const int nchunk = (int)((n + 63) >> 6);
+    const int nchunk = q1 >= 0 ? q1 : (int)((n + 63) >> 6);
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -371,15 +375,15 @@ __device__ __forceinline__ void nnf_xht_body(const float* __restrict__ X, int64_
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) ev[rr][nt] = 0.f;
 
-    stageA_load<MTA>(V, ldv, r, n, 0, a_vec_ok, areg);
+    stageA_load<MTA>(V, ldv, r, n, 64 * (int64_t)q0, a_vec_ok, areg);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 64 * t);
-    stageA_store<MTA>(ldsA[0], areg);
+        for (int nt = 0; nt < NT; ++nt) xb[t][nt] = nnf_bload4<VEC>(rs, voff, nt * 16 * ldx4 + 256 * q0 + 64 * t);
+    stageA_store<MTA>(ldsA[q0 & 1], areg);
     __syncthreads();
 
-    for (int q = 0; q < nchunk; ++q) {
+    for (int q = q0; q < nchunk; ++q) {
         const f32x4* img = ldsA[q & 1];
         stageA_load<MTA>(V, ldv, r, n, 64 * (int64_t)(q + 1), a_vec_ok, areg);
 #pragma unroll
@@ -445,7 +449,7 @@ __device__ __forceinline__ void nnf_xht_body(const float* __restrict__ X, int64_
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int rk = 16 * mt + 4 * g + reg;
-                    if (rk < r) out[(int64_t)rk * ldo + i] = acc[mt][nt][reg];
+                    if (rk < r) out[(int64_t)rk * ldo + (i - oshift)] = acc[mt][nt][reg];
                 }
         }
     }
@@ -459,7 +463,7 @@ __device__ __forceinline__ void nnf_xht_body(const float* __restrict__ X, int64_
                 x += __shfl_xor(x, 32, 64);
                 const int64_t i = i0w + 16 * nt + ii;
                 const int rk = 16 * MT + rr;
-                if (g == 0 && rk < r && i < m) out[(int64_t)rk * ldo + i] = x;
+                if (g == 0 && rk < r && i < m) out[(int64_t)rk * ldo + (i - oshift)] = x;
             }
     }
 }
@@ -471,7 +475,9 @@ __device__ __forceinline__ void nnf_xht_body(const float* __restrict__ X, int64_
 template <int MT, int REM, bool VEC, int NTH>
 __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 || NTH <= 2 ? 2 : 1)) void nnf_xht_kernel(const float* __restrict__ X, int64_t m, int64_t n, int64_t ldx,
                                                          const float* __restrict__ V, int64_t ldv, int r,
-                                                         float* __restrict__ out, int64_t ldo, int a_vec_ok, int n_hi) {
+                                                         float* __restrict__ out, int64_t ldo, int a_vec_ok, int n_hi,
+                                                         float* __restrict__ tail_slabs, int64_t tail_row0, int64_t tail_ld,
+                                                         int tail_tiles, int tail_parts, int tail_cpp) {
     constexpr int MTA = MT + (REM > 0 ? 1 : 0);
     __shared__ f32x4 ldsA[2][MTA * 256];
     const int b = (int)blockIdx.x;
@@ -480,10 +486,23 @@ __global__ __launch_bounds__(256, (MT + (REM > 0) <= 4 || NTH <= 2 ? 2 : 1)) voi
     else
         nnf_xht_body<MT, REM, VEC, NTH - 1>(X, m, n, ldx, V, ldv, r, out, ldo, a_vec_ok,
                                             (int64_t)n_hi * (64 * NTH) + (int64_t)(b - n_hi) * (64 * (NTH - 1)), ldsA);
+    // k-split tail (launch_xht): the row tiles that do not fill another whole round -- 106 of config B's 6250 -- are shared by ALL
+    // workgroups instead of making 27 of them a third longer: workgroup b takes chunk share p = b % parts of the four tiles
+    // 4 (b / parts) + wave, into slab p; the shares are added in share order by the usual slab reduction.
+    if (tail_parts > 0) {
+        const int p = b % tail_parts, tg = b / tail_parts;
+        if (4 * tg < tail_tiles) {
+            __syncthreads();
+            const int nchunk_all = (int)((n + 63) >> 6);
+            const int q0 = p * tail_cpp, q1 = (q0 + tail_cpp < nchunk_all) ? q0 + tail_cpp : nchunk_all;
+            nnf_xht_body<MT, REM, VEC, 1>(X, m, n, ldx, V, ldv, r, tail_slabs + (int64_t)p * r * tail_ld, tail_ld, a_vec_ok,
+                                          tail_row0 + 64 * (int64_t)tg, ldsA, q0 < q1 ? q0 : q1, q1, tail_row0);
+        }
+    }
 }
 
 template <int MT, int REM, bool VEC>
-static int launch_xht(nnf_ctx* ctx, nnf_ws_cursor&, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r, int64_t ldv,
+static int launch_xht(nnf_ctx* ctx, nnf_ws_cursor& cur, const float* X, int64_t m, int64_t n, int64_t ldx, const float* V, int r, int64_t ldv,
                       float* out, int64_t ldo, hipStream_t st) {
     if (64 * ldx * 4 + 4 * (n + 128) >= (int64_t)0x7fff0000) return NNF_ERR_UNSUPPORTED;
     const int a_vec_ok = ((((uintptr_t)V) & 15) == 0 && (ldv & 3) == 0) ? 1 : 0;
@@ -491,6 +510,9 @@ static int launch_xht(nnf_ctx* ctx, nnf_ws_cursor&, const float* X, int64_t m, i
     const int64_t T = nnf_cdiv(m, 16), waves = 4 * slots;
     int nth = 4;
     int64_t n_hi, grid;
+    float* tail_slabs = nullptr;
+    int64_t tail_row0 = 0, tail_ld = 0;
+    int tail_tiles = 0, tail_parts = 0, tail_cpp = 0;
     // six and more rank tiles (ranks 96 ... 128), many rounds: TWO row tiles per wave keep a wave at 248 registers, so that two
     // workgroups share a CU -- the four-tile form needs 404 (256 + 148 accumulation registers) and runs one wave per SIMD.
     // Measured (tools/probes/xht_nt2_probe.py, four -> two tiles): rank 100, 10^6 x 4000 7.16 -> 6.56 ms (0.71 -> 0.775 of the MFMA
@@ -508,25 +530,46 @@ static int launch_xht(nnf_ctx* ctx, nnf_ws_cursor&, const float* X, int64_t m, i
         nth = T > 3 * waves ? 4 : 3;
         n_hi = nnf_cdiv(T - 4 * (nth - 1) * slots, 4);
         grid = slots;
+        // few tiles beyond a whole round of nth - 1 per wave (config B: 106 beyond 6144): every workgroup stays at nth - 1 and the
+        // extra tiles are contracted in k-split shares by all of them -- 6 + 2 % on every SIMD instead of 7 tiles on the busiest.
+        // (Not for ranks <= 32: the LDS-staged form is bit for bit the unsplit kernel there, tests.  NNF_XHT_TAIL=0 switches it off.)
+        static const int tail_on = [] { const char* e = getenv("NNF_XHT_TAIL"); return e ? atoi(e) : 1; }();
+        const int64_t extra = T - 4 * (nth - 1) * slots, nchunk_all = nnf_cdiv(n, 64);
+        if (tail_on && MT + (REM > 0) >= 3 && extra > 0 && nchunk_all >= 4) {
+            int parts = 32;
+            while (parts > 1 && (parts > nchunk_all || 4 * (slots / parts) < extra)) parts >>= 1;
+            if (parts >= 4 && 4 * (slots / parts) >= extra && 8 * extra <= T) {
+                tail_parts = parts;
+                tail_tiles = (int)extra;
+                tail_cpp = (int)nnf_cdiv(nchunk_all, parts);
+                tail_row0 = 64 * (int64_t)(nth - 1) * slots;
+                tail_ld = nnf_rup(m - tail_row0, 4);
+                tail_slabs = (float*)cur.take((size_t)parts * r * tail_ld * 4);
+                if (tail_slabs) n_hi = 0;
+                else tail_parts = 0;
+            }
+        }
     } else {                        // small: 128-row workgroups
         nth = 3;
         n_hi = 0;
         grid = nnf_cdiv(m, 128);
     }
-    if (n_hi * 64 * nth + (grid - n_hi) * 64 * (nth - 1) < m) return NNF_ERR_UNSUPPORTED;   // (cannot happen: the split covers m by construction)
+    if (n_hi * 64 * nth + (grid - n_hi) * 64 * (nth - 1) + 16 * (int64_t)tail_tiles < m) return NNF_ERR_UNSUPPORTED;   // (cannot happen: the split covers m by construction)
     nnf_probe(ctx, NNF_PROBE_XHT, 0, st);
     if (nth == 4)
         hipLaunchKernelGGL((nnf_xht_kernel<MT, REM, VEC, 4>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
-                           a_vec_ok, (int)n_hi);
+                           a_vec_ok, (int)n_hi, tail_slabs, tail_row0, tail_ld, tail_tiles, tail_parts, tail_cpp);
     else if (nth == 2) {
         if constexpr (MT + (REM > 0) > 4)
             hipLaunchKernelGGL((nnf_xht_kernel<MT, REM, VEC, 2>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
-                               a_vec_ok, (int)n_hi);
+                               a_vec_ok, (int)n_hi, tail_slabs, tail_row0, tail_ld, tail_tiles, tail_parts, tail_cpp);
     } else
         hipLaunchKernelGGL((nnf_xht_kernel<MT, REM, VEC, 3>), dim3((int)grid), dim3(256), 0, st, X, m, n, ldx, V, ldv, r, out, ldo,
-                           a_vec_ok, (int)n_hi);
+                           a_vec_ok, (int)n_hi, tail_slabs, tail_row0, tail_ld, tail_tiles, tail_parts, tail_cpp);
     NNF_CHECK_LAUNCH();
     nnf_probe(ctx, NNF_PROBE_XHT, 1, st);
+    if (tail_parts > 0)    // the k-split shares of the last rows, added in share order
+        return nnf_launch_reduce_slabs(tail_slabs, tail_parts, (int64_t)r * tail_ld, r, m - tail_row0, tail_ld, out + tail_row0, ldo, st);
     return NNF_OK;
 }
 

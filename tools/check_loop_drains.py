@@ -23,18 +23,26 @@ def scan(path):
         dem = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True).stdout.strip().split("\n")
     res = {}
     for (i, name), dn in zip(starts, dem):
-        end = next((j for j in range(i, len(src)) if "s_endpgm" in src[j]), len(src))
+        # (to the end of the function, not to its first s_endpgm: a kernel with an early exit has several)
+        end = next((j for j in range(i, len(src)) if src[j].startswith(".Lfunc_end")), len(src))
         body = src[i:end]
         labels = {m.group(1): j for j, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
         out = []
+        segs = {}
         for j, l in enumerate(body):
             m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
             if m and labels.get(m.group(1), j) < j:
-                seg = body[labels[m.group(1)]:j]
-                nm = sum("v_mfma" in x for x in seg)
-                if nm >= 8:
-                    out.append(dict(lines=len(seg), mfma=nm, vmcnt0=sum("vmcnt(0)" in x for x in seg),
-                                    barriers=sum("s_barrier" in x for x in seg)))
+                a = labels[m.group(1)]
+                segs[a] = min(segs.get(a, j), j)          # (several back edges to one label: the shortest trip)
+        # innermost loops only: a back edge that spans another loop (an outer region the compiler laid out behind its exit
+        # blocks) would count that loop's prologue waits as if they sat inside the trip
+        inner = [(a, j) for a, j in segs.items() if not any(a < a2 and j2 < j for a2, j2 in segs.items())]
+        for a, j in sorted(inner):
+            seg = body[a:j]
+            nm = sum("v_mfma" in x for x in seg)
+            if nm >= 8:
+                out.append(dict(lines=len(seg), mfma=nm, vmcnt0=sum("vmcnt(0)" in x for x in seg),
+                                barriers=sum("s_barrier" in x for x in seg)))
         if out:
             res[dn] = out
     return res

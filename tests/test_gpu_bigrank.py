@@ -199,3 +199,16 @@ def test_ntf_at_rank_140_vs_oracle(built_lib, rule, beta):
     for a, b in zip(F, Fo):
         assert rel(a, b) < 1e-3
     np.testing.assert_allclose(costs, co, rtol=2e-3)
+
+
+def test_randomised_shapes_above_rank_128(built_lib):
+    """tools/probes/bigrank_stress.py: odd sizes, ragged last chunks (ranks 129 ... 400), every flag of the solve -- products and
+    costs within 3e-5 of float64, solves within 3e-4 of the oracle with equal sweep counts."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bigrank_stress", os.path.join(root, "tools", "probes", "bigrank_stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.run(cases=24, seed=3, verbose=False)
+    assert not bad, bad[:3]
